@@ -1,0 +1,165 @@
+/*
+ * rgcn_hip.h - C ABI of librgcn_hip.so: the MI355X (gfx950) R-GCN message-passing
+ * engine + DistMult scoring head.
+ *
+ * The reference (arnold117/PrimeKG-RGCN-LinkPrediction) has no FFI of its own: the
+ * path is reached through Python, `torch_geometric.nn.RGCNConv` constructed at
+ * src/models/rgcn.py:72-85 and called at rgcn.py:123,128, and `LinkPredictor.forward`
+ * (rgcn.py:189-213) called at rgcn.py:329.  Every entry point below names the
+ * torch-op sequence inside those calls that it replaces.
+ *
+ * Conventions
+ *  - plain C: pointers and sizes only, no torch types.  All data pointers are DEVICE
+ *    pointers unless the name ends in _host.  `stream` is a hipStream_t passed as void*.
+ *  - every function is asynchronous on `stream` and does no allocation, no host sync and
+ *    no host<->device copy (HIP-graph capturable), EXCEPT rgcn_graph_create /
+ *    rgcn_graph_destroy, the one-time bucketing of a static graph.
+ *  - inputs are borrowed and never written; outputs are caller-allocated.
+ *  - return value: RGCN_OK (0) or a negative RGCN_ERR_* code; rgcn_strerror() names it.
+ *    Nothing aborts the process.
+ *  - feature dims must be multiples of 4 floats (16-byte rows); fp32 throughout
+ *    ("within 1e-5 fp32 of PyG RGCNConv", BASELINE.json north_star).
+ */
+#ifndef RGCN_HIP_H
+#define RGCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGCN_ABI_VERSION 1
+
+enum {
+  RGCN_OK = 0,
+  RGCN_ERR_ARG = -1,          /* null pointer, negative size, dim not a multiple of 4 ... */
+  RGCN_ERR_RANGE = -2,        /* node id outside [0,N) or relation id outside [0,R) */
+  RGCN_ERR_HIP = -3,          /* a HIP runtime call failed */
+  RGCN_ERR_UNSUPPORTED = -4,  /* shape outside what the kernels were built for */
+  RGCN_ERR_WORKSPACE = -5     /* workspace pointer null or too small */
+};
+
+int rgcn_abi_version(void);
+const char* rgcn_strerror(int code);
+
+/* ------------------------------------------------------------------------------------
+ * Relation bucketing (row A2: `edge_index[:, edge_type == r]` for every r, done once).
+ *
+ * Builds, on the device, the two CSR-by-relation structures of a static multigraph:
+ *   forward    : segment s = dst*R + rel, col[] = src          (mean over in-edges)
+ *   transposed : segment s = src*R + rel, col_t[] = dst,
+ *                w_t[] = 1 / cnt[dst*R + rel]                  (what autograd of A4 scatters)
+ * via a STABLE radix sort of the edge columns, so inside every segment the edges keep the
+ * reference's order-preserving column selection (bit-exact integer work).  Also builds the
+ * chunked work lists the aggregate kernels walk (segments longer than 64 edges are split
+ * and tree-reduced so that degree skew cannot serialise a launch).
+ *
+ * edge_index: int64[2,E] row-major (row 0 = source j, row 1 = destination i);
+ * edge_type : int64[E].  Returns RGCN_ERR_RANGE (and *out = NULL) when any id is out of
+ * range - the reference filters those on the host (src/train.py:571-586).
+ * This call synchronises `stream` and allocates device memory owned by the handle.
+ * ---------------------------------------------------------------------------------- */
+typedef struct rgcn_graph rgcn_graph;
+
+int rgcn_graph_create(const int64_t* edge_index, const int64_t* edge_type, int64_t num_edges,
+                      int64_t num_nodes, int64_t num_relations, void* stream,
+                      rgcn_graph** out);
+void rgcn_graph_destroy(rgcn_graph* g);
+
+/* sizes */
+int64_t rgcn_graph_num_edges(const rgcn_graph* g);
+int64_t rgcn_graph_num_nodes(const rgcn_graph* g);
+int64_t rgcn_graph_num_relations(const rgcn_graph* g);
+/* number of aggregate launches (tree levels) one rgcn_aggregate call issues */
+int rgcn_graph_num_levels(const rgcn_graph* g, int transposed);
+
+/* Device views of the bucketed arrays (for parity tests and sidecar files):
+ *   rowptr int32[N*R+1], col int32[E], perm int64[E] (original column of each bucketed
+ *   edge), val float32: cnt[N*R] = max(1, segment size) when transposed == 0,
+ *   w_t[E] when transposed == 1.  The pointers stay owned by the handle. */
+int rgcn_graph_arrays(const rgcn_graph* g, int transposed, const int32_t** rowptr,
+                      const int32_t** col, const int64_t** perm, const float** val);
+/* Same arrays copied (device to device, async on `stream`) into caller buffers of the sizes
+ * above; any destination may be NULL. */
+int rgcn_graph_export(const rgcn_graph* g, int transposed, int32_t* rowptr, int32_t* col,
+                      int64_t* perm, float* val, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Gather + per-(node, relation) aggregation (rows A3 + A4, and their autograd, row A7).
+ *
+ *   transposed == 0:  agg[i*R + r, :] = (sum over edges e = (j -> i, r) of x[j, :]) / cnt[i, r]
+ *                     (`index_select` + `scatter_add_` + count + clamp(min=1) + divide)
+ *   transposed == 1:  agg[j*R + r, :] = sum over edges e = (j -> i, r) of x[i, :] * w_t[e]
+ *
+ * x: float[N, d] (ld = d), agg: float[N*R, d].  d % 4 == 0.  Segments with no edge are
+ * written as exact zeros.  Summation inside a segment runs in the bucketed (= original
+ * column) order for segments of <= 64 edges; longer ones are summed as a fixed tree of
+ * 64-edge chunks, so the result is run-to-run deterministic.
+ * `workspace` holds the chunk partial sums: rgcn_aggregate_workspace_bytes(g, t, d).
+ * ---------------------------------------------------------------------------------- */
+size_t rgcn_aggregate_workspace_bytes(const rgcn_graph* g, int transposed, int64_t d);
+int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Per-relation transform + root + bias (row A6), fp32 MFMA (v_mfma_f32_32x32x2_f32):
+ *
+ *   out[N, d_out] = sum_r agg[:, r, :] @ weight[r] + x @ root + bias
+ *
+ * agg: float[N, R*d_in], x: float[N, d_in], weight: float[R, d_in, d_out] (PyG layout),
+ * root: float[d_in, d_out] or NULL, bias: float[d_out] or NULL.
+ * `workspace` (rgcn_transform_workspace_bytes) holds the k-contiguous repack of the
+ * weights that the MFMA B-operand reads.
+ * ---------------------------------------------------------------------------------- */
+size_t rgcn_transform_workspace_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
+int rgcn_transform_fwd(const float* agg, const float* x, const float* weight, const float* root,
+                       const float* bias, int64_t num_nodes, int64_t num_relations, int64_t d_in,
+                       int64_t d_out, float* out, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* Autograd of A6 with respect to the layer input (row A7):
+ *   grad_x[N, d_in] = sum_r gagg[:, r, :] @ weight[r]^T + g @ root^T
+ * gagg: float[N, R*d_out] = rgcn_aggregate(transposed = 1) of g; g: float[N, d_out]. */
+int rgcn_transform_bwd_input(const float* gagg, const float* g, const float* weight,
+                             const float* root, int64_t num_nodes, int64_t num_relations,
+                             int64_t d_in, int64_t d_out, float* grad_x, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* Autograd of A6 with respect to the parameters (row A7):
+ *   grad_weight[r] = agg[:, r, :]^T @ g,  grad_root = x^T @ g,  grad_bias = colsum(g)
+ * Split over node ranges into fp32 slabs that a second kernel sums in a fixed order
+ * (deterministic; no float atomics).  grad_root / grad_bias may be NULL. */
+size_t rgcn_transform_bwd_params_workspace_bytes(int64_t num_nodes, int64_t num_relations,
+                                                 int64_t d_in, int64_t d_out);
+int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, int64_t num_nodes,
+                              int64_t num_relations, int64_t d_in, int64_t d_out,
+                              float* grad_weight, float* grad_root, float* grad_bias,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DistMult head (rows C1 + C2; rgcn.py:325-326 row gathers + rgcn.py:207-211):
+ *
+ *   scores[b] = sum_d H[hi(b), d] * Rm[ri(b), d] * T[ti(b), d]
+ *
+ * Each operand is a float matrix with row length d plus an optional int64 index vector;
+ * a NULL index means "row b".  So (emb, head_idx), (emb, tail_idx), (rel_table, rel_idx)
+ * is the fused gather form, and (head_emb, NULL), (tail_emb, NULL), (rel_rows, NULL) is
+ * LinkPredictor.forward on already-gathered rows (e.g. after relation dropout).
+ * ---------------------------------------------------------------------------------- */
+int distmult_fwd(const float* h, const int64_t* h_idx, const float* t, const int64_t* t_idx,
+                 const float* r, const int64_t* r_idx, int64_t batch, int64_t d, float* scores,
+                 void* stream);
+
+/* Backward: grad_h[hi(b), :] += gs[b] * r * t, etc.  Rows reached through an index vector
+ * are accumulated with fp32 atomics into buffers the caller has zeroed (duplicates in
+ * head/tail are legal); a NULL index writes row b directly.  Any grad pointer may be NULL. */
+int distmult_bwd(const float* grad_scores, const float* h, const int64_t* h_idx, const float* t,
+                 const int64_t* t_idx, const float* r, const int64_t* r_idx, int64_t batch,
+                 int64_t d, float* grad_h, float* grad_t, float* grad_r, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGCN_HIP_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of ``librgcn_hip.so`` (C ABI declared in ``include/rgcn_hip.h``).
+
+There is no CPU fallback: if the library is missing, or was built against another
+ABI version, every compute entry point raises.  ``import torch`` must precede the
+``dlopen`` so that the HIP runtime already in the process (torch's bundled
+``libamdhip64.so.7``) satisfies the library's NEEDED entry by soname.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_p
+
+import torch  # noqa: F401  (loads the HIP runtime first)
+
+ABI_VERSION = 1
+LIB_NAME = "librgcn_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+RGCN_OK = 0
+RGCN_ERR_ARG = -1
+RGCN_ERR_RANGE = -2
+RGCN_ERR_HIP = -3
+RGCN_ERR_UNSUPPORTED = -4
+RGCN_ERR_WORKSPACE = -5
+
+_P = c_void_p      # device pointers travel as integers (tensor.data_ptr())
+_I64 = c_int64
+
+# name -> (restype, argtypes); mirrors include/rgcn_hip.h one to one
+PROTOTYPES = {
+    "rgcn_abi_version": (c_int, []),
+    "rgcn_strerror": (c_char_p, [c_int]),
+    "rgcn_graph_create": (c_int, [_P, _P, _I64, _I64, _I64, _P, POINTER(c_void_p)]),
+    "rgcn_graph_destroy": (None, [c_void_p]),
+    "rgcn_graph_num_edges": (_I64, [c_void_p]),
+    "rgcn_graph_num_nodes": (_I64, [c_void_p]),
+    "rgcn_graph_num_relations": (_I64, [c_void_p]),
+    "rgcn_graph_num_levels": (c_int, [c_void_p, c_int]),
+    "rgcn_graph_arrays": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p),
+                                  POINTER(c_void_p), POINTER(c_void_p)]),
+    "rgcn_graph_export": (c_int, [c_void_p, c_int, _P, _P, _P, _P, _P]),
+    "rgcn_aggregate_workspace_bytes": (c_size_t, [c_void_p, c_int, _I64]),
+    "rgcn_aggregate": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, _P]),
+    "rgcn_transform_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),
+    "rgcn_transform_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, c_size_t, _P]),
+    "rgcn_transform_bwd_input": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, c_size_t, _P]),
+    "rgcn_transform_bwd_params_workspace_bytes": (c_size_t, [_I64, _I64, _I64, _I64]),
+    "rgcn_transform_bwd_params": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P,
+                                          c_size_t, _P]),
+    "distmult_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "distmult_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class RGCNLibraryError(RuntimeError):
+    """The HIP library is missing / unloadable / of the wrong ABI."""
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the library once and type every entry point.  Raises loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RGCNLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C primekg_rgcn_linkprediction_amd/csrc`). There is no "
+            f"CPU/PyTorch fallback for the R-GCN path.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as exc:  # pragma: no cover - depends on the host
+        raise RGCNLibraryError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise RGCNLibraryError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.rgcn_abi_version()
+    if got != ABI_VERSION:
+        raise RGCNLibraryError(f"{LIB_PATH} has ABI version {got}, host code expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def available() -> bool:
+    try:
+        load()
+        return True
+    except RGCNLibraryError:
+        return False
+
+
+def strerror(code: int) -> str:
+    return load().rgcn_strerror(code).decode()
+
+
+def check(code: int, what: str) -> None:
+    """Map a C return code to the Python exception the reference's stack would raise."""
+    if code == RGCN_OK:
+        return
+    msg = f"{what}: {strerror(code)} (code {code})"
+    if code == RGCN_ERR_RANGE:
+        raise IndexError(msg)
+    if code in (RGCN_ERR_ARG, RGCN_ERR_UNSUPPORTED):
+        raise ValueError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,158 @@
+"""``RGCNConv``: drop-in for ``torch_geometric.nn.RGCNConv`` as the reference uses it
+(imported at ``src/models/rgcn.py:17``, built at ``rgcn.py:72-85`` with
+``in_channels, out_channels, num_relations, num_bases``; called at ``rgcn.py:123,128``
+as ``conv(x, edge_index, edge_type)``).
+
+Same constructor signature, same registered parameter names/shapes (``weight``,
+``comp``, ``root``, ``bias`` -> state-dict keys ``encoder.conv1.weight`` ... so the
+reference's checkpoints load, ``src/evaluate.py:686-708``), same init
+(glorot / zeros).  The arithmetic runs in ``librgcn_hip.so``:
+
+    forward : bucket (cached, once per graph) -> gather+mean -> one fp32-MFMA GEMM
+    backward: params GEMM (split over node ranges) ; transposed gather -> input GEMM
+
+There is no CPU path and no PyG / torch_scatter fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+
+
+def _glorot(t: Optional[Tensor]) -> None:
+    # PyG nn.inits.glorot: U(-a, a), a = sqrt(6 / (size(-2) + size(-1)))
+    if t is not None:
+        bound = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+        t.data.uniform_(-bound, bound)
+
+
+class _RGCNConvFunction(torch.autograd.Function):
+    """x, weight[R, d_in, d_out], root, bias -> out, on a bucketed graph."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
+                graph: ops.BucketedGraph) -> Tensor:
+        x = x.contiguous()
+        weight = weight.contiguous()
+        root_c = root.contiguous() if root is not None else None
+        bias_c = bias.contiguous() if bias is not None else None
+        agg = ops.aggregate(graph, x, transposed=False)                 # rows A3 + A4
+        out = ops.transform_fwd(agg, x, weight, root_c, bias_c)         # row A6
+        ctx.graph = graph
+        ctx.has_root, ctx.has_bias = root is not None, bias is not None
+        ctx.save_for_backward(x, agg, weight, root_c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        x, agg, weight, root = ctx.saved_tensors
+        graph = ctx.graph
+        g = g.contiguous()
+        need_x, need_w, need_root, need_bias = ctx.needs_input_grad[:4]
+        gx = gw = groot = gbias = None
+        if need_w or (need_root and ctx.has_root) or (need_bias and ctx.has_bias):
+            gw, groot, gbias = ops.transform_bwd_params(
+                agg, x, g, graph.num_relations, want_root=ctx.has_root, want_bias=ctx.has_bias)
+        if need_x:
+            gagg = ops.aggregate(graph, g, transposed=True)             # autograd of A3 + A4
+            gx = ops.transform_bwd_input(gagg, g, weight, root)         # autograd of A6 wrt x
+        return gx, gw, groot, gbias, None
+
+
+def rgcn_conv(x: Tensor, edge_index: Tensor, edge_type: Tensor, weight: Tensor,
+              root: Optional[Tensor], bias: Optional[Tensor], num_relations: int) -> Tensor:
+    """Functional form on effective weights ``[R, d_in, d_out]``."""
+    if x.dtype != torch.float32:
+        raise TypeError(f"x must be float32 (got {x.dtype}); integer-index / embedding mode of "
+                        f"PyG's RGCNConv is not used by the reference and not implemented")
+    graph = ops.bucket(edge_index, edge_type, x.size(0), num_relations)
+    return _RGCNConvFunction.apply(x, weight, root, bias, graph)
+
+
+class RGCNConv(nn.Module):
+    r"""Relational graph convolution, mean aggregation per (destination, relation):
+
+    .. math:: x'_i = \Theta_{root} x_i + \sum_r \frac{1}{|N_r(i)|} \sum_{j \in N_r(i)} \Theta_r x_j + b
+
+    Messages flow ``edge_index[0] -> edge_index[1]``; duplicate edges count once each;
+    no self loops are added; an empty ``(i, r)`` contributes exactly 0.
+    """
+
+    def __init__(self, in_channels: Union[int, Tuple[int, int]], out_channels: int,
+                 num_relations: int, num_bases: Optional[int] = None,
+                 num_blocks: Optional[int] = None, aggr: str = "mean", root_weight: bool = True,
+                 is_sorted: bool = False, bias: bool = True, **kwargs):
+        super().__init__()
+        if num_bases is not None and num_blocks is not None:
+            raise ValueError("Can not apply both basis-decomposition and "
+                             "block-diagonal-decomposition at the same time.")
+        if num_blocks is not None:
+            raise NotImplementedError("block-diagonal decomposition is not used by the reference "
+                                      "(rgcn.py:72-85) and is not implemented")
+        if aggr != "mean":
+            raise NotImplementedError(f"aggr={aggr!r}: only PyG's default 'mean' is implemented")
+        if kwargs:
+            raise TypeError(f"unexpected keyword arguments: {sorted(kwargs)}")
+        if isinstance(in_channels, int):
+            in_channels = (in_channels, in_channels)
+        if in_channels[0] != in_channels[1]:
+            raise NotImplementedError("bipartite (x_l, x_r) inputs are not implemented")
+        self.in_channels = in_channels
+        self.in_channels_l = in_channels[0]
+        self.out_channels = out_channels
+        self.num_relations = num_relations
+        self.num_bases = num_bases
+        self.num_blocks = num_blocks
+        self.is_sorted = is_sorted      # accepted; bucketing makes it irrelevant
+
+        if num_bases is not None:
+            self.weight = nn.Parameter(torch.empty(num_bases, in_channels[0], out_channels))
+            self.comp = nn.Parameter(torch.empty(num_relations, num_bases))
+        else:
+            self.weight = nn.Parameter(torch.empty(num_relations, in_channels[0], out_channels))
+            self.register_parameter("comp", None)
+        if root_weight:
+            self.root = nn.Parameter(torch.empty(in_channels[1], out_channels))
+        else:
+            self.register_parameter("root", None)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        _glorot(self.weight)
+        _glorot(self.comp)
+        _glorot(self.root)
+        if self.bias is not None:
+            self.bias.data.zero_()
+
+    def effective_weight(self) -> Tensor:
+        """``weight`` or the basis composition (row A5; left to torch/autograd: it is a
+        [R, B] x [B, d_in*d_out] product, negligible next to the layer)."""
+        if self.num_bases is None:
+            return self.weight
+        return (self.comp @ self.weight.view(self.num_bases, -1)).view(
+            self.num_relations, self.in_channels_l, self.out_channels)
+
+    def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None) -> Tensor:
+        if isinstance(x, (tuple, list)) or x is None:
+            raise NotImplementedError("x must be a float tensor [N, in_channels]")
+        if not isinstance(edge_index, Tensor):
+            raise NotImplementedError("SparseTensor adjacency is not implemented")
+        assert edge_type is not None, "edge_type is required"
+        if x.dim() != 2 or x.size(1) != self.in_channels_l:
+            raise ValueError(f"x must be [N, {self.in_channels_l}], got {tuple(x.shape)}")
+        return rgcn_conv(x, edge_index, edge_type, self.effective_weight(), self.root, self.bias,
+                         self.num_relations)
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}({self.in_channels_l}, {self.out_channels}, "
+                f"num_relations={self.num_relations})")

@@ -1,0 +1,44 @@
+// Shared declarations for librgcn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rgcn_hip.h"
+
+#define RGCN_HIP_TRY(expr)                       \
+  do {                                           \
+    hipError_t err__ = (expr);                   \
+    if (err__ != hipSuccess) return RGCN_ERR_HIP; \
+  } while (0)
+
+// Longest run of source rows one lane group sums sequentially.  At ~1 us per dependent
+// round trip and 8 rows in flight per group this bounds a work item to a few us, which is
+// what keeps a 25-50 us gather launch free of a straggler tail under Zipf-like degree skew.
+constexpr int RGCN_CHUNK = 64;
+constexpr int RGCN_MAX_LEVELS = 8;
+
+// One unit of aggregate work: sum source rows [begin, end) into row `dst`.
+//   level 0 : source rows are x[col[e]] for e in [begin, end)
+//   level>0 : source rows are partial[begin .. end) (contiguous)
+//   flags&1 : `dst` is a final segment row of agg (apply the mean divide), otherwise a row
+//             of the partial-sum workspace.
+struct rgcn_item {
+  int32_t begin, end, dst, flags;
+};
+
+struct rgcn_csr {
+  int32_t* rowptr = nullptr;  // [N*R+1]
+  int32_t* col = nullptr;     // [E]  the other endpoint
+  int64_t* perm = nullptr;    // [E]  original column of each bucketed edge
+  float* val = nullptr;       // cnt[N*R] (forward) or w_t[E] (transposed)
+  int num_levels = 0;
+  rgcn_item* items[RGCN_MAX_LEVELS] = {};
+  int64_t num_items[RGCN_MAX_LEVELS] = {};
+  int64_t num_partials = 0;   // rows of partial-sum workspace (all levels)
+};
+
+struct rgcn_graph {
+  int64_t E = 0, N = 0, R = 0;
+  rgcn_csr dir[2];  // [0] forward (dst,rel), [1] transposed (src,rel)
+};
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,292 @@
+// Relation bucketing of a static multigraph + the chunked work plan the aggregate kernels
+// walk.  Replaces, once per graph, what PyG's RGCNConv.forward redoes on every call:
+// `edge_index[:, edge_type == r]` for each r (reference call sites src/models/rgcn.py:123,128;
+// SURVEY.md section 8a row A2) and the count pass of the mean aggregation (row A4).
+//
+// Integer work, bit exact: a stable LSD radix sort (rocPRIM through hipCUB) of
+// key = node*R + rel keeps the original column order inside every (node, rel) segment.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "rgcn_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__global__ void k_validate(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ edge_type,
+                           int64_t E, int64_t N, int64_t R, int* __restrict__ flag) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t s = edge_index[e], d = edge_index[E + e], t = edge_type[e];
+  if (s < 0 || s >= N || d < 0 || d >= N || t < 0 || t >= R) atomicOr(flag, 1);
+}
+
+// key = node*R + rel with node = destination (forward) or source (transposed).
+__global__ void k_make_keys(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ edge_type,
+                            int64_t E, int64_t R, int transposed, uint32_t* __restrict__ keys,
+                            uint32_t* __restrict__ ids) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t node = transposed ? edge_index[e] : edge_index[E + e];
+  keys[e] = (uint32_t)(node * R + edge_type[e]);
+  ids[e] = (uint32_t)e;
+}
+
+// rowptr[k] = first sorted position whose key is >= k.  Position e owns the keys in
+// (key[e-1], key[e]]; position E owns (key[E-1], NR].  Every entry is written exactly once.
+__global__ void k_rowptr(const uint32_t* __restrict__ skeys, int64_t E, int64_t NR,
+                         int32_t* __restrict__ rowptr) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e > E) return;
+  int64_t lo = (e == 0) ? 0 : (int64_t)skeys[e - 1] + 1;
+  int64_t hi = (e == E) ? NR : (int64_t)skeys[e];
+  for (int64_t k = lo; k <= hi; ++k) rowptr[k] = (int32_t)e;
+}
+
+__global__ void k_fill_edges(const int64_t* __restrict__ edge_index, int64_t E, int transposed,
+                             const uint32_t* __restrict__ sids, int32_t* __restrict__ col,
+                             int64_t* __restrict__ perm) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  uint32_t p = sids[e];
+  perm[e] = (int64_t)p;
+  col[e] = (int32_t)(transposed ? edge_index[E + p] : edge_index[p]);
+}
+
+__global__ void k_counts(const int32_t* __restrict__ rowptr, int64_t NR, float* __restrict__ cnt) {
+  int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= NR) return;
+  int deg = rowptr[s + 1] - rowptr[s];
+  cnt[s] = (float)(deg < 1 ? 1 : deg);   // clamp(min=1)
+}
+
+// w_t[e] = 1 / cnt[dst*R + rel] for the transposed order (dst = col_t[e], rel = key % R).
+__global__ void k_edge_weights(const uint32_t* __restrict__ skeys_t, const int32_t* __restrict__ col_t,
+                               const float* __restrict__ cnt, int64_t E, int64_t R,
+                               float* __restrict__ w) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t rel = (int64_t)(skeys_t[e] % (uint32_t)R);
+  w[e] = 1.0f / cnt[(int64_t)col_t[e] * R + rel];
+}
+
+inline unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, ceil_div64(n, kThreads)); }
+
+// Host-side plan: split every segment into runs of <= RGCN_CHUNK source rows; runs of a
+// multi-run segment write partial sums that the next level reduces the same way, until one
+// run is left.  Inside a level the items are ordered by descending length so that the lane
+// groups of one wavefront finish together (no divergence tail) and long items start first.
+int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, rgcn_csr* csr) {
+  struct Pending { int32_t seg, begin, end; };
+  std::vector<std::vector<rgcn_item>> levels;
+  std::vector<Pending> pending, next;
+  int64_t partial_rows = 0;
+
+  auto emit = [&](std::vector<rgcn_item>& out, std::vector<Pending>& nxt, int32_t seg,
+                  int32_t begin, int32_t end) {
+    int32_t len = end - begin;
+    if (len <= RGCN_CHUNK) {
+      out.push_back({begin, end, seg, 1});
+      return;
+    }
+    int32_t nch = (int32_t)ceil_div64(len, RGCN_CHUNK);
+    int32_t pbase = (int32_t)partial_rows;
+    for (int32_t c = 0; c < nch; ++c) {
+      int32_t b = begin + c * RGCN_CHUNK;
+      out.push_back({b, std::min(b + RGCN_CHUNK, end), pbase + c, 0});
+    }
+    partial_rows += nch;
+    nxt.push_back({seg, pbase, pbase + nch});
+  };
+
+  levels.emplace_back();
+  levels[0].reserve((size_t)NR + 16);
+  for (int64_t s = 0; s < NR; ++s) emit(levels[0], pending, (int32_t)s, rowptr[s], rowptr[s + 1]);
+  while (!pending.empty()) {
+    if ((int)levels.size() >= RGCN_MAX_LEVELS) return RGCN_ERR_UNSUPPORTED;
+    levels.emplace_back();
+    next.clear();
+    for (const Pending& p : pending) emit(levels.back(), next, p.seg, p.begin, p.end);
+    pending.swap(next);
+  }
+  if (partial_rows > INT32_MAX) return RGCN_ERR_UNSUPPORTED;
+
+  csr->num_levels = (int)levels.size();
+  csr->num_partials = partial_rows;
+  for (int l = 0; l < csr->num_levels; ++l) {
+    auto& v = levels[l];
+    std::stable_sort(v.begin(), v.end(), [](const rgcn_item& a, const rgcn_item& b) {
+      return (a.end - a.begin) > (b.end - b.begin);
+    });
+    csr->num_items[l] = (int64_t)v.size();
+    if (v.empty()) continue;
+    RGCN_HIP_TRY(hipMalloc((void**)&csr->items[l], v.size() * sizeof(rgcn_item)));
+    RGCN_HIP_TRY(hipMemcpy(csr->items[l], v.data(), v.size() * sizeof(rgcn_item), hipMemcpyHostToDevice));
+  }
+  return RGCN_OK;
+}
+
+void free_csr(rgcn_csr* c) {
+  (void)hipFree(c->rowptr);
+  (void)hipFree(c->col);
+  (void)hipFree(c->perm);
+  (void)hipFree(c->val);
+  for (int l = 0; l < RGCN_MAX_LEVELS; ++l) (void)hipFree(c->items[l]);
+  *c = rgcn_csr();
+}
+
+struct Scratch {
+  uint32_t *keys = nullptr, *ids = nullptr, *skeys[2] = {nullptr, nullptr}, *sids = nullptr;
+  void* sort_tmp = nullptr;
+  int* flag = nullptr;
+  ~Scratch() {
+    (void)hipFree(keys); (void)hipFree(ids); (void)hipFree(skeys[0]); (void)hipFree(skeys[1]);
+    (void)hipFree(sids); (void)hipFree(sort_tmp); (void)hipFree(flag);
+  }
+};
+
+int create_impl(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t N, int64_t R,
+                hipStream_t stream, rgcn_graph* g) {
+  const int64_t NR = N * R;
+  g->E = E; g->N = N; g->R = R;
+  Scratch sc;
+  RGCN_HIP_TRY(hipMalloc((void**)&sc.flag, sizeof(int)));
+  RGCN_HIP_TRY(hipMemsetAsync(sc.flag, 0, sizeof(int), stream));
+  if (E > 0) {
+    k_validate<<<grid_for(E), kThreads, 0, stream>>>(edge_index, edge_type, E, N, R, sc.flag);
+    int host_flag = 0;
+    RGCN_HIP_TRY(hipMemcpyAsync(&host_flag, sc.flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RGCN_HIP_TRY(hipStreamSynchronize(stream));
+    if (host_flag) return RGCN_ERR_RANGE;
+
+    RGCN_HIP_TRY(hipMalloc((void**)&sc.keys, E * sizeof(uint32_t)));
+    RGCN_HIP_TRY(hipMalloc((void**)&sc.ids, E * sizeof(uint32_t)));
+    RGCN_HIP_TRY(hipMalloc((void**)&sc.skeys[0], E * sizeof(uint32_t)));
+    RGCN_HIP_TRY(hipMalloc((void**)&sc.skeys[1], E * sizeof(uint32_t)));
+    RGCN_HIP_TRY(hipMalloc((void**)&sc.sids, E * sizeof(uint32_t)));
+  }
+  int end_bit = 1;
+  while (end_bit < 32 && ((int64_t)1 << end_bit) < NR) ++end_bit;
+
+  for (int t = 0; t < 2; ++t) {
+    rgcn_csr* c = &g->dir[t];
+    RGCN_HIP_TRY(hipMalloc((void**)&c->rowptr, (NR + 1) * sizeof(int32_t)));
+    if (E > 0) {
+      RGCN_HIP_TRY(hipMalloc((void**)&c->col, E * sizeof(int32_t)));
+      RGCN_HIP_TRY(hipMalloc((void**)&c->perm, E * sizeof(int64_t)));
+      k_make_keys<<<grid_for(E), kThreads, 0, stream>>>(edge_index, edge_type, E, R, t, sc.keys, sc.ids);
+      size_t tmp_bytes = 0;
+      RGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, sc.keys, sc.skeys[t], sc.ids,
+                                                       sc.sids, (int)E, 0, end_bit, stream));
+      if (!sc.sort_tmp) RGCN_HIP_TRY(hipMalloc(&sc.sort_tmp, tmp_bytes + 256));
+      RGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sc.sort_tmp, tmp_bytes, sc.keys, sc.skeys[t], sc.ids,
+                                                       sc.sids, (int)E, 0, end_bit, stream));
+      k_rowptr<<<grid_for(E + 1), kThreads, 0, stream>>>(sc.skeys[t], E, NR, c->rowptr);
+      k_fill_edges<<<grid_for(E), kThreads, 0, stream>>>(edge_index, E, t, sc.sids, c->col, c->perm);
+    } else {
+      RGCN_HIP_TRY(hipMemsetAsync(c->rowptr, 0, (NR + 1) * sizeof(int32_t), stream));
+    }
+  }
+  // forward: cnt[N*R]; transposed: per-edge 1/cnt[dst, rel]
+  RGCN_HIP_TRY(hipMalloc((void**)&g->dir[0].val, std::max<int64_t>(NR, 1) * sizeof(float)));
+  if (NR > 0) k_counts<<<grid_for(NR), kThreads, 0, stream>>>(g->dir[0].rowptr, NR, g->dir[0].val);
+  if (E > 0) {
+    RGCN_HIP_TRY(hipMalloc((void**)&g->dir[1].val, E * sizeof(float)));
+    k_edge_weights<<<grid_for(E), kThreads, 0, stream>>>(sc.skeys[1], g->dir[1].col, g->dir[0].val, E, R,
+                                                         g->dir[1].val);
+  }
+  RGCN_HIP_TRY(hipGetLastError());
+
+  std::vector<int32_t> rp((size_t)NR + 1);
+  for (int t = 0; t < 2; ++t) {
+    RGCN_HIP_TRY(hipMemcpyAsync(rp.data(), g->dir[t].rowptr, (NR + 1) * sizeof(int32_t),
+                                hipMemcpyDeviceToHost, stream));
+    RGCN_HIP_TRY(hipStreamSynchronize(stream));
+    int rc = build_plan(rp, NR, &g->dir[t]);
+    if (rc != RGCN_OK) return rc;
+  }
+  RGCN_HIP_TRY(hipStreamSynchronize(stream));
+  return RGCN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rgcn_abi_version(void) { return RGCN_ABI_VERSION; }
+
+const char* rgcn_strerror(int code) {
+  switch (code) {
+    case RGCN_OK: return "ok";
+    case RGCN_ERR_ARG: return "invalid argument (null pointer, negative size, or feature dim not a multiple of 4)";
+    case RGCN_ERR_RANGE: return "edge_index / edge_type holds an id outside [0, num_nodes) / [0, num_relations)";
+    case RGCN_ERR_HIP: return "HIP runtime call failed";
+    case RGCN_ERR_UNSUPPORTED: return "shape not supported by this build";
+    case RGCN_ERR_WORKSPACE: return "workspace missing or too small";
+    default: return "unknown error code";
+  }
+}
+
+int rgcn_graph_create(const int64_t* edge_index, const int64_t* edge_type, int64_t num_edges,
+                      int64_t num_nodes, int64_t num_relations, void* stream, rgcn_graph** out) {
+  if (!out) return RGCN_ERR_ARG;
+  *out = nullptr;
+  if (num_edges < 0 || num_nodes < 0 || num_relations <= 0) return RGCN_ERR_ARG;
+  if (num_edges > 0 && (!edge_index || !edge_type)) return RGCN_ERR_ARG;
+  if (num_nodes * num_relations >= ((int64_t)1 << 31) - 1 || num_edges >= ((int64_t)1 << 31) - 1)
+    return RGCN_ERR_UNSUPPORTED;
+  rgcn_graph* g = new (std::nothrow) rgcn_graph();
+  if (!g) return RGCN_ERR_HIP;
+  int rc = create_impl(edge_index, edge_type, num_edges, num_nodes, num_relations, (hipStream_t)stream, g);
+  if (rc != RGCN_OK) {
+    rgcn_graph_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return RGCN_OK;
+}
+
+void rgcn_graph_destroy(rgcn_graph* g) {
+  if (!g) return;
+  free_csr(&g->dir[0]);
+  free_csr(&g->dir[1]);
+  delete g;
+}
+
+int64_t rgcn_graph_num_edges(const rgcn_graph* g) { return g ? g->E : -1; }
+int64_t rgcn_graph_num_nodes(const rgcn_graph* g) { return g ? g->N : -1; }
+int64_t rgcn_graph_num_relations(const rgcn_graph* g) { return g ? g->R : -1; }
+int rgcn_graph_num_levels(const rgcn_graph* g, int transposed) {
+  return g ? g->dir[transposed ? 1 : 0].num_levels : -1;
+}
+
+int rgcn_graph_arrays(const rgcn_graph* g, int transposed, const int32_t** rowptr, const int32_t** col,
+                      const int64_t** perm, const float** val) {
+  if (!g) return RGCN_ERR_ARG;
+  const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
+  if (rowptr) *rowptr = c->rowptr;
+  if (col) *col = c->col;
+  if (perm) *perm = c->perm;
+  if (val) *val = c->val;
+  return RGCN_OK;
+}
+
+int rgcn_graph_export(const rgcn_graph* g, int transposed, int32_t* rowptr, int32_t* col, int64_t* perm,
+                      float* val, void* stream_) {
+  if (!g) return RGCN_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
+  const size_t nr = (size_t)(g->N * g->R), e = (size_t)g->E;
+  if (rowptr) RGCN_HIP_TRY(hipMemcpyAsync(rowptr, c->rowptr, (nr + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+  if (col && e) RGCN_HIP_TRY(hipMemcpyAsync(col, c->col, e * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+  if (perm && e) RGCN_HIP_TRY(hipMemcpyAsync(perm, c->perm, e * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+  const size_t nval = transposed ? e : nr;
+  if (val && nval) RGCN_HIP_TRY(hipMemcpyAsync(val, c->val, nval * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  return RGCN_OK;
+}
+
+}  // extern "C"

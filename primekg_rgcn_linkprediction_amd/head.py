@@ -1,0 +1,108 @@
+"""DistMult scoring head on the HIP library.
+
+Mirror of the reference's ``LinkPredictor`` (``src/models/rgcn.py:145-243``): same
+constructor ``(num_relations, embedding_dim, dropout=0.0)``, same parameter
+(``relation_embeddings.weight`` [R, d], xavier-uniform), same methods
+``forward(head_embeddings, tail_embeddings, relation_types)`` and
+``score_all_tails(head_embeddings, relation_types, all_tail_embeddings)``.
+
+Extra entry ``score_triples(node_embeddings, head_idx, tail_idx, relation_types)`` fuses
+the two row gathers of ``rgcn.py:325-326`` into the scoring kernel (SURVEY row C1 + C2).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+
+
+class _DistMultFunction(torch.autograd.Function):
+    """scores[b] = sum_d H[hi(b)] * Rm[ri(b)] * T[ti(b)]; an index of None means row b."""
+
+    @staticmethod
+    def forward(ctx, h: Tensor, h_idx: Optional[Tensor], t: Tensor, t_idx: Optional[Tensor],
+                r: Tensor, r_idx: Optional[Tensor]) -> Tensor:
+        h, t, r = h.contiguous(), t.contiguous(), r.contiguous()
+        h_idx = h_idx.contiguous() if h_idx is not None else None
+        t_idx = t_idx.contiguous() if t_idx is not None else None
+        r_idx = r_idx.contiguous() if r_idx is not None else None
+        batch = (h_idx if h_idx is not None else h).size(0)
+        scores = ops.distmult_fwd(h, h_idx, t, t_idx, r, r_idx, batch)
+        ctx.batch = batch
+        ctx.same_ht = h.data_ptr() == t.data_ptr() and h.shape == t.shape
+        ctx.save_for_backward(h, h_idx, t, t_idx, r, r_idx)
+        return scores
+
+    @staticmethod
+    def backward(ctx, gs: Tensor):
+        h, h_idx, t, t_idx, r, r_idx = ctx.saved_tensors
+        gs = gs.contiguous()
+        need_h, _, need_t, _, need_r, _ = ctx.needs_input_grad
+
+        def buf(src, idx, need):
+            if not need:
+                return None
+            return torch.zeros_like(src) if idx is not None else torch.empty_like(src)
+
+        gh = buf(h, h_idx, need_h)
+        # head and tail gathered from one table: accumulate both into one buffer
+        shared = ctx.same_ht and need_h and need_t and h_idx is not None and t_idx is not None
+        gt = gh if shared else buf(t, t_idx, need_t)
+        gr = buf(r, r_idx, need_r)
+        ops.distmult_bwd(gs, h, h_idx, t, t_idx, r, r_idx, ctx.batch, gh, gt, gr)
+        if shared:
+            # autograd sums the two returned grads of the same leaf: hand back the whole
+            # accumulation once and an untouched None for the second slot
+            return gh, None, None, None, gr, None
+        return gh, None, gt, None, gr, None
+
+
+def distmult(h, h_idx, t, t_idx, r, r_idx) -> Tensor:
+    return _DistMultFunction.apply(h, h_idx, t, t_idx, r, r_idx)
+
+
+class LinkPredictor(nn.Module):
+    """DistMult decoder: ``score(h, r, t) = sum_d h_d * r_d * t_d``."""
+
+    def __init__(self, num_relations: int, embedding_dim: int, dropout: float = 0.0):
+        super().__init__()
+        self.num_relations = num_relations
+        self.embedding_dim = embedding_dim
+        self.relation_embeddings = nn.Embedding(num_relations, embedding_dim)
+        self.dropout = nn.Dropout(dropout)
+        self._init_embeddings()
+
+    def _init_embeddings(self) -> None:
+        nn.init.xavier_uniform_(self.relation_embeddings.weight)
+
+    def _relation_operand(self, relation_types: Tensor):
+        """(matrix, index) for the relation factor.  With active dropout the reference
+        drops the *gathered* [B, d] rows (rgcn.py:207-208), one mask per sample, so the
+        gather + dropout stay torch ops and the kernel reads the dropped rows; otherwise the
+        kernel gathers straight from the [R, d] table."""
+        if self.training and self.dropout.p > 0:
+            return self.dropout(self.relation_embeddings(relation_types)), None
+        return self.relation_embeddings.weight, relation_types
+
+    def forward(self, head_embeddings: Tensor, tail_embeddings: Tensor,
+                relation_types: Tensor) -> Tensor:
+        r, r_idx = self._relation_operand(relation_types)
+        return distmult(head_embeddings, None, tail_embeddings, None, r, r_idx)
+
+    def score_triples(self, node_embeddings: Tensor, head_indices: Tensor, tail_indices: Tensor,
+                      relation_types: Tensor) -> Tensor:
+        """``forward(node_embeddings[head], node_embeddings[tail], rel)`` without
+        materialising the two [B, d] gathers."""
+        r, r_idx = self._relation_operand(relation_types)
+        return distmult(node_embeddings, head_indices, node_embeddings, tail_indices, r, r_idx)
+
+    def score_all_tails(self, head_embeddings: Tensor, relation_types: Tensor,
+                        all_tail_embeddings: Tensor) -> Tensor:
+        """``(h * r) @ E^T`` -> [B, num_entities] (rgcn.py:215-243).  A plain library GEMM
+        (SURVEY section 8f "next" row 2), kept on torch/rocBLAS for now."""
+        hr = head_embeddings * self.relation_embeddings(relation_types)
+        return hr @ all_tail_embeddings.t()

@@ -1,0 +1,389 @@
+"""GPU tier: the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Tolerances (BASELINE.json north_star / SURVEY.md section 8d): bucketing bit exact;
+forward max|delta| <= 1e-5 fp32; gradients <= 1e-4 relative to the largest entry.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import LAYER_CASES, load_golden, need_gpu
+from oracle import rgcn_oracle as O
+from primekg_rgcn_linkprediction_amd import (DrugDiseaseModel, LinkPredictor, RGCNConv, distmult, ops,
+                                             rgcn_conv, synth)
+
+pytestmark = pytest.mark.gpu
+
+FWD_ATOL = 1e-5
+GRAD_RTOL = 1e-4
+
+
+def rel_err(got, want):
+    want = want.double()
+    return ((got.double().cpu() - want).abs().max() / (want.abs().max() + 1e-30)).item()
+
+
+def assert_fwd(got, want, atol=FWD_ATOL):
+    err = (got.double().cpu() - want.double()).abs().max().item() if want.numel() else 0.0
+    assert err <= atol, f"forward differs by {err:.3e} (> {atol})"
+
+
+def assert_grad(got, want, rtol=GRAD_RTOL):
+    if want.numel() == 0:
+        return
+    if want.abs().max() == 0:
+        assert got.abs().max().item() == 0
+        return
+    err = rel_err(got, want)
+    assert err <= rtol, f"gradient differs by {err:.3e} relative (> {rtol})"
+
+
+# ------------------------------------------------------------------ bucketing: bit exact
+def _check_bucket(dev, ei, et, n, r):
+    g = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
+    fw = O.bucket_ref(ei, et, n, r, transpose=False)
+    bw = O.bucket_ref(ei, et, n, r, transpose=True)
+    for transposed, ref in ((False, fw), (True, bw)):
+        rowptr, col, perm, val = [t.cpu().numpy() for t in g.arrays(transposed)]
+        assert np.array_equal(rowptr, ref[0]) and rowptr.dtype == np.int32
+        assert np.array_equal(col, ref[1]) and col.dtype == np.int32
+        assert np.array_equal(perm, ref[2]) and perm.dtype == np.int64
+        if not transposed:
+            assert np.array_equal(val, ref[3])
+        else:                                   # w_t[e] = 1 / cnt[dst*R + rel], same fp32 division
+            dst, rel = ei[1].numpy()[ref[2]], et.numpy()[ref[2]]
+            want = (np.float32(1.0) / fw[3][dst * r + rel]).astype(np.float32)
+            assert np.array_equal(val, want)
+    return g
+
+
+@pytest.mark.parametrize("case", LAYER_CASES)
+def test_bucket_golden_bit_exact(case):
+    dev = need_gpu()
+    z = load_golden(f"bucket_{case}.npz")
+    g = ops.BucketedGraph(z["edge_index"].to(dev), z["edge_type"].to(dev), z["num_nodes"], z["num_relations"])
+    for transposed, sfx in ((False, ""), (True, "_t")):
+        rowptr, col, perm, val = [t.cpu() for t in g.arrays(transposed)]
+        assert torch.equal(rowptr, z["rowptr" + sfx]) and torch.equal(col, z["col" + sfx])
+        assert torch.equal(perm, z["perm" + sfx])
+        if not transposed:
+            assert torch.equal(val, z["cnt"])
+
+
+def test_bucket_random_and_real_graphs_bit_exact():
+    dev = need_gpu()
+    ei, et, n, r = synth.uniform_graph(1000, 10000, 3, seed=42)              # C1
+    _check_bucket(dev, ei, et, n, r)
+    ei, et, n, r = synth.uniform_graph(777, 50001, 16, seed=1)                # R = 16, odd E
+    _check_bucket(dev, ei, et, n, r)
+    z = load_golden("primekg_test_edges.npz")                                  # real PrimeKG subgraph
+    _check_bucket(dev, z["edge_index"].long(), z["edge_type"].long(), 30926, 3)
+    ei, et, n, r = synth.primekg_like(seed=42)                                 # C2 full size
+    g = _check_bucket(dev, ei, et, n, r)
+    assert g.num_levels(False) >= 2 and g.num_levels(True) >= 2               # heavy segments split
+
+
+def test_bucket_rejects_out_of_range_ids():
+    dev = need_gpu()
+    ei = torch.tensor([[0, 1, 5], [1, 2, 0]], device=dev)
+    et = torch.tensor([0, 1, 0], device=dev)
+    with pytest.raises(IndexError):
+        ops.BucketedGraph(ei, et, 5, 2)                  # node 5 >= N (train.py:571-586 filters these)
+    with pytest.raises(IndexError):
+        ops.BucketedGraph(ei, et, 6, 1)                  # relation 1 >= R
+    with pytest.raises(IndexError):
+        ops.BucketedGraph(torch.tensor([[0, -1], [1, 0]], device=dev), torch.tensor([0, 0], device=dev), 3, 1)
+    ops.BucketedGraph(ei, et, 6, 2)
+
+
+def test_graph_cache_hits_and_invalidates():
+    dev = need_gpu()
+    ops.clear_graph_cache()
+    ei, et, n, r = synth.uniform_graph(50, 300, 3, seed=3)
+    ei, et = ei.to(dev), et.to(dev)
+    a = ops.bucket(ei, et, n, r)
+    assert ops.bucket(ei, et, n, r) is a                  # conv1 and conv2 share one bucketing
+    et[0] = (et[0] + 1) % r                               # in-place edit bumps _version
+    b = ops.bucket(ei, et, n, r)
+    assert b is not a
+    assert ops.bucket(ei.clone(), et, n, r) is not b
+    ops.clear_graph_cache()
+
+
+# ------------------------------------------------------------------ aggregate (A3 + A4)
+@pytest.mark.parametrize("case", LAYER_CASES)
+def test_aggregate_golden(case):
+    dev = need_gpu()
+    z = load_golden(f"layer_{case}.npz")
+    n, r = z["num_nodes"], z["num_relations"]
+    g = ops.BucketedGraph(z["edge_index"].to(dev), z["edge_type"].to(dev), n, r)
+    agg = ops.aggregate(g, z["x"].to(dev))
+    assert_fwd(agg.view(n, r, -1), z["agg"], 2e-6)
+
+
+@pytest.mark.parametrize("d", [4, 8, 24, 64, 128, 256, 320])
+def test_aggregate_feature_widths_and_transposed(d):
+    dev = need_gpu()
+    ei, et, n, r = synth.uniform_graph(300, 6000, 3, seed=d)
+    ei[1, :900] = 7                                        # one heavy destination: 3 levels of chunks
+    ei[0, 1000:1200] = 9                                   # and a heavy source
+    gen = torch.Generator().manual_seed(d)
+    x = torch.randn(n, d, generator=gen)
+    g = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
+    assert g.num_levels(False) >= 2
+    agg = ops.aggregate(g, x.to(dev))
+    assert_fwd(agg.view(n, r, d), O.mean_aggregate_ref(x, ei, et, r), 5e-6)
+    # transposed: what autograd scatters for the mean aggregation
+    xr = x.clone().requires_grad_(True)
+    cot = torch.randn(n, r, d, generator=gen)
+    (O.mean_aggregate_ref(xr, ei, et, r) * cot).sum().backward()
+    # grad_x[j] = sum_r sum_{e: j->i,r} cot[i, r] / cnt[i, r]; feed cot[:, r] one relation at a time
+    gagg = torch.zeros(n, d)
+    for rel in range(r):
+        t = ops.aggregate(g, cot[:, rel].contiguous().to(dev), transposed=True).view(n, r, d)
+        gagg += t[:, rel].cpu()
+    assert_grad(gagg, xr.grad, 2e-5)
+
+
+def test_aggregate_is_deterministic_and_exact_on_ones():
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(seed=42)
+    g = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
+    deg = torch.bincount(ei[1] * r + et, minlength=n * r)
+    ones = ops.aggregate(g, torch.ones(n, 64, device=dev)).view(n * r, 64).cpu()
+    # mean of ones is exactly 1 on non-empty segments (sums of <= 2^24 ones are exact), else 0
+    assert torch.equal(ones, (deg > 0).float().view(-1, 1).expand(-1, 64))
+    x = torch.randn(n, 128, generator=torch.Generator().manual_seed(0)).to(dev)
+    a, b = ops.aggregate(g, x), ops.aggregate(g, x)
+    assert torch.equal(a, b)                               # fixed summation tree: bitwise reproducible
+    # linearity (size independent property): agg(2x + y) = 2 agg(x) + agg(y)
+    y = torch.randn(n, 128, generator=torch.Generator().manual_seed(1)).to(dev)
+    lhs = ops.aggregate(g, 2 * x + y)
+    torch.testing.assert_close(lhs, 2 * a + ops.aggregate(g, y), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------ transform (A6) and its grads
+@pytest.mark.parametrize("n,r,d_in,d_out", [(100, 3, 64, 128), (257, 1, 8, 4), (1000, 3, 64, 64),
+                                            (513, 16, 32, 64), (300, 3, 128, 256), (129, 2, 20, 36)])
+def test_transform_kernels(n, r, d_in, d_out):
+    dev = need_gpu()
+    gen = torch.Generator().manual_seed(n + d_in)
+    agg = torch.randn(n, r * d_in, generator=gen)
+    x = torch.randn(n, d_in, generator=gen)
+    w = torch.randn(r, d_in, d_out, generator=gen) * 0.1
+    root = torch.randn(d_in, d_out, generator=gen) * 0.1
+    bias = torch.randn(d_out, generator=gen)
+    g = torch.randn(n, d_out, generator=gen)
+    want = (agg.double() @ w.double().view(r * d_in, d_out) + x.double() @ root.double() + bias.double())
+    out = ops.transform_fwd(agg.to(dev), x.to(dev), w.to(dev), root.to(dev), bias.to(dev))
+    assert rel_err(out, want) <= 2e-6
+    out_nr = ops.transform_fwd(agg.to(dev), x.to(dev), w.to(dev), None, None)
+    assert rel_err(out_nr, agg.double() @ w.double().view(r * d_in, d_out)) <= 2e-6
+    # grad wrt input: gagg [n, r*d_out] plays agg's role
+    gagg = torch.randn(n, r * d_out, generator=gen)
+    want_gx = sum(gagg.double()[:, k * d_out:(k + 1) * d_out] @ w.double()[k].t() for k in range(r)) \
+        + g.double() @ root.double().t()
+    gx = ops.transform_bwd_input(gagg.to(dev), g.to(dev), w.to(dev), root.to(dev))
+    assert rel_err(gx, want_gx) <= 2e-6
+    # grads wrt parameters
+    gw, groot, gbias = ops.transform_bwd_params(agg.to(dev), x.to(dev), g.to(dev), r)
+    assert rel_err(gw, (agg.double().t() @ g.double()).view(r, d_in, d_out)) <= 5e-6
+    assert rel_err(groot, x.double().t() @ g.double()) <= 5e-6
+    assert rel_err(gbias, g.double().sum(0)) <= 5e-6
+    gw2, groot2, gbias2 = ops.transform_bwd_params(agg.to(dev), x.to(dev), g.to(dev), r, want_root=False,
+                                                   want_bias=False)
+    assert groot2 is None and gbias2 is None and torch.equal(gw2, gw)
+
+
+# ------------------------------------------------------------------ the layer against the goldens
+@pytest.mark.parametrize("case", LAYER_CASES)
+def test_layer_forward_backward_golden(case):
+    dev = need_gpu()
+    z = load_golden(f"layer_{case}.npz")
+    r = z["num_relations"]
+    nb = z["weight"].size(0) if "comp" in z else None
+    conv = RGCNConv(z["x"].size(1), z["weight"].size(2), r, num_bases=nb).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(z["weight"]); conv.root.copy_(z["root"]); conv.bias.copy_(z["bias"])
+        if nb is not None:
+            conv.comp.copy_(z["comp"])
+    x = z["x"].to(dev).requires_grad_(True)
+    out = conv(x, z["edge_index"].to(dev), z["edge_type"].to(dev))
+    assert out.dtype == torch.float32 and out.shape == z["out"].shape
+    assert_fwd(out, z["out_dense_f64"])                    # vs the independent float64 formulation
+    assert_fwd(out, z["out"])                              # vs PyG's op sequence restated
+    (out * z["cot"].to(dev)).sum().backward()
+    assert_grad(x.grad, z["grad_x"])
+    assert_grad(conv.weight.grad, z["grad_weight"])
+    assert_grad(conv.root.grad, z["grad_root"])
+    assert_grad(conv.bias.grad, z["grad_bias"])
+    if nb is not None:
+        assert_grad(conv.comp.grad, z["grad_comp"])
+
+
+def test_layer_no_root_no_bias_and_frozen_input():
+    dev = need_gpu()
+    ei, et, n, r = synth.uniform_graph(200, 3000, 4, seed=9)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(n, 32, generator=gen)
+    conv = RGCNConv(32, 16, r, root_weight=False, bias=False).to(dev)
+    out = conv(x.to(dev), ei.to(dev), et.to(dev))           # x does not require grad
+    want = O.rgcn_conv_ref(x, ei, et, conv.weight.detach().cpu(), None, None)
+    assert_fwd(out, want)
+    out.sum().backward()
+    wr = conv.weight.detach().cpu().clone().requires_grad_(True)
+    O.rgcn_conv_ref(x, ei, et, wr, None, None).sum().backward()
+    assert_grad(conv.weight.grad, wr.grad)
+
+
+# ------------------------------------------------------------------ model + head vs reference-run vectors
+def _load_ref_model(z, dev, **kw):
+    sd = {k[4:].replace("__", "."): v for k, v in z.items() if k.startswith("sd__")}
+    n = sd["encoder.node_embeddings.weight"].size(0)
+    hidden = sd["decoder.relation_embeddings.weight"].size(1)
+    m = DrugDiseaseModel(n, 3, 64, hidden, **kw)
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev)
+
+
+def test_model_eval_matches_reference_run():
+    dev = need_gpu()
+    z = load_golden("ref_model_eval.npz")
+    m = _load_ref_model(z, dev)
+    ei, et = z["edge_index"].to(dev), z["edge_type"].to(dev)
+    hi, ti, ri = z["head"].to(dev), z["tail"].to(dev), z["rel"].to(dev)
+    assert_fwd(m.get_embeddings(ei, et), z["embeddings"])
+    assert_fwd(m.predict(ei, et, hi, ti, ri), z["scores"])
+    assert_fwd(m.predict_all_tails(ei, et, hi, ri), z["all_scores"], 2e-5)
+    m.eval()
+    with torch.no_grad():                                   # unfused decoder entry: same numbers
+        emb = m.encoder(ei, et)
+        assert_fwd(m.decoder(emb[hi], emb[ti], ri), z["scores"])
+
+
+def test_model_bases_matches_reference_run():
+    dev = need_gpu()
+    z = load_golden("ref_model_bases.npz")
+    m = _load_ref_model(z, dev, num_bases=4)
+    assert_fwd(m.get_embeddings(z["edge_index"].to(dev), z["edge_type"].to(dev)), z["embeddings"])
+
+
+def test_training_step_matches_reference_run():
+    """scores, BCE loss and every parameter gradient of one step of the reference's model
+    (train.py:291-306 arithmetic, dropout p = 0)."""
+    dev = need_gpu()
+    z, t = load_golden("ref_model_eval.npz"), load_golden("ref_model_train_step.npz")
+    m = _load_ref_model(z, dev, dropout=0.0, decoder_dropout=0.0).train()
+    scores = m(z["edge_index"].to(dev), z["edge_type"].to(dev), z["head"].to(dev), z["tail"].to(dev),
+               z["rel"].to(dev))
+    assert_fwd(scores, t["scores"])
+    loss = torch.nn.BCEWithLogitsLoss()(scores, t["labels"].to(dev))
+    assert abs(loss.item() - t["loss"].item()) <= 1e-6
+    loss.backward()
+    for name, p in m.named_parameters():
+        assert_grad(p.grad, t["grad__" + name.replace(".", "__")])
+
+
+def test_link_predictor_matches_reference_run():
+    dev = need_gpu()
+    z = load_golden("ref_link_predictor.npz")
+    dec = LinkPredictor(3, 128, dropout=0.0).to(dev)
+    with torch.no_grad():
+        dec.relation_embeddings.weight.copy_(z["rel_table"])
+    h = z["head"].to(dev).requires_grad_(True)
+    t = z["tail"].to(dev).requires_grad_(True)
+    scores = dec(h, t, z["rel"].to(dev))
+    assert_fwd(scores, z["scores"])
+    assert_fwd(dec.score_all_tails(h, z["rel"].to(dev), z["all_tails"].to(dev)), z["all_scores"], 2e-5)
+    (scores * z["cot"].to(dev)).sum().backward()
+    assert_grad(h.grad, z["grad_head"])
+    assert_grad(t.grad, z["grad_tail"])
+    assert_grad(dec.relation_embeddings.weight.grad, z["grad_rel_table"])
+
+
+def test_distmult_duplicate_rows_and_dropout_path():
+    dev = need_gpu()
+    gen = torch.Generator().manual_seed(5)
+    emb = torch.randn(50, 128, generator=gen)
+    rel = torch.randn(3, 128, generator=gen)
+    hi = torch.randint(0, 5, (2048,), generator=gen)          # many duplicate rows
+    ti = torch.randint(0, 50, (2048,), generator=gen)
+    ri = torch.randint(0, 3, (2048,), generator=gen)
+    cot = torch.randn(2048, generator=gen)
+    e1, r1 = emb.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+    (O.distmult_ref(e1[hi], e1[ti], r1[ri]) * cot).sum().backward()
+    e2, r2 = emb.to(dev).requires_grad_(True), rel.to(dev).requires_grad_(True)
+    sc = distmult(e2, hi.to(dev), e2, ti.to(dev), r2, ri.to(dev))
+    assert_fwd(sc, O.distmult_ref(emb[hi], emb[ti], rel[ri]), 2e-5)
+    (sc * cot.to(dev)).sum().backward()
+    assert_grad(e2.grad, e1.grad, 1e-5)
+    assert_grad(r2.grad, r1.grad, 1e-5)
+    # training with relation dropout: rows are dropped by torch, kernel reads [B, d] rows
+    dec = LinkPredictor(3, 128, dropout=0.5).to(dev).train()
+    torch.manual_seed(3)
+    s_drop = dec.score_triples(e2.detach(), hi.to(dev), ti.to(dev), ri.to(dev))
+    torch.manual_seed(3)
+    rows = dec.dropout(dec.relation_embeddings(ri.to(dev)))
+    want = (e2.detach()[hi.to(dev)] * rows * e2.detach()[ti.to(dev)]).sum(1)
+    assert_fwd(s_drop, want.detach().cpu(), 2e-5)
+    assert distmult(e2[:0], None, e2[:0], None, e2[:0], None).shape == (0,)
+
+
+# ------------------------------------------------------------------ BASELINE configs
+def _encoder_vs_oracle(dev, ei, et, n, r, dims, num_bases=None, seed=0, fwd_atol=FWD_ATOL):
+    torch.manual_seed(seed)
+    emb = torch.nn.init.xavier_uniform_(torch.empty(n, dims[0]))
+    convs = [RGCNConv(dims[0], dims[1], r, num_bases=num_bases), RGCNConv(dims[1], dims[2], r, num_bases=num_bases)]
+    for c in convs:
+        c.bias.data.uniform_(-0.1, 0.1)
+    cot = torch.randn(n, dims[2])
+    # oracle
+    ref_p = [{k: v.detach().clone().requires_grad_(True) for k, v in c.named_parameters()} for c in convs]
+    e_ref = emb.clone().requires_grad_(True)
+    out_ref = O.encoder_ref(e_ref, ref_p[0], ref_p[1], ei, et)
+    (out_ref * cot).sum().backward()
+    # HIP
+    convs = [c.to(dev) for c in convs]
+    e_gpu = emb.to(dev).requires_grad_(True)
+    eid, etd = ei.to(dev), et.to(dev)
+    h = torch.relu(convs[0](e_gpu, eid, etd))
+    out = convs[1](h, eid, etd)
+    (out * cot.to(dev)).sum().backward()
+    assert_fwd(out, out_ref.detach(), fwd_atol)
+    assert_grad(e_gpu.grad, e_ref.grad)
+    for c, rp in zip(convs, ref_p):
+        for k, v in c.named_parameters():
+            assert_grad(v.grad, rp[k].grad)
+
+
+def test_config_c1_two_layers_vs_oracle():
+    """BASELINE configs[0]: 1k nodes / 10k edges / 3 relations, hidden 64, 2 layers."""
+    dev = need_gpu()
+    ei, et, n, r = synth.uniform_graph(1000, 10000, 3, seed=42)
+    _encoder_vs_oracle(dev, ei, et, n, r, (64, 64, 64))
+
+
+def test_config_c2_full_size_vs_oracle():
+    """BASELINE configs[1]: PrimeKG shape 30,926 / 849,456 / 3, 64 -> 128 -> 128."""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(seed=42)
+    _encoder_vs_oracle(dev, ei, et, n, r, (64, 128, 128), fwd_atol=2e-5)
+
+
+def test_config_c3_bases_on_real_subgraph():
+    """BASELINE configs[2] layer form (hidden 256, num_bases 4) on the real PrimeKG test edges."""
+    dev = need_gpu()
+    z = load_golden("primekg_test_edges.npz")
+    _encoder_vs_oracle(dev, z["edge_index"].long(), z["edge_type"].long(), 30926, 3, (64, 256, 256), num_bases=4)
+
+
+def test_functional_entry_and_r16():
+    dev = need_gpu()
+    ei, et, n, r = synth.uniform_graph(2000, 60000, 16, seed=4)     # C4's relation count, small N
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(n, 64, generator=gen)
+    w = torch.randn(r, 64, 128, generator=gen) * 0.05
+    root = torch.randn(64, 128, generator=gen) * 0.05
+    bias = torch.randn(128, generator=gen)
+    out = rgcn_conv(x.to(dev), ei.to(dev), et.to(dev), w.to(dev), root.to(dev), bias.to(dev), r)
+    assert_fwd(out, O.rgcn_conv_ref(x, ei, et, w, root, bias))

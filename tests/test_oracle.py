@@ -1,0 +1,210 @@
+"""CPU tier: pins the oracle against the committed golden vectors.
+
+* ``ref_*.npz`` were produced by running the REFERENCE's own classes
+  (LinkPredictor, DrugDiseaseModel wiring, NegativeSampler) in the build container
+  (tests/golden/make_golden.py) - the oracle's head / wiring restatements must reproduce them.
+* ``layer_*.npz`` / ``bucket_*.npz``: restatement #1, cross-checked against the independent
+  float64 dense restatement #2.  The layer itself is "parity unpinned" by the reference
+  (PyG is not installable here; the reference's tests assert shapes only).
+* semantics checklist of SURVEY.md section 8a, one test each.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import LAYER_CASES, load_golden
+from oracle import rgcn_oracle as O
+
+
+# ------------------------------------------------------------------ reference-run vectors
+def test_head_matches_reference_run():
+    z = load_golden("ref_link_predictor.npz")
+    rel_rows = z["rel_table"][z["rel"]]
+    scores = O.distmult_ref(z["head"], z["tail"], rel_rows)
+    assert torch.equal(scores, z["scores"])          # same torch ops, same order -> bit equal
+    all_scores = O.distmult_all_tails_ref(z["head"], rel_rows, z["all_tails"])
+    torch.testing.assert_close(all_scores, z["all_scores"], rtol=1e-6, atol=1e-6)
+
+
+def test_head_grads_match_reference_run():
+    z = load_golden("ref_link_predictor.npz")
+    h = z["head"].clone().requires_grad_(True)
+    t = z["tail"].clone().requires_grad_(True)
+    table = z["rel_table"].clone().requires_grad_(True)
+    (O.distmult_ref(h, t, table[z["rel"]]) * z["cot"]).sum().backward()
+    torch.testing.assert_close(h.grad, z["grad_head"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(t.grad, z["grad_tail"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(table.grad, z["grad_rel_table"], rtol=1e-5, atol=1e-6)
+
+
+def _conv_dicts(z, prefix="sd__encoder__"):
+    out = []
+    for c in ("conv1", "conv2"):
+        d = {k: z[f"{prefix}{c}__{k}"] for k in ("weight", "root", "bias")}
+        if f"{prefix}{c}__comp" in z:
+            d["comp"] = z[f"{prefix}{c}__comp"]
+        out.append(d)
+    return out
+
+
+def test_encoder_wiring_matches_reference_run():
+    """reference DrugDiseaseModel in eval(): embeddings, scores, all-tail scores."""
+    z = load_golden("ref_model_eval.npz")
+    c1, c2 = _conv_dicts(z)
+    emb = O.encoder_ref(z["sd__encoder__node_embeddings__weight"], c1, c2, z["edge_index"], z["edge_type"])
+    torch.testing.assert_close(emb, z["embeddings"], rtol=0, atol=1e-6)
+    rel = z["sd__decoder__relation_embeddings__weight"][z["rel"]]
+    scores = O.distmult_ref(emb[z["head"]], emb[z["tail"]], rel)
+    torch.testing.assert_close(scores, z["scores"], rtol=0, atol=1e-5)
+    allsc = O.distmult_all_tails_ref(emb[z["head"]], rel, emb)
+    torch.testing.assert_close(allsc, z["all_scores"], rtol=0, atol=1e-5)
+    assert z["num_params"] == 100 * 64 + (3 * 64 * 128 + 64 * 128 + 128) + (3 * 128 * 128 + 128 * 128 + 128) + 3 * 128
+
+
+def test_basis_decomposition_matches_reference_run():
+    z = load_golden("ref_model_bases.npz")
+    c1, c2 = _conv_dicts(z)
+    assert c1["weight"].shape == (4, 64, 32) and c1["comp"].shape == (3, 4)
+    emb = O.encoder_ref(z["sd__encoder__node_embeddings__weight"], c1, c2, z["edge_index"], z["edge_type"])
+    torch.testing.assert_close(emb, z["embeddings"], rtol=0, atol=1e-6)
+
+
+def test_parameter_count_primekg():
+    """results_final/results.json:28 -> 2,078,208 for N=30,926 / R=3 / 64 -> 128 -> 128."""
+    n, r, e, h = 30926, 3, 64, 128
+    convs = [O.RGCNConvRef(e, h, r), O.RGCNConvRef(h, h, r)]
+    total = n * e + sum(p.numel() for c in convs for p in c.parameters()) + r * h
+    assert total == 2078208
+
+
+# ------------------------------------------------------------------ oracle vectors
+@pytest.mark.parametrize("case", LAYER_CASES)
+def test_layer_golden(case):
+    z = load_golden(f"layer_{case}.npz")
+    r = z["num_relations"]
+    comp = z.get("comp")
+    params = [z[k].clone().requires_grad_(True) for k in ("x", "weight", "root", "bias")]
+    cpar = comp.clone().requires_grad_(True) if comp is not None else None
+    out = O.rgcn_conv_ref(params[0], z["edge_index"], z["edge_type"], params[1], params[2], params[3], cpar, r)
+    torch.testing.assert_close(out, z["out"], rtol=0, atol=2e-6)
+    dense = O.rgcn_conv_dense_f64(z["x"], z["edge_index"], z["edge_type"], z["weight"], z["root"], z["bias"],
+                                  comp, r)
+    torch.testing.assert_close(out.double(), dense, rtol=0, atol=2e-5)
+    torch.testing.assert_close(dense, z["out_dense_f64"], rtol=0, atol=1e-12)
+    (out * z["cot"]).sum().backward()
+    for p, k in zip(params, ("grad_x", "grad_weight", "grad_root", "grad_bias")):
+        torch.testing.assert_close(p.grad, z[k], rtol=1e-5, atol=1e-6)
+    agg = O.mean_aggregate_ref(z["x"], z["edge_index"], z["edge_type"], r)
+    torch.testing.assert_close(agg, z["agg"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", LAYER_CASES)
+def test_bucket_golden(case):
+    z = load_golden(f"bucket_{case}.npz")
+    n, r = z["num_nodes"], z["num_relations"]
+    for transpose, sfx in ((False, ""), (True, "_t")):
+        rowptr, col, perm, cnt = O.bucket_ref(z["edge_index"], z["edge_type"], n, r, transpose)
+        for got, key in ((rowptr, "rowptr"), (col, "col"), (perm, "perm"), (cnt, "cnt")):
+            assert np.array_equal(got, z[key + sfx].numpy()), (case, key + sfx)
+
+
+def test_bucket_is_the_reference_mask_select():
+    """edge_index[:, edge_type == r] restricted to one destination == the CSR segment."""
+    g = torch.Generator().manual_seed(11)
+    n, e, r = 23, 400, 4
+    ei = torch.randint(0, n, (2, e), generator=g)
+    et = torch.randint(0, r, (e,), generator=g)
+    rowptr, col, perm, cnt = O.bucket_ref(ei, et, n, r)
+    for rel in range(r):
+        cols = ei[:, et == rel]                               # PyG masked_edge_index
+        for i in range(n):
+            want = cols[0, cols[1] == i].numpy()               # order preserved
+            s = i * r + rel
+            assert np.array_equal(col[rowptr[s]:rowptr[s + 1]], want)
+            assert cnt[s] == max(1, len(want))
+    assert np.array_equal(np.sort(perm), np.arange(e))
+
+
+def test_real_primekg_fixture():
+    z = load_golden("primekg_test_edges.npz")
+    ei, et = z["edge_index"].long(), z["edge_type"].long()
+    assert ei.shape == (2, 15372) and z["num_nodes"] == 30926 and z["num_relations"] == 3
+    assert torch.equal(ei[:, 0::2], ei[:, 1::2].flip(0))       # reverse pairs (preprocess.py:228-234)
+    assert torch.unique(ei, dim=1).size(1) == 14200            # duplicates exist in the real data
+    rowptr, col, perm, cnt = O.bucket_ref(ei, et, 30926, 3)
+    assert rowptr[-1] == 15372 and cnt.max() > 64              # a heavy destination
+
+
+# ------------------------------------------------------------------ semantics checklist (section 8a)
+def _layer(x, ei, et, r, d_out=4, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(r, x.size(1), d_out, generator=g)
+    root = torch.randn(x.size(1), d_out, generator=g)
+    bias = torch.randn(d_out, generator=g)
+    return O.rgcn_conv_ref(x, ei, et, w, root, bias), w, root, bias
+
+
+def test_direction_row0_to_row1():
+    x = torch.eye(3, 4)
+    ei, et = torch.tensor([[0], [2]]), torch.tensor([0])       # 0 -> 2
+    agg = O.mean_aggregate_ref(x, ei, et, 1)
+    assert torch.equal(agg[2, 0], x[0]) and agg[0].abs().sum() == 0
+
+
+def test_mean_is_per_destination_and_relation():
+    x = torch.arange(12.0).view(4, 3)
+    ei = torch.tensor([[0, 1, 2], [3, 3, 3]])
+    et = torch.tensor([0, 0, 1])
+    agg = O.mean_aggregate_ref(x, ei, et, 2)
+    assert torch.equal(agg[3, 0], (x[0] + x[1]) / 2)           # not divided by 3
+    assert torch.equal(agg[3, 1], x[2])
+
+
+def test_isolated_rows_are_exact_zero_and_get_root_plus_bias():
+    x = torch.randn(5, 4)
+    ei, et = torch.tensor([[0], [1]]), torch.tensor([0])
+    out, w, root, bias = _layer(x, ei, et, 2)
+    assert torch.equal(O.mean_aggregate_ref(x, ei, et, 2)[4], torch.zeros(2, 4))
+    torch.testing.assert_close(out[4], (torch.zeros(4) + x[4] @ root) + bias)
+
+
+def test_duplicate_edges_count():
+    x = torch.randn(3, 4)
+    ei = torch.tensor([[0, 0, 1], [2, 2, 2]])
+    et = torch.zeros(3, dtype=torch.long)
+    agg = O.mean_aggregate_ref(x, ei, et, 1)
+    torch.testing.assert_close(agg[2, 0], (x[0] + x[0] + x[1]) / 3)
+
+
+def test_no_implicit_self_loops():
+    x = torch.randn(3, 4)
+    ei, et = torch.empty(2, 0, dtype=torch.long), torch.empty(0, dtype=torch.long)
+    out, w, root, bias = _layer(x, ei, et, 2)
+    torch.testing.assert_close(out, x @ root + bias)
+
+
+def test_out_is_fp32():
+    x = torch.randn(3, 4)
+    out, *_ = _layer(x, torch.tensor([[0], [1]]), torch.tensor([0]), 1)
+    assert out.dtype == torch.float32
+
+
+def test_both_decompositions_raise():
+    with pytest.raises(ValueError):
+        O.RGCNConvRef(4, 4, 3, num_bases=2, num_blocks=2)
+
+
+def test_out_of_range_is_rejected():
+    with pytest.raises(ValueError):
+        O.bucket_ref(torch.tensor([[0], [5]]), torch.tensor([0]), 5, 1)
+    with pytest.raises(ValueError):
+        O.bucket_ref(torch.tensor([[0], [1]]), torch.tensor([3]), 5, 3)
+
+
+def test_glorot_bounds_and_zero_bias():
+    torch.manual_seed(0)
+    c = O.RGCNConvRef(64, 128, 3)
+    a = (6.0 / (64 + 128)) ** 0.5
+    assert c.weight.shape == (3, 64, 128) and c.root.shape == (64, 128) and c.bias.shape == (128,)
+    assert c.weight.abs().max() <= a and c.root.abs().max() <= a and c.weight.abs().max() > 0.9 * a
+    assert torch.count_nonzero(c.bias) == 0
