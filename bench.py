@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: edges/sec per R-GCN layer (fwd+bwd) on the PrimeKG-shaped
+synthetic graph (BASELINE.json metric; configs[1] = C2: 30,926 nodes / 849,456 edges /
+3 relations, 64 -> 128 -> 128, fp32).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the two-layer encoder over the whole graph, forward + backward
+(conv1 -> relu -> conv2, seeded cotangent; dropout p = 0; bucketing excluded - the graph is
+static and bucketed once, the one-time cost is reported in `bucket_ms`).
+value = L * E * K / t with L = 2 layers.  N > 1: node-partitioned across the ranks with an
+RCCL exchange per layer and direction (primekg_rgcn_linkprediction_amd/dist.py), one process
+per GPU, launched by torch.distributed.run.
+
+Rank 0 prints ONE JSON line, carrying `roofline` (the dominant gather kernel, HIP events
+recorded live inside the timed region on the launch stream) and, at N = 1, `cpu_baseline`
+(the PyG-equivalent CPU path of oracle/ timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+DIMS = (64, 128, 128)
+LAYERS = 2
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--edges", type=int, default=None, help="override E (default 849,456)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def gather_bytes(num_edges, num_nodes, num_relations, d, weighted):
+    """Algorithmic bytes of ONE level-0 gather launch that materialises its output
+    (SURVEY.md section 8d / DESIGN.md): every edge reads one d-float row + a 4-byte column id
+    (+ a 4-byte 1/cnt weight in the transposed form), plus rowptr and cnt once, plus the
+    [N*R, d] output written once."""
+    nr = num_nodes * num_relations
+    b = num_edges * (4 * d + 4) + 4 * (nr + 1) + 4 * nr * d
+    b += 4 * num_edges if weighted else 4 * nr
+    return b
+
+
+def cpu_baseline(ei, et, n, r, seconds):
+    """PyG-equivalent CPU path (restated; torch_geometric unavailable offline): the oracle's
+    op-for-op loop path incl. autograd, all host cores, same graph/seed/step definition.
+    Mask/bucketing time is included, as PyG redoes it every call."""
+    from oracle import rgcn_oracle as O
+    torch.manual_seed(0)
+    emb = torch.nn.init.xavier_uniform_(torch.empty(n, DIMS[0])).requires_grad_(True)
+    convs = [O.RGCNConvRef(DIMS[0], DIMS[1], r), O.RGCNConvRef(DIMS[1], DIMS[2], r)]
+    cot = torch.randn(n, DIMS[2])
+
+    def step():
+        h = torch.relu(convs[0](emb, ei, et))
+        out = convs[1](h, ei, et)
+        emb.grad = None
+        for c in convs:
+            c.zero_grad(set_to_none=True)
+        out.backward(cot)
+
+    step()
+    times = []
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end or len(times) < 3:
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": LAYERS * ei.size(1) / med, "unit": "edges/s", "cores": torch.get_num_threads(),
+            "kind": "port", "ms_per_step": med * 1e3,
+            "sample": f"{len(times)} full C2 encoder fwd+bwd steps (median) of the oracle's "
+                      f"PyG-equivalent loop path, {torch.get_num_threads()} threads"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 "
+                             f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the measured path")
+
+    from primekg_rgcn_linkprediction_amd import RGCNConv, _lib, ops, synth
+    _lib.load()                                           # fail loudly if the HIP library is missing
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    ei, et, n, r = synth.primekg_like(num_edges=args.edges or synth.PRIMEKG_EDGES, seed=42)
+    num_edges = ei.size(1)
+    torch.manual_seed(0)
+    emb_cpu = torch.nn.init.xavier_uniform_(torch.empty(n, DIMS[0]))
+    convs = [RGCNConv(DIMS[0], DIMS[1], r), RGCNConv(DIMS[1], DIMS[2], r)]
+    cot_cpu = torch.randn(n, DIMS[2])
+
+    if world == 1:
+        eid, etd = ei.to(dev), et.to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ops.bucket(eid, etd, n, r)
+        torch.cuda.synchronize()
+        bucket_ms = (time.perf_counter() - t0) * 1e3
+        emb = emb_cpu.to(dev).requires_grad_(True)
+        convs = [c.to(dev) for c in convs]
+        cot = cot_cpu.to(dev)
+        params = [emb] + [p for c in convs for p in c.parameters()]
+
+        def step():
+            h = torch.relu(convs[0](emb, eid, etd))
+            out = convs[1](h, eid, etd)
+            for p in params:
+                p.grad = None
+            out.backward(cot)
+        parallelism = "1 GPU"
+    else:
+        from primekg_rgcn_linkprediction_amd import dist as rdist
+        t0 = time.perf_counter()
+        enc = rdist.PartitionedEncoder(ei, et, n, r, emb_cpu, convs, dev)
+        torch.cuda.synchronize()
+        bucket_ms = (time.perf_counter() - t0) * 1e3
+        cot = enc.shard_rows(cot_cpu).to(dev)
+        step = lambda: enc.step(cot)                                     # noqa: E731
+        parallelism = f"node-partitioned x{world} (edge-balanced ranges), RCCL exchange per layer"
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ops.GATHER_EVENTS = [] if world == 1 else None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    events, ops.GATHER_EVENTS = ops.GATHER_EVENTS, None
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    result = {
+        "metric": "edges/sec per RGCN layer (fwd+bwd), PrimeKG 30.9k nodes/849k edges/3 rels",
+        "value": LAYERS * num_edges * args.steps / elapsed,
+        "unit": "edges/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C2: PrimeKG-shaped synthetic graph, {n} nodes / {num_edges} edge columns / "
+                               f"{r} relations, encoder {DIMS[0]}->{DIMS[1]}->{DIMS[2]}, 2 layers fwd+bwd, "
+                               f"full graph per step, dropout 0",
+                   "parallelism": parallelism},
+        "bucket_ms": bucket_ms,
+    }
+
+    if world == 1 and events:
+        # per instantiation of the gather kernel: average duration from the live HIP events
+        per = {}
+        for transposed, d, beg, end in events:
+            per.setdefault((transposed, d), []).append(beg.elapsed_time(end) * 1e-3)   # seconds
+        kernels = []
+        for (transposed, d), ts in sorted(per.items()):
+            avg = sum(ts) / len(ts)
+            nbytes = gather_bytes(num_edges, n, r, d, transposed)
+            kernels.append({"kernel": f"k_aggregate<{d // 4},{'true,true' if transposed else 'true,false'}>",
+                            "d": d, "transposed": transposed, "launches_per_step": len(ts) // args.steps,
+                            "avg_us": avg * 1e6, "bytes": nbytes, "gbs": nbytes / avg / 1e9,
+                            "total_us_per_step": sum(ts) / args.steps * 1e6})
+        dom = max(kernels, key=lambda k: k["total_us_per_step"])
+        result["roofline"] = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": None, "kernel": dom["kernel"],
+                              "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"]}
+        result["gather_kernels"] = kernels
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(ei, et, n, r, args.cpu_seconds)
+        result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,6 +102,10 @@ int rgcn_graph_export(const rgcn_graph* g, int transposed, int32_t* rowptr, int3
 size_t rgcn_aggregate_workspace_bytes(const rgcn_graph* g, int transposed, int64_t d);
 int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* One launch of the above (level in [0, rgcn_graph_num_levels)); calling the levels in order
+ * equals rgcn_aggregate.  Lets a profiler bracket the level-0 gather kernel by itself. */
+int rgcn_aggregate_level(const rgcn_graph* g, int transposed, int level, const float* x, int64_t d,
+                         float* agg, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Per-relation transform + root + bias (row A6), fp32 MFMA (v_mfma_f32_32x32x2_f32):

@@ -42,6 +42,7 @@ PROTOTYPES = {
     "rgcn_graph_export": (c_int, [c_void_p, c_int, _P, _P, _P, _P, _P]),
     "rgcn_aggregate_workspace_bytes": (c_size_t, [c_void_p, c_int, _I64]),
     "rgcn_aggregate": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, _P]),
+    "rgcn_aggregate_level": (c_int, [c_void_p, c_int, c_int, _P, _I64, _P, _P, c_size_t, _P]),
     "rgcn_transform_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),
     "rgcn_transform_fwd": (c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, c_size_t, _P]),
     "rgcn_transform_bwd_input": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, c_size_t, _P]),

@@ -94,13 +94,14 @@ size_t rgcn_aggregate_workspace_bytes(const rgcn_graph* g, int transposed, int64
   return (size_t)g->dir[transposed ? 1 : 0].num_partials * (size_t)d * sizeof(float);
 }
 
-int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
-                   void* workspace, size_t workspace_bytes, void* stream_) {
+static int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, const float* x, int64_t d,
+                            float* agg, void* workspace, size_t workspace_bytes, void* stream_) {
   if (!g || !agg || d <= 0 || (d & 3)) return RGCN_ERR_ARG;
   if (g->N == 0) return RGCN_OK;
   if (!x) return RGCN_ERR_ARG;
   if (d > (1 << 20)) return RGCN_ERR_UNSUPPORTED;
   const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
+  if (first < 0 || last > c->num_levels || first > last) return RGCN_ERR_ARG;
   if (c->num_partials > 0 &&
       (!workspace || workspace_bytes < (size_t)c->num_partials * (size_t)d * sizeof(float)))
     return RGCN_ERR_WORKSPACE;
@@ -109,7 +110,7 @@ int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t 
   const float* cnt = transposed ? nullptr : c->val;
   const bool weighted = transposed != 0;
   const int q = (int)(d / 4);
-  for (int l = 0; l < c->num_levels; ++l) {
+  for (int l = first; l < last; ++l) {
     if (q <= 1) launch_level<1>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
     else if (q <= 2) launch_level<2>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
     else if (q <= 4) launch_level<4>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
@@ -120,6 +121,18 @@ int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t 
   }
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
+}
+
+int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g) return RGCN_ERR_ARG;
+  return aggregate_levels(g, transposed, 0, g->dir[transposed ? 1 : 0].num_levels, x, d, agg, workspace,
+                          workspace_bytes, stream);
+}
+
+int rgcn_aggregate_level(const rgcn_graph* g, int transposed, int level, const float* x, int64_t d, float* agg,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  return aggregate_levels(g, transposed, level, level + 1, x, d, agg, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -147,6 +147,9 @@ def clear_graph_cache() -> None:
 # ----------------------------------------------------------------------------------
 # aggregate (rows A3 + A4 / their autograd)
 # ----------------------------------------------------------------------------------
+# bench.py sets this to a list to collect (transposed, d, start_event, end_event) per
+# level-0 gather launch; None (the default) means one C call per aggregate, no events.
+GATHER_EVENTS = None
 def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     """``[N, R*d]``: per-(dst, rel) mean of source rows (``transposed=False``) or the
     1/cnt-weighted sum over out-edges per (src, rel) (``transposed=True``)."""
@@ -163,8 +166,22 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False) -
         out = torch.empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
         nbytes = lib.rgcn_aggregate_workspace_bytes(graph.handle, int(transposed), d)
         ws = _workspace(nbytes, x.device)
-        rc = lib.rgcn_aggregate(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
-                                _stream())
+        if GATHER_EVENTS is None:
+            rc = lib.rgcn_aggregate(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
+                                    _stream())
+        else:
+            # measurement mode (bench.py): same launches, level 0 (the gather kernel proper)
+            # bracketed by HIP events on the stream it is launched on
+            rc = 0
+            for level in range(graph.num_levels(transposed)):
+                if level == 0:
+                    beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    beg.record()
+                rc = rc or lib.rgcn_aggregate_level(graph.handle, int(transposed), level, _ptr(x), d,
+                                                    _ptr(out), _ptr(ws), nbytes, _stream())
+                if level == 0:
+                    end.record()
+                    GATHER_EVENTS.append((bool(transposed), d, beg, end))
     _lib.check(rc, "rgcn_aggregate")
     return out
 
