@@ -66,6 +66,17 @@ typedef struct rgcn_graph rgcn_graph;
 int rgcn_graph_create(const int64_t* edge_index, const int64_t* edge_type, int64_t num_edges,
                       int64_t num_nodes, int64_t num_relations, void* stream,
                       rgcn_graph** out);
+/* One direction between two node sets - the shard of a node-partitioned graph (SURVEY.md
+ * section 8e): segments are key_node*R + rel over num_key_nodes (the rows this rank owns),
+ * col[] ids refer to num_other_nodes (the gathered rows of all ranks).  edge_weight == NULL:
+ * mean mode (divide by the segment size, i.e. the forward structure of a rank that holds all
+ * in-edges of its rows); otherwise weighted-sum mode with the given per-edge weights in input
+ * order (the transposed structure, weights = 1 / global cnt[dst, rel]).  Only direction 0 of
+ * the returned handle exists (use transposed = 0). */
+int rgcn_graph_create_bipartite(const int64_t* key_node, const int64_t* other_node,
+                                const int64_t* edge_type, int64_t num_edges, int64_t num_key_nodes,
+                                int64_t num_other_nodes, int64_t num_relations,
+                                const float* edge_weight, void* stream, rgcn_graph** out);
 void rgcn_graph_destroy(rgcn_graph* g);
 
 /* sizes */

@@ -32,6 +32,7 @@ PROTOTYPES = {
     "rgcn_abi_version": (c_int, []),
     "rgcn_strerror": (c_char_p, [c_int]),
     "rgcn_graph_create": (c_int, [_P, _P, _I64, _I64, _I64, _P, POINTER(c_void_p)]),
+    "rgcn_graph_create_bipartite": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, POINTER(c_void_p)]),
     "rgcn_graph_destroy": (None, [c_void_p]),
     "rgcn_graph_num_edges": (_I64, [c_void_p]),
     "rgcn_graph_num_nodes": (_I64, [c_void_p]),

@@ -97,7 +97,7 @@ size_t rgcn_aggregate_workspace_bytes(const rgcn_graph* g, int transposed, int64
 static int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, const float* x, int64_t d,
                             float* agg, void* workspace, size_t workspace_bytes, void* stream_) {
   if (!g || !agg || d <= 0 || (d & 3)) return RGCN_ERR_ARG;
-  if (g->N == 0) return RGCN_OK;
+  if (g->dir[transposed ? 1 : 0].n_key == 0) return RGCN_OK;
   if (!x) return RGCN_ERR_ARG;
   if (d > (1 << 20)) return RGCN_ERR_UNSUPPORTED;
   const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
@@ -107,8 +107,9 @@ static int aggregate_levels(const rgcn_graph* g, int transposed, int first, int 
     return RGCN_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   float* partial = (float*)workspace;
-  const float* cnt = transposed ? nullptr : c->val;
-  const bool weighted = transposed != 0;
+  if (!c->rowptr) return RGCN_ERR_ARG;   // direction not built
+  const float* cnt = c->weighted ? nullptr : c->val;
+  const bool weighted = c->weighted;
   const int q = (int)(d / 4);
   for (int l = first; l < last; ++l) {
     if (q <= 1) launch_level<1>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);

@@ -29,7 +29,10 @@ struct rgcn_csr {
   int32_t* rowptr = nullptr;  // [N*R+1]
   int32_t* col = nullptr;     // [E]  the other endpoint
   int64_t* perm = nullptr;    // [E]  original column of each bucketed edge
-  float* val = nullptr;       // cnt[N*R] (forward) or w_t[E] (transposed)
+  float* val = nullptr;       // cnt[n_key*R] (mean mode) or w[E] (weighted-sum mode)
+  bool weighted = false;      // false: agg = sum / cnt (mean); true: agg = sum of w[e] * row
+  int64_t n_key = 0;          // nodes that own segments (rows of agg = n_key * R)
+  int64_t n_other = 0;        // nodes the col[] ids refer to (rows of x)
   int num_levels = 0;
   rgcn_item* items[RGCN_MAX_LEVELS] = {};
   int64_t num_items[RGCN_MAX_LEVELS] = {};

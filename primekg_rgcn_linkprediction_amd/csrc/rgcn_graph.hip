@@ -17,22 +17,20 @@ namespace {
 
 constexpr int kThreads = 256;
 
-__global__ void k_validate(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ edge_type,
-                           int64_t E, int64_t N, int64_t R, int* __restrict__ flag) {
+__global__ void k_validate(const int64_t* __restrict__ key_node, const int64_t* __restrict__ other_node,
+                           const int64_t* __restrict__ edge_type, int64_t E, int64_t n_key, int64_t n_other,
+                           int64_t R, int* __restrict__ flag) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  int64_t s = edge_index[e], d = edge_index[E + e], t = edge_type[e];
-  if (s < 0 || s >= N || d < 0 || d >= N || t < 0 || t >= R) atomicOr(flag, 1);
+  int64_t k = key_node[e], o = other_node[e], t = edge_type[e];
+  if (k < 0 || k >= n_key || o < 0 || o >= n_other || t < 0 || t >= R) atomicOr(flag, 1);
 }
 
-// key = node*R + rel with node = destination (forward) or source (transposed).
-__global__ void k_make_keys(const int64_t* __restrict__ edge_index, const int64_t* __restrict__ edge_type,
-                            int64_t E, int64_t R, int transposed, uint32_t* __restrict__ keys,
-                            uint32_t* __restrict__ ids) {
+__global__ void k_make_keys(const int64_t* __restrict__ key_node, const int64_t* __restrict__ edge_type,
+                            int64_t E, int64_t R, uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  int64_t node = transposed ? edge_index[e] : edge_index[E + e];
-  keys[e] = (uint32_t)(node * R + edge_type[e]);
+  keys[e] = (uint32_t)(key_node[e] * R + edge_type[e]);
   ids[e] = (uint32_t)e;
 }
 
@@ -47,14 +45,14 @@ __global__ void k_rowptr(const uint32_t* __restrict__ skeys, int64_t E, int64_t 
   for (int64_t k = lo; k <= hi; ++k) rowptr[k] = (int32_t)e;
 }
 
-__global__ void k_fill_edges(const int64_t* __restrict__ edge_index, int64_t E, int transposed,
+__global__ void k_fill_edges(const int64_t* __restrict__ other_node, int64_t E,
                              const uint32_t* __restrict__ sids, int32_t* __restrict__ col,
                              int64_t* __restrict__ perm) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   uint32_t p = sids[e];
   perm[e] = (int64_t)p;
-  col[e] = (int32_t)(transposed ? edge_index[E + p] : edge_index[p]);
+  col[e] = (int32_t)other_node[p];
 }
 
 __global__ void k_counts(const int32_t* __restrict__ rowptr, int64_t NR, float* __restrict__ cnt) {
@@ -72,6 +70,13 @@ __global__ void k_edge_weights(const uint32_t* __restrict__ skeys_t, const int32
   if (e >= E) return;
   int64_t rel = (int64_t)(skeys_t[e] % (uint32_t)R);
   w[e] = 1.0f / cnt[(int64_t)col_t[e] * R + rel];
+}
+
+// caller-supplied per-edge weights, moved into bucketed order
+__global__ void k_permute_weights(const float* __restrict__ w_in, const int64_t* __restrict__ perm, int64_t E,
+                                  float* __restrict__ w) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < E) w[e] = w_in[perm[e]];
 }
 
 inline unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, ceil_div64(n, kThreads)); }
@@ -142,75 +147,140 @@ void free_csr(rgcn_csr* c) {
 struct Scratch {
   uint32_t *keys = nullptr, *ids = nullptr, *skeys[2] = {nullptr, nullptr}, *sids = nullptr;
   void* sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
   int* flag = nullptr;
+  int alloc(int64_t E) {
+    RGCN_HIP_TRY(hipMalloc((void**)&flag, sizeof(int)));
+    if (E <= 0) return RGCN_OK;
+    RGCN_HIP_TRY(hipMalloc((void**)&keys, E * sizeof(uint32_t)));
+    RGCN_HIP_TRY(hipMalloc((void**)&ids, E * sizeof(uint32_t)));
+    RGCN_HIP_TRY(hipMalloc((void**)&skeys[0], E * sizeof(uint32_t)));
+    RGCN_HIP_TRY(hipMalloc((void**)&skeys[1], E * sizeof(uint32_t)));
+    RGCN_HIP_TRY(hipMalloc((void**)&sids, E * sizeof(uint32_t)));
+    return RGCN_OK;
+  }
   ~Scratch() {
     (void)hipFree(keys); (void)hipFree(ids); (void)hipFree(skeys[0]); (void)hipFree(skeys[1]);
     (void)hipFree(sids); (void)hipFree(sort_tmp); (void)hipFree(flag);
   }
 };
 
-int create_impl(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t N, int64_t R,
-                hipStream_t stream, rgcn_graph* g) {
-  const int64_t NR = N * R;
-  g->E = E; g->N = N; g->R = R;
-  Scratch sc;
-  RGCN_HIP_TRY(hipMalloc((void**)&sc.flag, sizeof(int)));
+int validate(const int64_t* key_node, const int64_t* other_node, const int64_t* edge_type, int64_t E, int64_t n_key,
+             int64_t n_other, int64_t R, Scratch& sc, hipStream_t stream) {
+  if (E <= 0) return RGCN_OK;
   RGCN_HIP_TRY(hipMemsetAsync(sc.flag, 0, sizeof(int), stream));
-  if (E > 0) {
-    k_validate<<<grid_for(E), kThreads, 0, stream>>>(edge_index, edge_type, E, N, R, sc.flag);
-    int host_flag = 0;
-    RGCN_HIP_TRY(hipMemcpyAsync(&host_flag, sc.flag, sizeof(int), hipMemcpyDeviceToHost, stream));
-    RGCN_HIP_TRY(hipStreamSynchronize(stream));
-    if (host_flag) return RGCN_ERR_RANGE;
+  k_validate<<<grid_for(E), kThreads, 0, stream>>>(key_node, other_node, edge_type, E, n_key, n_other, R, sc.flag);
+  int host_flag = 0;
+  RGCN_HIP_TRY(hipMemcpyAsync(&host_flag, sc.flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+  RGCN_HIP_TRY(hipStreamSynchronize(stream));
+  return host_flag ? RGCN_ERR_RANGE : RGCN_OK;
+}
 
-    RGCN_HIP_TRY(hipMalloc((void**)&sc.keys, E * sizeof(uint32_t)));
-    RGCN_HIP_TRY(hipMalloc((void**)&sc.ids, E * sizeof(uint32_t)));
-    RGCN_HIP_TRY(hipMalloc((void**)&sc.skeys[0], E * sizeof(uint32_t)));
-    RGCN_HIP_TRY(hipMalloc((void**)&sc.skeys[1], E * sizeof(uint32_t)));
-    RGCN_HIP_TRY(hipMalloc((void**)&sc.sids, E * sizeof(uint32_t)));
+// rowptr / col / perm of one direction; sorted keys are left in sc.skeys[slot].
+int build_structure(const int64_t* key_node, const int64_t* other_node, const int64_t* edge_type, int64_t E,
+                    int64_t n_key, int64_t n_other, int64_t R, int slot, Scratch& sc, hipStream_t stream,
+                    rgcn_csr* c) {
+  const int64_t NR = n_key * R;
+  c->n_key = n_key;
+  c->n_other = n_other;
+  RGCN_HIP_TRY(hipMalloc((void**)&c->rowptr, (NR + 1) * sizeof(int32_t)));
+  if (E <= 0) {
+    RGCN_HIP_TRY(hipMemsetAsync(c->rowptr, 0, (NR + 1) * sizeof(int32_t), stream));
+    return RGCN_OK;
   }
   int end_bit = 1;
   while (end_bit < 32 && ((int64_t)1 << end_bit) < NR) ++end_bit;
-
-  for (int t = 0; t < 2; ++t) {
-    rgcn_csr* c = &g->dir[t];
-    RGCN_HIP_TRY(hipMalloc((void**)&c->rowptr, (NR + 1) * sizeof(int32_t)));
-    if (E > 0) {
-      RGCN_HIP_TRY(hipMalloc((void**)&c->col, E * sizeof(int32_t)));
-      RGCN_HIP_TRY(hipMalloc((void**)&c->perm, E * sizeof(int64_t)));
-      k_make_keys<<<grid_for(E), kThreads, 0, stream>>>(edge_index, edge_type, E, R, t, sc.keys, sc.ids);
-      size_t tmp_bytes = 0;
-      RGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, sc.keys, sc.skeys[t], sc.ids,
-                                                       sc.sids, (int)E, 0, end_bit, stream));
-      if (!sc.sort_tmp) RGCN_HIP_TRY(hipMalloc(&sc.sort_tmp, tmp_bytes + 256));
-      RGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sc.sort_tmp, tmp_bytes, sc.keys, sc.skeys[t], sc.ids,
-                                                       sc.sids, (int)E, 0, end_bit, stream));
-      k_rowptr<<<grid_for(E + 1), kThreads, 0, stream>>>(sc.skeys[t], E, NR, c->rowptr);
-      k_fill_edges<<<grid_for(E), kThreads, 0, stream>>>(edge_index, E, t, sc.sids, c->col, c->perm);
-    } else {
-      RGCN_HIP_TRY(hipMemsetAsync(c->rowptr, 0, (NR + 1) * sizeof(int32_t), stream));
-    }
+  RGCN_HIP_TRY(hipMalloc((void**)&c->col, E * sizeof(int32_t)));
+  RGCN_HIP_TRY(hipMalloc((void**)&c->perm, E * sizeof(int64_t)));
+  k_make_keys<<<grid_for(E), kThreads, 0, stream>>>(key_node, edge_type, E, R, sc.keys, sc.ids);
+  size_t tmp_bytes = 0;
+  RGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, sc.keys, sc.skeys[slot], sc.ids, sc.sids,
+                                                   (int)E, 0, end_bit, stream));
+  if (tmp_bytes > sc.sort_tmp_bytes) {
+    RGCN_HIP_TRY(hipStreamSynchronize(stream));
+    (void)hipFree(sc.sort_tmp);
+    sc.sort_tmp = nullptr;
+    RGCN_HIP_TRY(hipMalloc(&sc.sort_tmp, tmp_bytes + 256));
+    sc.sort_tmp_bytes = tmp_bytes;
   }
-  // forward: cnt[N*R]; transposed: per-edge 1/cnt[dst, rel]
-  RGCN_HIP_TRY(hipMalloc((void**)&g->dir[0].val, std::max<int64_t>(NR, 1) * sizeof(float)));
-  if (NR > 0) k_counts<<<grid_for(NR), kThreads, 0, stream>>>(g->dir[0].rowptr, NR, g->dir[0].val);
+  RGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(sc.sort_tmp, tmp_bytes, sc.keys, sc.skeys[slot], sc.ids, sc.sids,
+                                                   (int)E, 0, end_bit, stream));
+  k_rowptr<<<grid_for(E + 1), kThreads, 0, stream>>>(sc.skeys[slot], E, NR, c->rowptr);
+  k_fill_edges<<<grid_for(E), kThreads, 0, stream>>>(other_node, E, sc.sids, c->col, c->perm);
+  return RGCN_OK;
+}
+
+int plan_structure(rgcn_csr* c, int64_t R, hipStream_t stream) {
+  const int64_t NR = c->n_key * R;
+  std::vector<int32_t> rp((size_t)NR + 1);
+  RGCN_HIP_TRY(hipMemcpyAsync(rp.data(), c->rowptr, (NR + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  RGCN_HIP_TRY(hipStreamSynchronize(stream));
+  return build_plan(rp, NR, c);
+}
+
+int mean_counts(rgcn_csr* c, int64_t R, hipStream_t stream) {
+  const int64_t NR = c->n_key * R;
+  RGCN_HIP_TRY(hipMalloc((void**)&c->val, std::max<int64_t>(NR, 1) * sizeof(float)));
+  if (NR > 0) k_counts<<<grid_for(NR), kThreads, 0, stream>>>(c->rowptr, NR, c->val);
+  c->weighted = false;
+  return RGCN_OK;
+}
+
+#define TRY_RC(expr) do { int rc__ = (expr); if (rc__ != RGCN_OK) return rc__; } while (0)
+
+// square graph, both directions
+int create_impl(const int64_t* edge_index, const int64_t* edge_type, int64_t E, int64_t N, int64_t R,
+                hipStream_t stream, rgcn_graph* g) {
+  g->E = E; g->N = N; g->R = R;
+  const int64_t* src = edge_index;
+  const int64_t* dst = edge_index + E;
+  Scratch sc;
+  TRY_RC(sc.alloc(E));
+  TRY_RC(validate(dst, src, edge_type, E, N, N, R, sc, stream));
+  TRY_RC(build_structure(dst, src, edge_type, E, N, N, R, 0, sc, stream, &g->dir[0]));
+  TRY_RC(build_structure(src, dst, edge_type, E, N, N, R, 1, sc, stream, &g->dir[1]));
+  TRY_RC(mean_counts(&g->dir[0], R, stream));
+  g->dir[1].weighted = true;
   if (E > 0) {
     RGCN_HIP_TRY(hipMalloc((void**)&g->dir[1].val, E * sizeof(float)));
     k_edge_weights<<<grid_for(E), kThreads, 0, stream>>>(sc.skeys[1], g->dir[1].col, g->dir[0].val, E, R,
                                                          g->dir[1].val);
   }
   RGCN_HIP_TRY(hipGetLastError());
-
-  std::vector<int32_t> rp((size_t)NR + 1);
-  for (int t = 0; t < 2; ++t) {
-    RGCN_HIP_TRY(hipMemcpyAsync(rp.data(), g->dir[t].rowptr, (NR + 1) * sizeof(int32_t),
-                                hipMemcpyDeviceToHost, stream));
-    RGCN_HIP_TRY(hipStreamSynchronize(stream));
-    int rc = build_plan(rp, NR, &g->dir[t]);
-    if (rc != RGCN_OK) return rc;
-  }
+  TRY_RC(plan_structure(&g->dir[0], R, stream));
+  TRY_RC(plan_structure(&g->dir[1], R, stream));
   RGCN_HIP_TRY(hipStreamSynchronize(stream));
   return RGCN_OK;
+}
+
+// one direction between two node sets (a shard of a partitioned graph)
+int create_bipartite_impl(const int64_t* key_node, const int64_t* other_node, const int64_t* edge_type, int64_t E,
+                          int64_t n_key, int64_t n_other, int64_t R, const float* edge_weight, hipStream_t stream,
+                          rgcn_graph* g) {
+  g->E = E; g->N = n_key; g->R = R;
+  Scratch sc;
+  TRY_RC(sc.alloc(E));
+  TRY_RC(validate(key_node, other_node, edge_type, E, n_key, n_other, R, sc, stream));
+  rgcn_csr* c = &g->dir[0];
+  TRY_RC(build_structure(key_node, other_node, edge_type, E, n_key, n_other, R, 0, sc, stream, c));
+  if (edge_weight) {
+    c->weighted = true;
+    if (E > 0) {
+      RGCN_HIP_TRY(hipMalloc((void**)&c->val, E * sizeof(float)));
+      k_permute_weights<<<grid_for(E), kThreads, 0, stream>>>(edge_weight, c->perm, E, c->val);
+    }
+  } else {
+    TRY_RC(mean_counts(c, R, stream));
+  }
+  RGCN_HIP_TRY(hipGetLastError());
+  TRY_RC(plan_structure(c, R, stream));
+  RGCN_HIP_TRY(hipStreamSynchronize(stream));
+  return RGCN_OK;
+}
+
+bool too_big(int64_t n_key, int64_t n_other, int64_t R, int64_t E) {
+  const int64_t lim = ((int64_t)1 << 31) - 1;
+  return n_key * R >= lim || n_other >= lim || E >= lim;
 }
 
 }  // namespace
@@ -237,11 +307,31 @@ int rgcn_graph_create(const int64_t* edge_index, const int64_t* edge_type, int64
   *out = nullptr;
   if (num_edges < 0 || num_nodes < 0 || num_relations <= 0) return RGCN_ERR_ARG;
   if (num_edges > 0 && (!edge_index || !edge_type)) return RGCN_ERR_ARG;
-  if (num_nodes * num_relations >= ((int64_t)1 << 31) - 1 || num_edges >= ((int64_t)1 << 31) - 1)
-    return RGCN_ERR_UNSUPPORTED;
+  if (too_big(num_nodes, num_nodes, num_relations, num_edges)) return RGCN_ERR_UNSUPPORTED;
   rgcn_graph* g = new (std::nothrow) rgcn_graph();
   if (!g) return RGCN_ERR_HIP;
   int rc = create_impl(edge_index, edge_type, num_edges, num_nodes, num_relations, (hipStream_t)stream, g);
+  if (rc != RGCN_OK) {
+    rgcn_graph_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return RGCN_OK;
+}
+
+int rgcn_graph_create_bipartite(const int64_t* key_node, const int64_t* other_node, const int64_t* edge_type,
+                                int64_t num_edges, int64_t num_key_nodes, int64_t num_other_nodes,
+                                int64_t num_relations, const float* edge_weight, void* stream,
+                                rgcn_graph** out) {
+  if (!out) return RGCN_ERR_ARG;
+  *out = nullptr;
+  if (num_edges < 0 || num_key_nodes < 0 || num_other_nodes < 0 || num_relations <= 0) return RGCN_ERR_ARG;
+  if (num_edges > 0 && (!key_node || !other_node || !edge_type)) return RGCN_ERR_ARG;
+  if (too_big(num_key_nodes, num_other_nodes, num_relations, num_edges)) return RGCN_ERR_UNSUPPORTED;
+  rgcn_graph* g = new (std::nothrow) rgcn_graph();
+  if (!g) return RGCN_ERR_HIP;
+  int rc = create_bipartite_impl(key_node, other_node, edge_type, num_edges, num_key_nodes, num_other_nodes,
+                                 num_relations, edge_weight, (hipStream_t)stream, g);
   if (rc != RGCN_OK) {
     rgcn_graph_destroy(g);
     return rc;
@@ -280,11 +370,12 @@ int rgcn_graph_export(const rgcn_graph* g, int transposed, int32_t* rowptr, int3
   if (!g) return RGCN_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
-  const size_t nr = (size_t)(g->N * g->R), e = (size_t)g->E;
+  if (!c->rowptr) return RGCN_ERR_ARG;   // direction not built (bipartite handles have only one)
+  const size_t nr = (size_t)(c->n_key * g->R), e = (size_t)g->E;
   if (rowptr) RGCN_HIP_TRY(hipMemcpyAsync(rowptr, c->rowptr, (nr + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
   if (col && e) RGCN_HIP_TRY(hipMemcpyAsync(col, c->col, e * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
   if (perm && e) RGCN_HIP_TRY(hipMemcpyAsync(perm, c->perm, e * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
-  const size_t nval = transposed ? e : nr;
+  const size_t nval = c->weighted ? e : nr;
   if (val && nval) RGCN_HIP_TRY(hipMemcpyAsync(val, c->val, nval * sizeof(float), hipMemcpyDeviceToDevice, stream));
   return RGCN_OK;
 }

@@ -1,0 +1,227 @@
+"""Node-partitioned execution of the R-GCN encoder: one process per GPU,
+``torch.distributed`` (backend "nccl" = RCCL over xGMI), one exchange per layer and
+direction.  The reference has no distributed code at all; this is the
+multi-GPU form BASELINE.json's north star asks for, built for MI355X's point-to-point xGMI.
+
+Scheme ("owner computes", SURVEY.md section 8e "alternative worth measuring" - chosen over
+the partial-sum all-reduce form because it keeps BOTH halves of the layer sharded):
+
+* nodes are dealt to the P ranks greedily in descending degree (least-loaded rank first,
+  at most cap = ceil(N/P) row slots each): near-equal shares of edge endpoints (PrimeKG ids
+  are type-sorted and genes carry ~88 % of the endpoints, so contiguous ranges would be
+  badly skewed, and its hubs defeat a plain round-robin deal);
+* rank p holds the in-edges of its rows (forward structure, mean mode) and the out-edges of
+  its rows (transposed structure, weights 1/cnt[dst, rel] from the GLOBAL counts);
+* forward of a layer : all-gather x [P*cap, d_in]  -> gather+mean over own (dst, rel)
+  segments -> MFMA transform of own rows only;
+* backward           : all-gather g [P*cap, d_out] -> weighted gather over own (src, rel)
+  segments -> input-grad transform of own rows; parameter grads are partial sums over own
+  rows -> ONE flat all-reduce per layer (<= 0.4 MB).
+
+No row of the output is ever a cross-rank partial sum, so activations and input gradients
+are bit-identical to the single-GPU run (same per-segment summation order, same k-ordered
+MFMA chains); only the parameter gradients see a different (rank-ordered) summation.
+The all-reduce form of the north star would make every rank run the dense transform over all
+N rows (or ship R*d_in-wide partial aggregates): it shards only the gather.
+
+xGMI is point to point (7 links per GPU): an all-gather of equal slabs drives all seven
+links at once, which is why rows are padded to equal ``cap`` slabs instead of using
+variable-size ranges.
+
+The compute backend is injectable so that the N > 1 logic is covered by world_size-2 gloo
+tests on CPU (tests/ supply an oracle-backed backend); the product backend is the HIP
+library and there is no CPU fallback here.
+"""
+from __future__ import annotations
+
+import heapq
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+class HipBackend:
+    """The product compute path: every call lands in librgcn_hip.so."""
+
+    def __init__(self):
+        from . import ops
+        self.ops = ops
+
+    def make_shard(self, key, other, etype, n_key, n_other, num_relations, edge_weight=None):
+        return self.ops.BucketedGraph.from_shard(key, other, etype, n_key, n_other, num_relations,
+                                                 edge_weight)
+
+    def aggregate(self, shard, x):
+        return self.ops.aggregate(shard, x)
+
+    def transform_fwd(self, agg, x, weight, root, bias):
+        return self.ops.transform_fwd(agg, x, weight, root, bias)
+
+    def transform_bwd_input(self, gagg, g, weight, root):
+        return self.ops.transform_bwd_input(gagg, g, weight, root)
+
+    def transform_bwd_params(self, agg, x, g, num_relations, want_root, want_bias):
+        return self.ops.transform_bwd_params(agg, x, g, num_relations, want_root, want_bias)
+
+
+class NodePartition:
+    """Deterministic assignment node -> (rank, slot), identical on every rank."""
+
+    def __init__(self, edge_index: Tensor, num_nodes: int, world: int):
+        ei = edge_index.cpu()
+        deg = torch.bincount(ei[0], minlength=num_nodes) + torch.bincount(ei[1], minlength=num_nodes)
+        order = torch.argsort(deg, descending=True, stable=True)        # heavy nodes first
+        self.world, self.num_nodes = world, num_nodes
+        self.cap = (num_nodes + world - 1) // world
+        # longest-processing-time greedy under a capacity of `cap` rows per rank: each node, in
+        # descending degree, goes to the least-loaded rank that still has a free slot
+        # (ties -> lowest rank).  A Zipf tail (top node ~4 % of all endpoints) defeats a plain
+        # round-robin deal; this keeps max/mean edge load within a few percent.
+        heap = [(0, k) for k in range(world)]
+        fill = [0] * world
+        rank_l, slot_l = [0] * num_nodes, [0] * num_nodes
+        deg_l = deg[order].tolist()
+        for node, d in zip(order.tolist(), deg_l):
+            load, k = heapq.heappop(heap)
+            rank_l[node], slot_l[node] = k, fill[k]
+            fill[k] += 1
+            if fill[k] < self.cap:
+                heapq.heappush(heap, (load + d, k))
+        self.rank_of = torch.tensor(rank_l, dtype=torch.int64)
+        self.slot_of = torch.tensor(slot_l, dtype=torch.int64)
+        self.pid = self.rank_of * self.cap + self.slot_of               # row in the gathered layout
+
+    def nodes_of(self, rank: int) -> Tensor:
+        """node ids owned by ``rank`` in slot order"""
+        mine = torch.nonzero(self.rank_of == rank).flatten()
+        return mine[torch.argsort(self.slot_of[mine])]
+
+    def shard_rows(self, full: Tensor, rank: int) -> Tensor:
+        """[N, ...] -> [cap, ...] rows of ``rank`` (zero padded)"""
+        nodes = self.nodes_of(rank)
+        out = full.new_zeros((self.cap,) + tuple(full.shape[1:]))
+        out[: nodes.numel()] = full[nodes]
+        return out
+
+    def unshard_rows(self, gathered: Tensor) -> Tensor:
+        """[P*cap, ...] gathered layout -> [N, ...] in node order"""
+        return gathered[self.pid.to(gathered.device)]
+
+
+class RankShard:
+    """What one rank holds of the static graph: both bucketed structures of its rows."""
+
+    def __init__(self, part: NodePartition, edge_index: Tensor, edge_type: Tensor, num_relations: int,
+                 rank: int, device, backend):
+        ei, et = edge_index.cpu(), edge_type.cpu()
+        n, r = part.num_nodes, num_relations
+        src, dst = ei[0], ei[1]
+        cnt = torch.bincount(dst * r + et, minlength=n * r).clamp(min=1).to(torch.float32)
+        self.part, self.rank, self.num_relations = part, rank, r
+        self.cap, self.rows_all = part.cap, part.cap * part.world
+        m_in = part.rank_of[dst] == rank             # in-edges of own rows, column order kept
+        self.g_in = backend.make_shard(part.slot_of[dst[m_in]].to(device), part.pid[src[m_in]].to(device),
+                                       et[m_in].to(device), self.cap, self.rows_all, r)
+        m_out = part.rank_of[src] == rank            # out-edges of own rows
+        w = (1.0 / cnt[dst[m_out] * r + et[m_out]]).to(torch.float32)
+        self.g_out = backend.make_shard(part.slot_of[src[m_out]].to(device), part.pid[dst[m_out]].to(device),
+                                        et[m_out].to(device), self.cap, self.rows_all, r, w.to(device))
+        self.num_in_edges, self.num_out_edges = int(m_in.sum()), int(m_out.sum())
+
+
+def _all_gather_rows(own: Tensor, world: int, group) -> Tensor:
+    out = own.new_empty((own.size(0) * world,) + tuple(own.shape[1:]))
+    dist.all_gather_into_tensor(out, own.contiguous(), group=group)
+    return out
+
+
+class _PartitionedConvFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_own, weight, root, bias, shard: RankShard, backend, group):
+        x_own = x_own.contiguous()
+        weight = weight.contiguous()
+        x_all = _all_gather_rows(x_own, shard.part.world, group)           # the layer's one exchange
+        agg = backend.aggregate(shard.g_in, x_all)
+        out = backend.transform_fwd(agg, x_own, weight, root, bias)
+        ctx.shard, ctx.backend, ctx.group = shard, backend, group
+        ctx.has_root, ctx.has_bias = root is not None, bias is not None
+        ctx.save_for_backward(x_own, agg, weight, root)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_own):
+        x_own, agg, weight, root = ctx.saved_tensors
+        shard, backend, group = ctx.shard, ctx.backend, ctx.group
+        g_own = g_own.contiguous()
+        need_x = ctx.needs_input_grad[0]
+        gw, groot, gbias = backend.transform_bwd_params(agg, x_own, g_own, shard.num_relations,
+                                                        ctx.has_root, ctx.has_bias)
+        parts = [t for t in (gw, groot, gbias) if t is not None]
+        flat = torch.cat([t.reshape(-1) for t in parts])
+        work = dist.all_reduce(flat, group=group, async_op=True)            # overlaps the gather below
+        gx = None
+        if need_x:
+            g_all = _all_gather_rows(g_own, shard.part.world, group)
+            gagg = backend.aggregate(shard.g_out, g_all)
+            gx = backend.transform_bwd_input(gagg, g_own, weight, root)
+        work.wait()
+        outs, off = [], 0
+        for t in parts:
+            outs.append(flat[off: off + t.numel()].view_as(t))
+            off += t.numel()
+        it = iter(outs)
+        gw = next(it)
+        groot = next(it) if ctx.has_root else None
+        gbias = next(it) if ctx.has_bias else None
+        return gx, gw, groot, gbias, None, None, None
+
+
+def partitioned_conv(x_own: Tensor, weight: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
+                     shard: RankShard, backend, group=None) -> Tensor:
+    """One R-GCN layer on this rank's rows (``[cap, d_in] -> [cap, d_out]``)."""
+    return _PartitionedConvFunction.apply(x_own, weight, root, bias, shard, backend, group)
+
+
+class PartitionedEncoder:
+    """conv1 -> relu -> conv2 over a node-partitioned graph (what ``bench.py --gpus N`` times).
+
+    ``convs``: two ``RGCNConv``-like modules (``effective_weight()``, ``root``, ``bias``)
+    with identical parameters on every rank; ``emb_full``: the [N, d] input table."""
+
+    def __init__(self, edge_index: Tensor, edge_type: Tensor, num_nodes: int, num_relations: int,
+                 emb_full: Tensor, convs: Sequence[torch.nn.Module], device, backend=None, group=None):
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.group = group
+        self.backend = backend if backend is not None else HipBackend()
+        self.part = NodePartition(edge_index, num_nodes, self.world)
+        self.shard = RankShard(self.part, edge_index, edge_type, num_relations, self.rank, device,
+                               self.backend)
+        self.emb = self.part.shard_rows(emb_full, self.rank).to(device).requires_grad_(True)
+        self.convs: List[torch.nn.Module] = [c.to(device) for c in convs]
+        self.params = [self.emb] + [p for c in self.convs for p in c.parameters()]
+
+    def shard_rows(self, full: Tensor) -> Tensor:
+        return self.part.shard_rows(full, self.rank)
+
+    def forward(self) -> Tensor:
+        c1, c2 = self.convs
+        h = partitioned_conv(self.emb, c1.effective_weight(), c1.root, c1.bias, self.shard, self.backend,
+                             self.group)
+        h = torch.relu(h)
+        return partitioned_conv(h, c2.effective_weight(), c2.root, c2.bias, self.shard, self.backend,
+                                self.group)
+
+    def step(self, cot_own: Tensor) -> Tensor:
+        """forward + backward with the given cotangent rows; grads land in ``.grad``."""
+        out = self.forward()
+        for p in self.params:
+            p.grad = None
+        out.backward(cot_own)
+        return out
+
+    def gather_output(self, own: Tensor) -> Tensor:
+        """all ranks' rows -> [N, d] in node order (for checks)"""
+        return self.part.unshard_rows(_all_gather_rows(own.detach(), self.world, self.group))

@@ -70,6 +70,8 @@ class BucketedGraph:
         lib = _lib.load()
         self.device = edge_index.device
         self.num_nodes, self.num_relations = int(num_nodes), int(num_relations)
+        self.num_other_nodes = self.num_nodes      # rows of the gathered input
+        self.bipartite = False
         self.num_edges = int(edge_index.size(1))
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -78,6 +80,40 @@ class BucketedGraph:
                                        ctypes.byref(handle))
         _lib.check(rc, "rgcn_graph_create")
         self._handle = handle
+
+    @classmethod
+    def from_shard(cls, key_node: torch.Tensor, other_node: torch.Tensor, edge_type: torch.Tensor,
+                   num_key_nodes: int, num_other_nodes: int, num_relations: int,
+                   edge_weight: Optional[torch.Tensor] = None) -> "BucketedGraph":
+        """One direction between two node sets: the shard a rank of a node-partitioned graph
+        holds (``rgcn_graph_create_bipartite``).  Segments = (key_node, rel) over the rank's
+        own ``num_key_nodes`` rows; ``other_node`` ids index the ``num_other_nodes`` gathered
+        rows.  Without ``edge_weight``: mean mode; with it: weighted-sum mode."""
+        self = cls.__new__(cls)
+        self._handle = None
+        for name, t in (("key_node", key_node), ("other_node", other_node), ("edge_type", edge_type)):
+            _need_gpu(name, t, torch.int64)
+            if t.dim() != 1 or t.size(0) != key_node.size(0):
+                raise ValueError(f"{name} must be [E]")
+        if edge_weight is not None:
+            _need_gpu("edge_weight", edge_weight, torch.float32)
+            if edge_weight.shape != key_node.shape:
+                raise ValueError("edge_weight must be [E]")
+        lib = _lib.load()
+        self.device = key_node.device
+        self.num_nodes, self.num_relations = int(num_key_nodes), int(num_relations)
+        self.num_other_nodes = int(num_other_nodes)
+        self.bipartite = True
+        self.num_edges = int(key_node.size(0))
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = lib.rgcn_graph_create_bipartite(_ptr(key_node), _ptr(other_node), _ptr(edge_type),
+                                                 self.num_edges, self.num_nodes, self.num_other_nodes,
+                                                 self.num_relations, _ptr(edge_weight), _stream(),
+                                                 ctypes.byref(handle))
+        _lib.check(rc, "rgcn_graph_create_bipartite")
+        self._handle = handle
+        return self
 
     @property
     def handle(self) -> ctypes.c_void_p:
@@ -150,12 +186,18 @@ def clear_graph_cache() -> None:
 # bench.py sets this to a list to collect (transposed, d, start_event, end_event) per
 # level-0 gather launch; None (the default) means one C call per aggregate, no events.
 GATHER_EVENTS = None
+
+
 def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     """``[N, R*d]``: per-(dst, rel) mean of source rows (``transposed=False``) or the
-    1/cnt-weighted sum over out-edges per (src, rel) (``transposed=True``)."""
+    1/cnt-weighted sum over out-edges per (src, rel) (``transposed=True``).  For a shard
+    (``BucketedGraph.from_shard``) x holds the gathered rows of all ranks and the result has
+    the rank's own rows."""
     _need_gpu("x", x, torch.float32)
-    if x.dim() != 2 or x.size(0) != graph.num_nodes:
-        raise ValueError(f"x must be [{graph.num_nodes}, d], got {tuple(x.shape)}")
+    if graph.bipartite and transposed:
+        raise ValueError("a shard structure has one direction only (transposed=False)")
+    if x.dim() != 2 or x.size(0) != graph.num_other_nodes:
+        raise ValueError(f"x must be [{graph.num_other_nodes}, d], got {tuple(x.shape)}")
     if x.device != graph.device:
         raise RuntimeError("x and the bucketed graph are on different devices")
     d = x.size(1)
