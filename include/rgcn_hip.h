@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 1
+#define RGCN_ABI_VERSION 2
 
 enum {
   RGCN_OK = 0,
@@ -123,24 +123,25 @@ int rgcn_aggregate_level(const rgcn_graph* g, int transposed, int level, const f
  *
  *   out[N, d_out] = sum_r agg[:, r, :] @ weight[r] + x @ root + bias
  *
- * agg: float[N, R*d_in], x: float[N, d_in], weight: float[R, d_in, d_out] (PyG layout),
- * root: float[d_in, d_out] or NULL, bias: float[d_out] or NULL.
- * `workspace` (rgcn_transform_workspace_bytes) holds the k-contiguous repack of the
- * weights that the MFMA B-operand reads.
+ * agg: float[N, R*d_in], x: float[N, d_in], weight: float[R, d_in, d_out] (PyG layout, read in
+ * place as the MFMA B operand), root: float[d_in, d_out] or NULL, bias: float[d_out] or NULL.
+ * relu != 0 fuses the `F.relu` that follows conv1 (rgcn.py:124) into the epilogue:
+ * out = max(out, 0).
  * ---------------------------------------------------------------------------------- */
-size_t rgcn_transform_workspace_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
 int rgcn_transform_fwd(const float* agg, const float* x, const float* weight, const float* root,
-                       const float* bias, int64_t num_nodes, int64_t num_relations, int64_t d_in,
-                       int64_t d_out, float* out, void* workspace, size_t workspace_bytes,
-                       void* stream);
+                       const float* bias, int relu, int64_t num_nodes, int64_t num_relations,
+                       int64_t d_in, int64_t d_out, float* out, void* stream);
 
 /* Autograd of A6 with respect to the layer input (row A7):
  *   grad_x[N, d_in] = sum_r gagg[:, r, :] @ weight[r]^T + g @ root^T
- * gagg: float[N, R*d_out] = rgcn_aggregate(transposed = 1) of g; g: float[N, d_out]. */
+ * gagg: float[N, R*d_out] = rgcn_aggregate(transposed = 1) of g; g: float[N, d_out].
+ * relu_mask (float[N, d_in] or NULL): when the layer's input x was produced by a fused-ReLU
+ * layer, pass x itself; the epilogue then writes grad_x * (x > 0), i.e. the gradient with
+ * respect to that producer's pre-activation (autograd of rgcn.py:124). */
 int rgcn_transform_bwd_input(const float* gagg, const float* g, const float* weight,
-                             const float* root, int64_t num_nodes, int64_t num_relations,
-                             int64_t d_in, int64_t d_out, float* grad_x, void* workspace,
-                             size_t workspace_bytes, void* stream);
+                             const float* root, const float* relu_mask, int64_t num_nodes,
+                             int64_t num_relations, int64_t d_in, int64_t d_out, float* grad_x,
+                             void* stream);
 
 /* Autograd of A6 with respect to the parameters (row A7):
  *   grad_weight[r] = agg[:, r, :]^T @ g,  grad_root = x^T @ g,  grad_bias = colsum(g)

@@ -33,26 +33,28 @@ def _glorot(t: Optional[Tensor]) -> None:
 
 
 class _RGCNConvFunction(torch.autograd.Function):
-    """x, weight[R, d_in, d_out], root, bias -> out, on a bucketed graph."""
+    """x, weight[R, d_in, d_out], root, bias -> out (optionally relu(out)), on a bucketed graph."""
 
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
-                graph: ops.BucketedGraph) -> Tensor:
+                graph: ops.BucketedGraph, relu: bool = False) -> Tensor:
         x = x.contiguous()
         weight = weight.contiguous()
         root_c = root.contiguous() if root is not None else None
         bias_c = bias.contiguous() if bias is not None else None
-        agg = ops.aggregate(graph, x, transposed=False)                 # rows A3 + A4
-        out = ops.transform_fwd(agg, x, weight, root_c, bias_c)         # row A6
-        ctx.graph = graph
+        agg = ops.aggregate(graph, x, transposed=False)                     # rows A3 + A4
+        out = ops.transform_fwd(agg, x, weight, root_c, bias_c, relu=relu)  # row A6 (+ fused ReLU)
+        ctx.graph, ctx.relu = graph, relu
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
-        ctx.save_for_backward(x, agg, weight, root_c)
+        ctx.save_for_backward(x, agg, weight, root_c, out if relu else None)
         return out
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        x, agg, weight, root = ctx.saved_tensors
+        x, agg, weight, root, out = ctx.saved_tensors
         graph = ctx.graph
+        if ctx.relu:
+            g = g * (out > 0)                                               # ReLU backward
         g = g.contiguous()
         need_x, need_w, need_root, need_bias = ctx.needs_input_grad[:4]
         gx = gw = groot = gbias = None
@@ -60,19 +62,71 @@ class _RGCNConvFunction(torch.autograd.Function):
             gw, groot, gbias = ops.transform_bwd_params(
                 agg, x, g, graph.num_relations, want_root=ctx.has_root, want_bias=ctx.has_bias)
         if need_x:
-            gagg = ops.aggregate(graph, g, transposed=True)             # autograd of A3 + A4
-            gx = ops.transform_bwd_input(gagg, g, weight, root)         # autograd of A6 wrt x
-        return gx, gw, groot, gbias, None
+            gagg = ops.aggregate(graph, g, transposed=True)                 # autograd of A3 + A4
+            gx = ops.transform_bwd_input(gagg, g, weight, root)             # autograd of A6 wrt x
+        return gx, gw, groot, gbias, None, None
 
 
-def rgcn_conv(x: Tensor, edge_index: Tensor, edge_type: Tensor, weight: Tensor,
-              root: Optional[Tensor], bias: Optional[Tensor], num_relations: int) -> Tensor:
-    """Functional form on effective weights ``[R, d_in, d_out]``."""
+class _Encoder2Function(torch.autograd.Function):
+    """conv1 -> ReLU -> conv2 (``src/models/rgcn.py:123-128`` with dropout inactive) as one
+    autograd node: the ReLU rides in conv1's GEMM epilogue, and its backward rides in the
+    epilogue of conv2's input-gradient GEMM (which then emits the gradient with respect to
+    conv1's pre-activation directly), so no elementwise kernel runs between the layers."""
+
+    @staticmethod
+    def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph):
+        x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
+        agg1 = ops.aggregate(graph, x)
+        h = ops.transform_fwd(agg1, x, w1, root1, b1, relu=True)
+        agg2 = ops.aggregate(graph, h)
+        out = ops.transform_fwd(agg2, h, w2, root2, b2)
+        ctx.graph = graph
+        ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
+        ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, agg1, h, agg2, w1, root1, w2, root2 = ctx.saved_tensors
+        graph, r = ctx.graph, ctx.graph.num_relations
+        has_root1, has_b1, has_root2, has_b2 = ctx.flags
+        g = g.contiguous()
+        gw2, groot2, gb2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2)
+        gagg2 = ops.aggregate(graph, g, transposed=True)
+        gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h)      # d loss / d (pre-ReLU of conv1)
+        gw1, groot1, gb1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gagg1 = ops.aggregate(graph, gz, transposed=True)
+            gx = ops.transform_bwd_input(gagg1, gz, w1, root1)
+        return gx, gw1, groot1, gb1, gw2, groot2, gb2, None
+
+
+def _check_x(x: Tensor) -> None:
     if x.dtype != torch.float32:
         raise TypeError(f"x must be float32 (got {x.dtype}); integer-index / embedding mode of "
                         f"PyG's RGCNConv is not used by the reference and not implemented")
+
+
+def rgcn_conv(x: Tensor, edge_index: Tensor, edge_type: Tensor, weight: Tensor,
+              root: Optional[Tensor], bias: Optional[Tensor], num_relations: int,
+              activation: Optional[str] = None) -> Tensor:
+    """Functional form on effective weights ``[R, d_in, d_out]``; ``activation='relu'`` fuses
+    the ReLU into the layer."""
+    _check_x(x)
+    if activation not in (None, "relu"):
+        raise ValueError(f"activation must be None or 'relu', got {activation!r}")
     graph = ops.bucket(edge_index, edge_type, x.size(0), num_relations)
-    return _RGCNConvFunction.apply(x, weight, root, bias, graph)
+    return _RGCNConvFunction.apply(x, weight, root, bias, graph, activation == "relu")
+
+
+def rgcn_encoder2(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: "RGCNConv",
+                  conv2: "RGCNConv") -> Tensor:
+    """``conv2(relu(conv1(x)))`` through the fused two-layer autograd node."""
+    _check_x(x)
+    graph = ops.bucket(edge_index, edge_type, x.size(0), conv1.num_relations)
+    return _Encoder2Function.apply(x, conv1.effective_weight(), conv1.root, conv1.bias,
+                                   conv2.effective_weight(), conv2.root, conv2.bias, graph)
 
 
 class RGCNConv(nn.Module):
@@ -142,7 +196,10 @@ class RGCNConv(nn.Module):
         return (self.comp @ self.weight.view(self.num_bases, -1)).view(
             self.num_relations, self.in_channels_l, self.out_channels)
 
-    def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None) -> Tensor:
+    def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None,
+                activation: Optional[str] = None) -> Tensor:
+        """PyG's ``forward(x, edge_index, edge_type)``; the extra keyword ``activation='relu'``
+        returns ``relu(out)`` with the ReLU fused into the transform's epilogue."""
         if isinstance(x, (tuple, list)) or x is None:
             raise NotImplementedError("x must be a float tensor [N, in_channels]")
         if not isinstance(edge_index, Tensor):
@@ -151,7 +208,7 @@ class RGCNConv(nn.Module):
         if x.dim() != 2 or x.size(1) != self.in_channels_l:
             raise ValueError(f"x must be [N, {self.in_channels_l}], got {tuple(x.shape)}")
         return rgcn_conv(x, edge_index, edge_type, self.effective_weight(), self.root, self.bias,
-                         self.num_relations)
+                         self.num_relations, activation)
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}({self.in_channels_l}, {self.out_channels}, "

@@ -9,8 +9,14 @@
 // work item (a run of <= 64 source rows of one (node, rel) segment); each lane holds a
 // float4 column slice, so every neighbour row is read as one coalesced 16 B x G access and
 // the neighbour sum needs no cross-lane reduction.  A wave64 carries 64/G items.  Eight
-// row loads are kept in flight per group; the adds retire in edge order, which keeps the
-// sum of an unsplit segment identical to a sequential scatter.
+// row loads are kept in flight per group, the column ids of the next eight are fetched
+// behind them, and the adds retire in edge order, which keeps the sum of an unsplit segment
+// identical to a sequential scatter.
+//
+// Segments longer than 64 edges leave one partial row per run; k_reduce_partials sums the
+// (contiguous) partial rows of a segment with a whole workgroup per item (up to 512 rows:
+// 256/G row slots in parallel, LDS combine in slot order), so even a 30k-edge hub costs one
+// extra short launch and the result is run-to-run deterministic.
 #include "rgcn_common.h"
 
 namespace {
@@ -18,40 +24,56 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kUnroll = 8;
 
-template <int G, bool INDEXED, bool WEIGHTED>
+__device__ inline float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ inline void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ inline void f4fma(float4& a, const float4& b, float s) {
+  a.x += b.x * s; a.y += b.y * s; a.z += b.z * s; a.w += b.w * s;
+}
+
+template <int G, bool WEIGHTED>
 __global__ __launch_bounds__(kThreads) void k_aggregate(
-    const float* src, const rgcn_item* __restrict__ items, int64_t nitems,
+    const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
-    float* __restrict__ agg, float* partial, int d) {
+    float* __restrict__ agg, float* __restrict__ partial, int d) {
   const int64_t item_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   const int c4 = ((int)threadIdx.x % G + (int)blockIdx.y * G) * 4;
   if (item_id >= nitems || c4 >= d) return;
   const rgcn_item it = items[item_id];
 
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc = f4zero();
+  int idx_n[kUnroll];
+  float wt_n[kUnroll];
+#pragma unroll
+  for (int u = 0; u < kUnroll; ++u) {
+    const bool ok = it.begin + u < it.end;
+    idx_n[u] = ok ? col[it.begin + u] : -1;
+    wt_n[u] = (WEIGHTED && ok) ? w[it.begin + u] : 0.f;
+  }
   for (int e = it.begin; e < it.end; e += kUnroll) {
     int idx[kUnroll];
     float wt[kUnroll];
     float4 v[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const bool ok = e + u < it.end;
-      idx[u] = ok ? (INDEXED ? col[e + u] : e + u) : -1;
-      wt[u] = (WEIGHTED && ok) ? w[e + u] : 0.f;
+      idx[u] = idx_n[u];
+      wt[u] = wt_n[u];
     }
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[u] = f4zero();
       if (idx[u] >= 0) v[u] = *reinterpret_cast<const float4*>(src + (size_t)idx[u] * d + c4);
     }
 #pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {   // ids of the next round, in flight behind the rows
+      const int en = e + kUnroll + u;
+      const bool ok = en < it.end;
+      idx_n[u] = ok ? col[en] : -1;
+      wt_n[u] = (WEIGHTED && ok) ? w[en] : 0.f;
+    }
+#pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      if (WEIGHTED) {
-        acc.x += v[u].x * wt[u]; acc.y += v[u].y * wt[u];
-        acc.z += v[u].z * wt[u]; acc.w += v[u].w * wt[u];
-      } else {
-        acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
-      }
+      if (WEIGHTED) f4fma(acc, v[u], wt[u]);
+      else f4add(acc, v[u]);
     }
   }
   if (it.flags & 1) {
@@ -65,49 +87,84 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
   }
 }
 
+// One workgroup per item: rows [begin, end) of `partial` (contiguous) -> one row.
+// Slot s of SLOTS = 256/G sums rows begin+s, begin+s+SLOTS, ... in order; the slots are then
+// added in slot order through LDS.  Reads and writes of `partial` never alias inside one
+// launch: a level reads rows written by the level below and writes rows of its own range.
+template <int G>
+__global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* __restrict__ items,
+                                                              const float* __restrict__ cnt,
+                                                              float* __restrict__ agg, float* partial, int d) {
+  constexpr int SLOTS = kThreads / G;
+  __shared__ float4 red[kThreads];
+  const rgcn_item it = items[blockIdx.x];
+  const int gl = (int)threadIdx.x % G, slot = (int)threadIdx.x / G;
+  const int c4 = (gl + (int)blockIdx.y * G) * 4;
+  const bool live = c4 < d;
+  float4 acc = f4zero();
+  if (live) {
+    for (int r0 = it.begin + slot; r0 < it.end; r0 += SLOTS * kUnroll) {
+      float4 v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int row = r0 + u * SLOTS;
+        v[u] = f4zero();
+        if (row < it.end) v[u] = *reinterpret_cast<const float4*>(partial + (size_t)row * d + c4);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) f4add(acc, v[u]);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (slot == 0 && live) {
+    float4 s = red[gl];
+#pragma unroll
+    for (int k = 1; k < SLOTS; ++k) f4add(s, red[k * G + gl]);
+    if (it.flags & 1) {
+      if (cnt) {
+        const float c = cnt[it.dst];
+        s.x /= c; s.y /= c; s.z /= c; s.w /= c;
+      }
+      *reinterpret_cast<float4*>(agg + (size_t)it.dst * d + c4) = s;
+    } else {
+      *reinterpret_cast<float4*>(partial + (size_t)it.dst * d + c4) = s;
+    }
+  }
+}
+
 template <int G>
 void launch_level(const rgcn_csr* c, int level, bool weighted, const float* x, const float* cnt, float* agg,
                   float* partial, int d, hipStream_t stream) {
   const int64_t nitems = c->num_items[level];
   if (nitems == 0) return;
-  const int items_per_block = kThreads / G;
-  dim3 grid((unsigned)ceil_div64(nitems, items_per_block), (unsigned)ceil_div64(d, 4 * G));
+  const unsigned gy = (unsigned)ceil_div64(d, 4 * G);
   if (level == 0) {
+    dim3 grid((unsigned)ceil_div64(nitems, kThreads / G), gy);
     if (weighted)
-      k_aggregate<G, true, true><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, c->val, cnt, agg,
-                                                                  partial, d);
+      k_aggregate<G, true><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, c->val, cnt, agg, partial, d);
     else
-      k_aggregate<G, true, false><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, nullptr, cnt,
-                                                                   agg, partial, d);
+      k_aggregate<G, false><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, nullptr, cnt, agg, partial, d);
   } else {
-    k_aggregate<G, false, false><<<grid, kThreads, 0, stream>>>(partial, c->items[level], nitems, nullptr,
-                                                                  nullptr, cnt, agg, partial, d);
+    dim3 grid((unsigned)nitems, gy);
+    k_reduce_partials<G><<<grid, kThreads, 0, stream>>>(c->items[level], cnt, agg, partial, d);
   }
 }
 
-}  // namespace
-
-extern "C" {
-
-size_t rgcn_aggregate_workspace_bytes(const rgcn_graph* g, int transposed, int64_t d) {
-  if (!g || d <= 0) return 0;
-  return (size_t)g->dir[transposed ? 1 : 0].num_partials * (size_t)d * sizeof(float);
-}
-
-static int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, const float* x, int64_t d,
-                            float* agg, void* workspace, size_t workspace_bytes, void* stream_) {
+int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, const float* x, int64_t d,
+                     float* agg, void* workspace, size_t workspace_bytes, void* stream_) {
   if (!g || !agg || d <= 0 || (d & 3)) return RGCN_ERR_ARG;
-  if (g->dir[transposed ? 1 : 0].n_key == 0) return RGCN_OK;
+  const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
+  if (!c->rowptr) return RGCN_ERR_ARG;   // direction not built
+  if (c->n_key == 0) return RGCN_OK;
   if (!x) return RGCN_ERR_ARG;
   if (d > (1 << 20)) return RGCN_ERR_UNSUPPORTED;
-  const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
   if (first < 0 || last > c->num_levels || first > last) return RGCN_ERR_ARG;
   if (c->num_partials > 0 &&
       (!workspace || workspace_bytes < (size_t)c->num_partials * (size_t)d * sizeof(float)))
     return RGCN_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   float* partial = (float*)workspace;
-  if (!c->rowptr) return RGCN_ERR_ARG;   // direction not built
   const float* cnt = c->weighted ? nullptr : c->val;
   const bool weighted = c->weighted;
   const int q = (int)(d / 4);
@@ -122,6 +179,15 @@ static int aggregate_levels(const rgcn_graph* g, int transposed, int first, int 
   }
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rgcn_aggregate_workspace_bytes(const rgcn_graph* g, int transposed, int64_t d) {
+  if (!g || d <= 0) return 0;
+  return (size_t)g->dir[transposed ? 1 : 0].num_partials * (size_t)d * sizeof(float);
 }
 
 int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,

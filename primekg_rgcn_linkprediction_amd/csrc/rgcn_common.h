@@ -14,6 +14,8 @@
 // round trip and 8 rows in flight per group this bounds a work item to a few us, which is
 // what keeps a 25-50 us gather launch free of a straggler tail under Zipf-like degree skew.
 constexpr int RGCN_CHUNK = 64;
+// Fan-in of the levels above: partial rows are contiguous and a whole workgroup sums one run.
+constexpr int RGCN_CHUNK_UP = 512;
 constexpr int RGCN_MAX_LEVELS = 8;
 
 // One unit of aggregate work: sum source rows [begin, end) into row `dst`.

@@ -82,8 +82,8 @@ __global__ void k_permute_weights(const float* __restrict__ w_in, const int64_t*
 inline unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, ceil_div64(n, kThreads)); }
 
 // Host-side plan: split every segment into runs of <= RGCN_CHUNK source rows; runs of a
-// multi-run segment write partial sums that the next level reduces the same way, until one
-// run is left.  Inside a level the items are ordered by descending length so that the lane
+// multi-run segment write partial sums that the next level reduces in runs of <= RGCN_CHUNK_UP
+// partial rows (a workgroup per run), until one run is left.  Inside a level the items are ordered by descending length so that the lane
 // groups of one wavefront finish together (no divergence tail) and long items start first.
 int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, rgcn_csr* csr) {
   struct Pending { int32_t seg, begin, end; };
@@ -92,17 +92,17 @@ int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, rgcn_csr* csr) {
   int64_t partial_rows = 0;
 
   auto emit = [&](std::vector<rgcn_item>& out, std::vector<Pending>& nxt, int32_t seg,
-                  int32_t begin, int32_t end) {
+                  int32_t begin, int32_t end, int32_t chunk) {
     int32_t len = end - begin;
-    if (len <= RGCN_CHUNK) {
+    if (len <= chunk) {
       out.push_back({begin, end, seg, 1});
       return;
     }
-    int32_t nch = (int32_t)ceil_div64(len, RGCN_CHUNK);
+    int32_t nch = (int32_t)ceil_div64(len, chunk);
     int32_t pbase = (int32_t)partial_rows;
     for (int32_t c = 0; c < nch; ++c) {
-      int32_t b = begin + c * RGCN_CHUNK;
-      out.push_back({b, std::min(b + RGCN_CHUNK, end), pbase + c, 0});
+      int32_t b = begin + c * chunk;
+      out.push_back({b, std::min(b + chunk, end), pbase + c, 0});
     }
     partial_rows += nch;
     nxt.push_back({seg, pbase, pbase + nch});
@@ -110,12 +110,12 @@ int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, rgcn_csr* csr) {
 
   levels.emplace_back();
   levels[0].reserve((size_t)NR + 16);
-  for (int64_t s = 0; s < NR; ++s) emit(levels[0], pending, (int32_t)s, rowptr[s], rowptr[s + 1]);
+  for (int64_t s = 0; s < NR; ++s) emit(levels[0], pending, (int32_t)s, rowptr[s], rowptr[s + 1], RGCN_CHUNK);
   while (!pending.empty()) {
     if ((int)levels.size() >= RGCN_MAX_LEVELS) return RGCN_ERR_UNSUPPORTED;
     levels.emplace_back();
     next.clear();
-    for (const Pending& p : pending) emit(levels.back(), next, p.seg, p.begin, p.end);
+    for (const Pending& p : pending) emit(levels.back(), next, p.seg, p.begin, p.end, RGCN_CHUNK_UP);
     pending.swap(next);
   }
   if (partial_rows > INT32_MAX) return RGCN_ERR_UNSUPPORTED;

@@ -5,11 +5,15 @@
 // Replaces PyG RGCNConv.forward's `out = out + h_r @ weight[r]` (R times) + `x @ root` +
 // `+ bias` (reference call sites src/models/rgcn.py:123,128)
 // by ONE GEMM with K = (R+1)*d_in whose A operand is the concatenation [agg | x] read in
-// place from two buffers, and autograd's 3R+3 GEMMs of backward (row A7) by two more.
+// place from two buffers and whose B operand is read straight from the PyG-layout
+// parameters (no repack), and autograd's 3R+3 GEMMs of backward (row A7) by two more.
+// The ReLU that follows conv1 in the encoder (rgcn.py:124) can ride in the epilogues.
 //
-// LDS tiles are k-contiguous with a 36-float row stride: a lane's ds_read_b128 fetches the
-// operands of four consecutive MFMAs, and 9*i mod 16 is a permutation of the 16-byte slots so
-// the four 16-lane groups of the read are conflict free.
+// Tiles: 64 x (64|128) outputs per 256-thread workgroup, k-tile 32, 2+ workgroups per CU so
+// one workgroup's staging (global -> registers -> LDS, two barriers) hides behind the MFMAs
+// of its neighbour.  k-contiguous LDS tiles use a 36-float row stride: a lane's
+// ds_read_b128 fetches the operands of four consecutive MFMAs and 9*i mod 16 is a
+// permutation of the 16-byte slots, so the read is bank-conflict free.
 #include <algorithm>
 
 #include "rgcn_common.h"
@@ -20,55 +24,38 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;   // 4 waves, arranged 2 (m) x 2 (n)
 constexpr int BK = 32;          // k-tile
-constexpr int LDS_S = 36;       // LDS row stride in floats (144 B)
+constexpr int LDS_S = 36;       // row stride (floats) of k-contiguous LDS tiles (144 B)
+
+enum { B_KN = 0, B_BLK = 1 };            // how the B operand is addressed (see k_gemm_nt)
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_MASK = 2 };
+
+__device__ inline float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ inline float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // ---------------------------------------------------------------------------------------
-// weight repacks (tiny, L2 resident): the MFMA B operand wants Bt[n][k], k contiguous.
+// C[M, N] = [A1 | A2][M, K1+K2] * B[K, N] (+ bias) (epilogue).
+//   A1: [M, K1], A2: [M, K2] row major, read in place (K1, K2 multiples of 4).
+//   BMODE == B_KN  (forward):       B[k][n] = k < K1 ? W[k*N + n] : Rt[(k-K1)*N + n]
+//       W = weight viewed [R*d_in, d_out], Rt = root [d_in, d_out]; N = d_out.
+//   BMODE == B_BLK (input grad):    B[k][n], k = r*dk + o: W[(r*N + n)*dk + o], and for
+//       k >= K1: Rt[n*dk + (k-K1)];  N = d_in, dk = d_out  (i.e. weight[r]^T, root^T).
+//   EPI_RELU: C = max(C, 0).  EPI_MASK: C = mask[m*N+n] > 0 ? C : 0 (ReLU backward of the
+//   producer layer, mask = that layer's output).
 // ---------------------------------------------------------------------------------------
-// forward: Bt[o][k] = stacked[k][o], stacked = [weight.view(R*d_in, d_out); root]
-__global__ void k_pack_fwd(const float* __restrict__ weight, const float* __restrict__ root, int K1, int K,
-                           int d_out, float* __restrict__ bt) {
-  __shared__ float tile[32][33];
-  const int k0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  for (int r = ty; r < 32; r += 8) {
-    const int k = k0 + r, o = o0 + tx;
-    float v = 0.f;
-    if (k < K && o < d_out) v = (k < K1) ? weight[(size_t)k * d_out + o] : root[(size_t)(k - K1) * d_out + o];
-    tile[r][tx] = v;
-  }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int o = o0 + r, k = k0 + tx;
-    if (o < d_out && k < K) bt[(size_t)o * K + k] = tile[tx][r];
-  }
-}
-
-// backward-input: Bt[i][r*d_out + o] = weight[r][i][o], Bt[i][R*d_out + o] = root[i][o]
-__global__ void k_pack_bwd(const float* __restrict__ weight, const float* __restrict__ root, int R, int d_in,
-                           int d_out, int K, float* __restrict__ bt) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)d_in * K) return;
-  const int i = (int)(idx / K), k = (int)(idx % K);
-  const int r = k / d_out, o = k % d_out;
-  bt[idx] = (r < R) ? weight[((size_t)r * d_in + i) * d_out + o] : root[(size_t)i * d_out + o];
-}
-
-// ---------------------------------------------------------------------------------------
-// C[M, N] = [A1 | A2][M, K1+K2] * Bt[N, K]^T (+ bias).  A1: [M, K1], A2: [M, K2], both row
-// major and read in place; K1, K2 multiples of 4.  Block tile (64*TM) x (64*TN), k-tile 32,
-// register-staged prefetch of the next k-tile behind the MFMAs of the current one.
-// ---------------------------------------------------------------------------------------
-template <int TM, int TN>
+template <int TM, int TN, int BMODE, int EPI>
 __global__ __launch_bounds__(kThreads) void k_gemm_nt(const float* __restrict__ A1, int K1,
                                                       const float* __restrict__ A2, int K2,
-                                                      const float* __restrict__ Bt,
-                                                      const float* __restrict__ bias, float* __restrict__ C,
-                                                      int M, int N) {
+                                                      const float* __restrict__ W,
+                                                      const float* __restrict__ Rt, int dk,
+                                                      const float* __restrict__ bias,
+                                                      const float* __restrict__ mask,
+                                                      float* __restrict__ C, int M, int N) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
-  constexpr int A_LD = BM * 8 / kThreads, B_LD = BN * 8 / kThreads;   // float4 loads per thread
+  constexpr int A_LD = BM * 8 / kThreads;                       // float4 loads per thread (A tile)
+  constexpr int B_LD = BN * 8 / kThreads;                       // float4 loads per thread (B tile)
+  constexpr int B_FLOATS = (BMODE == B_KN) ? BK * BN : BN * LDS_S;
   __shared__ __attribute__((aligned(16))) float sA[BM * LDS_S];
-  __shared__ __attribute__((aligned(16))) float sB[BN * LDS_S];
+  __shared__ __attribute__((aligned(16))) float sB[B_FLOATS];
 
   const int K = K1 + K2;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -84,22 +71,63 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  // ---- per-thread load descriptors, fixed for the whole k loop
+  const float* pa1[A_LD];
+  const float* pa2[A_LD];
+  bool oka[A_LD];
+  int ka[A_LD];
+#pragma unroll
+  for (int t = 0; t < A_LD; ++t) {
+    const int idx = tid + t * kThreads, row = idx >> 3, m = m0 + row;
+    ka[t] = (idx & 7) * 4;
+    oka[t] = m < M;
+    const size_t mm = oka[t] ? (size_t)m : 0;
+    pa1[t] = A1 + mm * K1 + ka[t];
+    pa2[t] = A2 + mm * K2 + ka[t] - K1;
+  }
+  // B descriptors
+  int kb_[B_LD], nb_[B_LD];        // B_KN: (k row in tile, n); B_BLK: (k offset in tile, n)
+  bool okb[B_LD];
+  int blk_r[B_LD], blk_o[B_LD];    // B_BLK: running (relation block, offset inside block)
+#pragma unroll
+  for (int t = 0; t < B_LD; ++t) {
+    const int idx = tid + t * kThreads;
+    if (BMODE == B_KN) {
+      kb_[t] = idx / (BN / 4);
+      nb_[t] = n0 + (idx % (BN / 4)) * 4;
+    } else {
+      kb_[t] = (idx & 7) * 4;
+      nb_[t] = n0 + (idx >> 3);
+      blk_r[t] = kb_[t] / dk;
+      blk_o[t] = kb_[t] % dk;
+    }
+    okb[t] = nb_[t] < N;
+  }
+
   float4 ra[A_LD], rb[B_LD];
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int t = 0; t < A_LD; ++t) {
-      const int idx = tid + t * kThreads, row = idx >> 3, k = kt + (idx & 7) * 4, m = m0 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M && k < K)
-        v = (k < K1) ? *reinterpret_cast<const float4*>(A1 + (size_t)m * K1 + k)
-                     : *reinterpret_cast<const float4*>(A2 + (size_t)m * K2 + (k - K1));
+      const int k = kt + ka[t];
+      float4 v = f4zero();
+      if (oka[t] && k < K) v = ldg4((k < K1 ? pa1[t] : pa2[t]) + kt);
       ra[t] = v;
     }
 #pragma unroll
     for (int t = 0; t < B_LD; ++t) {
-      const int idx = tid + t * kThreads, row = idx >> 3, k = kt + (idx & 7) * 4, n = n0 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < N && k < K) v = *reinterpret_cast<const float4*>(Bt + (size_t)n * K + k);
+      float4 v = f4zero();
+      if (BMODE == B_KN) {
+        const int k = kt + kb_[t];
+        if (okb[t] && k < K)
+          v = ldg4(k < K1 ? W + (size_t)k * N + nb_[t] : Rt + (size_t)(k - K1) * N + nb_[t]);
+      } else {
+        const int k = kt + kb_[t];
+        if (okb[t] && k < K)
+          v = ldg4(k < K1 ? W + ((size_t)blk_r[t] * N + nb_[t]) * dk + blk_o[t]
+                          : Rt + (size_t)nb_[t] * dk + (k - K1));
+        blk_o[t] += BK;                      // advance to the next k-tile
+        while (blk_o[t] >= dk) { blk_o[t] -= dk; ++blk_r[t]; }
+      }
       rb[t] = v;
     }
   };
@@ -112,7 +140,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < B_LD; ++t) {
       const int idx = tid + t * kThreads;
-      *reinterpret_cast<float4*>(&sB[(idx >> 3) * LDS_S + (idx & 7) * 4]) = rb[t];
+      if (BMODE == B_KN) *reinterpret_cast<float4*>(&sB[idx * 4]) = rb[t];     // [k][n], n contiguous
+      else *reinterpret_cast<float4*>(&sB[(idx >> 3) * LDS_S + (idx & 7) * 4]) = rb[t];
     }
   };
 
@@ -124,21 +153,30 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt(const float* __restrict__ 
     if (kt + BK < K) load_tile(kt + BK);
 #pragma unroll
     for (int kb = 0; kb < BK; kb += 8) {
-      float4 fa[TM], fb[TN];
+      float4 fa[TM];
+      float fb[TN][4];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
         fa[a] = *reinterpret_cast<const float4*>(&sA[((wm * TM + a) * 32 + li) * LDS_S + kb + 4 * lh]);
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
-        fb[b] = *reinterpret_cast<const float4*>(&sB[((wn * TN + b) * 32 + li) * LDS_S + kb + 4 * lh]);
+      for (int b = 0; b < TN; ++b) {
+        if (BMODE == B_KN) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fb[b][t] = sB[(kb + 4 * lh + t) * BN + (wn * TN + b) * 32 + li];
+        } else {
+          const float4 v = *reinterpret_cast<const float4*>(&sB[((wn * TN + b) * 32 + li) * LDS_S + kb + 4 * lh]);
+          fb[b][0] = v.x; fb[b][1] = v.y; fb[b][2] = v.z; fb[b][3] = v.w;
+        }
+      }
+      // lane (i, h) feeds k = kb + 4h + t to MFMA t: A and B agree on the k of every lane half
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b].x, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b].y, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b][0], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b][1], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b][2], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b][3], acc[a][b], 0, 0, 0);
         }
     }
   }
@@ -154,7 +192,12 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < M) C[(size_t)m * N + n] = acc[a][b][r] + bv;
+        if (m < M) {
+          float v = acc[a][b][r] + bv;
+          if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+          if (EPI == EPI_MASK) v = mask[(size_t)m * N + n] > 0.f ? v : 0.f;
+          C[(size_t)m * N + n] = v;
+        }
       }
     }
 }
@@ -191,18 +234,21 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restri
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bsum = 0.f;
 
+  // per-thread descriptors: this thread always loads column quad cq of rows (tid>>5) + 8t
+  const int cq = (tid & 31) * 4, c = kc0 + cq, n = n0 + cq;
+  const bool okc = c < Kc, okn = n < N;
+  const float* pa = okc ? (c < K1 ? A1 + c : A2 + (c - K1)) : A1;
+  const int lda = (c < K1) ? K1 : K2;
+
   float4 ra[4], rg[4];
   auto load_tile = [&](int mt) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int idx = tid + t * kThreads, row = idx >> 5, cq = (idx & 31) * 4, m = mt + row;
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vg = va;
+      const int m = mt + (tid >> 5) + 8 * t;
+      float4 va = f4zero(), vg = va;
       if (m < mend) {
-        const int c = kc0 + cq, n = n0 + cq;
-        if (c < Kc)
-          va = (c < K1) ? *reinterpret_cast<const float4*>(A1 + (size_t)m * K1 + c)
-                        : *reinterpret_cast<const float4*>(A2 + (size_t)m * K2 + (c - K1));
-        if (n < N) vg = *reinterpret_cast<const float4*>(G + (size_t)m * N + n);
+        if (okc) va = ldg4(pa + (size_t)m * lda);
+        if (okn) vg = ldg4(G + (size_t)m * N + n);
       }
       ra[t] = va;
       rg[t] = vg;
@@ -214,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restri
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int idx = tid + t * kThreads;
+      const int idx = tid + t * kThreads;     // row = idx >> 5 = (tid >> 5) + 8t, quad = tid & 31
       *reinterpret_cast<float4*>(&sA[idx * 4]) = ra[t];
       *reinterpret_cast<float4*>(&sG[idx * 4]) = rg[t];
     }
@@ -244,37 +290,76 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restri
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int n = n0 + (wn * 2 + b) * 32 + li;
-      if (n >= N) continue;
+      const int nn = n0 + (wn * 2 + b) * 32 + li;
+      if (nn >= N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kc = kc0 + (wk * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (kc < Kc) out[(size_t)kc * N + n] = acc[a][b][r];
+        if (kc < Kc) out[(size_t)kc * N + nn] = acc[a][b][r];
       }
     }
   if (do_bias && n0 + tid < N) bias_part[(size_t)split * N + n0 + tid] = bsum;
 }
 
 // Fixed-order sum of the slabs (deterministic), split between grad_weight and grad_root.
-__global__ void k_reduce_slabs(const float* __restrict__ slab, const float* __restrict__ bias_part, int S, int K1,
-                               int Kc, int N, float* __restrict__ grad_weight, float* __restrict__ grad_root,
-                               float* __restrict__ grad_bias) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index
-  const int64_t nq = (int64_t)Kc * N / 4;
+// 64 outputs (float4 each) x 4 slab groups per workgroup: group g sums slabs
+// [g*S/4, (g+1)*S/4) in order, then the four partials are added in group order.
+__global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restrict__ slab,
+                                                           const float* __restrict__ bias_part, int S, int K1,
+                                                           int Kc, int N, float* __restrict__ grad_weight,
+                                                           float* __restrict__ grad_root,
+                                                           float* __restrict__ grad_bias) {
+  __shared__ float4 red[kThreads];
+  const int64_t nq = (int64_t)Kc * N / 4;                       // float4 outputs of the weight grads
+  const int64_t q = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int grp = threadIdx.x >> 6;
+  const int s0 = (int)((int64_t)S * grp / 4), s1 = (int)((int64_t)S * (grp + 1) / 4);
+  float4 acc = f4zero();
   if (q < nq) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int i = 0; i < S; ++i) {
-      const float4 v = *reinterpret_cast<const float4*>(slab + ((size_t)i * Kc * N + (size_t)q * 4));
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    const float* p = slab + (size_t)q * 4;
+    const size_t stride = (size_t)Kc * N;
+    int i = s0;
+    for (; i + 4 <= s1; i += 4) {
+      const float4 v0 = ldg4(p + (size_t)i * stride), v1 = ldg4(p + (size_t)(i + 1) * stride),
+                   v2 = ldg4(p + (size_t)(i + 2) * stride), v3 = ldg4(p + (size_t)(i + 3) * stride);
+      acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+      acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+      acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+      acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
     }
+    for (; i < s1; ++i) {
+      const float4 v = ldg4(p + (size_t)i * stride);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  } else if (grad_bias && q - nq < (N + 3) / 4) {               // tail workgroups: bias partials
+    const int n = (int)(q - nq) * 4;
+    for (int i = s0; i < s1; ++i) {
+      const float* b = bias_part + (size_t)i * N + n;
+      acc.x += b[0];
+      if (n + 1 < N) acc.y += b[1];
+      if (n + 2 < N) acc.z += b[2];
+      if (n + 3 < N) acc.w += b[3];
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (grp != 0) return;
+  float4 s = red[threadIdx.x];
+#pragma unroll
+  for (int g = 1; g < 4; ++g) {
+    const float4 v = red[g * 64 + threadIdx.x];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (q < nq) {
     const int64_t e = q * 4, k1n = (int64_t)K1 * N;
     if (e < k1n) *reinterpret_cast<float4*>(grad_weight + e) = s;
     else if (grad_root) *reinterpret_cast<float4*>(grad_root + (e - k1n)) = s;
-  } else if (grad_bias && q - nq < N) {
-    const int n = (int)(q - nq);
-    float s = 0.f;
-    for (int i = 0; i < S; ++i) s += bias_part[(size_t)i * N + n];
-    grad_bias[n] = s;
+  } else if (grad_bias && q - nq < (N + 3) / 4) {
+    const int n = (int)(q - nq) * 4;
+    grad_bias[n] = s.x;
+    if (n + 1 < N) grad_bias[n + 1] = s.y;
+    if (n + 2 < N) grad_bias[n + 2] = s.z;
+    if (n + 3 < N) grad_bias[n + 3] = s.w;
   }
 }
 
@@ -285,8 +370,8 @@ SplitPlan plan_splits(int64_t M, int64_t Kc, int64_t N) {
   p.kc_tiles = (int)ceil_div64(Kc, 128);
   p.n_tiles = (int)ceil_div64(N, 128);
   const int tiles = p.kc_tiles * p.n_tiles;
-  int64_t s = std::max<int64_t>(1, 256 / tiles);
-  s = std::min<int64_t>(s, std::max<int64_t>(1, ceil_div64(M, 64)));
+  int64_t s = std::max<int64_t>(1, 512 / tiles);                // ~2 workgroups per CU
+  s = std::min<int64_t>(s, std::max<int64_t>(1, ceil_div64(M, 128)));
   int64_t rps = ceil_div64(ceil_div64(M, s), 32) * 32;
   if (rps < 32) rps = 32;
   p.rows_per_split = (int)rps;
@@ -294,17 +379,16 @@ SplitPlan plan_splits(int64_t M, int64_t Kc, int64_t N) {
   return p;
 }
 
-template <int TM, int TN>
-void launch_nt(const float* A1, int K1, const float* A2, int K2, const float* Bt, const float* bias, float* C,
-               int M, int N, hipStream_t stream) {
-  dim3 grid((unsigned)ceil_div64(M, 64 * TM), (unsigned)ceil_div64(N, 64 * TN));
-  k_gemm_nt<TM, TN><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, Bt, bias, C, M, N);
-}
-
-void gemm_nt(const float* A1, int K1, const float* A2, int K2, const float* Bt, const float* bias, float* C, int M,
-             int N, hipStream_t stream) {
-  if (N <= 64) launch_nt<2, 1>(A1, K1, A2, K2, Bt, bias, C, M, N, stream);
-  else launch_nt<2, 2>(A1, K1, A2, K2, Bt, bias, C, M, N, stream);
+template <int BMODE, int EPI>
+void launch_nt(const float* A1, int K1, const float* A2, int K2, const float* W, const float* Rt, int dk,
+               const float* bias, const float* mask, float* C, int M, int N, hipStream_t stream) {
+  if (N <= 64) {
+    dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
+    k_gemm_nt<1, 1, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N);
+  } else {
+    dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 128));
+    k_gemm_nt<1, 2, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N);
+  }
 }
 
 bool bad_dims(int64_t n, int64_t r, int64_t di, int64_t dout) {
@@ -315,43 +399,38 @@ bool bad_dims(int64_t n, int64_t r, int64_t di, int64_t dout) {
 
 extern "C" {
 
-size_t rgcn_transform_workspace_bytes(int64_t num_relations, int64_t d_in, int64_t d_out) {
-  if (num_relations <= 0 || d_in <= 0 || d_out <= 0) return 0;
-  return (size_t)(num_relations + 1) * (size_t)d_in * (size_t)d_out * sizeof(float);
-}
-
 int rgcn_transform_fwd(const float* agg, const float* x, const float* weight, const float* root,
-                       const float* bias, int64_t N, int64_t R, int64_t d_in, int64_t d_out, float* out,
-                       void* workspace, size_t workspace_bytes, void* stream_) {
+                       const float* bias, int relu, int64_t N, int64_t R, int64_t d_in, int64_t d_out,
+                       float* out, void* stream_) {
   if (bad_dims(N, R, d_in, d_out) || !out) return RGCN_ERR_ARG;
   if (N == 0) return RGCN_OK;
   if (!agg || !x || !weight) return RGCN_ERR_ARG;
   if (N > INT32_MAX / 2 || (R + 1) * d_in > (1 << 24) || d_out > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
-  if (!workspace || workspace_bytes < rgcn_transform_workspace_bytes(R, d_in, d_out)) return RGCN_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
-  const int K1 = (int)(R * d_in), K2 = root ? (int)d_in : 0, K = K1 + K2;
-  float* bt = (float*)workspace;
-  dim3 pg((unsigned)ceil_div64(K, 32), (unsigned)ceil_div64(d_out, 32));
-  k_pack_fwd<<<pg, 256, 0, stream>>>(weight, root, K1, K, (int)d_out, bt);
-  gemm_nt(agg, K1, x, K2, bt, bias, out, (int)N, (int)d_out, stream);
+  const int K1 = (int)(R * d_in), K2 = root ? (int)d_in : 0;
+  if (relu)
+    launch_nt<B_KN, EPI_RELU>(agg, K1, x, K2, weight, root, 0, bias, nullptr, out, (int)N, (int)d_out, stream);
+  else
+    launch_nt<B_KN, EPI_NONE>(agg, K1, x, K2, weight, root, 0, bias, nullptr, out, (int)N, (int)d_out, stream);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
 
 int rgcn_transform_bwd_input(const float* gagg, const float* g, const float* weight, const float* root,
-                             int64_t N, int64_t R, int64_t d_in, int64_t d_out, float* grad_x,
-                             void* workspace, size_t workspace_bytes, void* stream_) {
+                             const float* relu_mask, int64_t N, int64_t R, int64_t d_in, int64_t d_out,
+                             float* grad_x, void* stream_) {
   if (bad_dims(N, R, d_in, d_out) || !grad_x) return RGCN_ERR_ARG;
   if (N == 0) return RGCN_OK;
   if (!gagg || !g || !weight) return RGCN_ERR_ARG;
   if (N > INT32_MAX / 2 || (R + 1) * d_out > (1 << 24) || d_in > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
-  if (!workspace || workspace_bytes < rgcn_transform_workspace_bytes(R, d_in, d_out)) return RGCN_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
-  const int K1 = (int)(R * d_out), K2 = root ? (int)d_out : 0, K = K1 + K2;
-  float* bt = (float*)workspace;
-  const int64_t total = d_in * K;
-  k_pack_bwd<<<(unsigned)ceil_div64(total, 256), 256, 0, stream>>>(weight, root, (int)R, (int)d_in, (int)d_out, K, bt);
-  gemm_nt(gagg, K1, g, K2, bt, nullptr, grad_x, (int)N, (int)d_in, stream);
+  const int K1 = (int)(R * d_out), K2 = root ? (int)d_out : 0;
+  if (relu_mask)
+    launch_nt<B_BLK, EPI_MASK>(gagg, K1, g, K2, weight, root, (int)d_out, nullptr, relu_mask, grad_x, (int)N,
+                               (int)d_in, stream);
+  else
+    launch_nt<B_BLK, EPI_NONE>(gagg, K1, g, K2, weight, root, (int)d_out, nullptr, nullptr, grad_x, (int)N,
+                               (int)d_in, stream);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -387,9 +466,10 @@ int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, 
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
   k_gemm_tn_slab<<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
                                                 p.rows_per_split, slab, grad_bias ? bias_part : nullptr);
-  const int64_t nq = (int64_t)Kc * d_out / 4 + d_out;
-  k_reduce_slabs<<<(unsigned)ceil_div64(nq, 256), 256, 0, stream>>>(slab, bias_part, p.splits, K1, Kc, (int)d_out,
-                                                                   grad_weight, grad_root, grad_bias);
+  const int64_t nq = (int64_t)Kc * d_out / 4 + (d_out + 3) / 4;
+  k_reduce_slabs<<<(unsigned)ceil_div64(nq, 64), kThreads, 0, stream>>>(slab, bias_part, p.splits, K1, Kc,
+                                                                        (int)d_out, grad_weight, grad_root,
+                                                                        grad_bias);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -56,8 +56,8 @@ class HipBackend:
     def aggregate(self, shard, x):
         return self.ops.aggregate(shard, x)
 
-    def transform_fwd(self, agg, x, weight, root, bias):
-        return self.ops.transform_fwd(agg, x, weight, root, bias)
+    def transform_fwd(self, agg, x, weight, root, bias, relu=False):
+        return self.ops.transform_fwd(agg, x, weight, root, bias, relu)
 
     def transform_bwd_input(self, gagg, g, weight, root):
         return self.ops.transform_bwd_input(gagg, g, weight, root)
@@ -139,21 +139,23 @@ def _all_gather_rows(own: Tensor, world: int, group) -> Tensor:
 
 class _PartitionedConvFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_own, weight, root, bias, shard: RankShard, backend, group):
+    def forward(ctx, x_own, weight, root, bias, shard: RankShard, backend, group, relu=False):
         x_own = x_own.contiguous()
         weight = weight.contiguous()
         x_all = _all_gather_rows(x_own, shard.part.world, group)           # the layer's one exchange
         agg = backend.aggregate(shard.g_in, x_all)
-        out = backend.transform_fwd(agg, x_own, weight, root, bias)
-        ctx.shard, ctx.backend, ctx.group = shard, backend, group
+        out = backend.transform_fwd(agg, x_own, weight, root, bias, relu)
+        ctx.shard, ctx.backend, ctx.group, ctx.relu = shard, backend, group, relu
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
-        ctx.save_for_backward(x_own, agg, weight, root)
+        ctx.save_for_backward(x_own, agg, weight, root, out if relu else None)
         return out
 
     @staticmethod
     def backward(ctx, g_own):
-        x_own, agg, weight, root = ctx.saved_tensors
+        x_own, agg, weight, root, out = ctx.saved_tensors
         shard, backend, group = ctx.shard, ctx.backend, ctx.group
+        if ctx.relu:
+            g_own = g_own * (out > 0)                                       # ReLU backward
         g_own = g_own.contiguous()
         need_x = ctx.needs_input_grad[0]
         gw, groot, gbias = backend.transform_bwd_params(agg, x_own, g_own, shard.num_relations,
@@ -175,13 +177,14 @@ class _PartitionedConvFunction(torch.autograd.Function):
         gw = next(it)
         groot = next(it) if ctx.has_root else None
         gbias = next(it) if ctx.has_bias else None
-        return gx, gw, groot, gbias, None, None, None
+        return gx, gw, groot, gbias, None, None, None, None
 
 
 def partitioned_conv(x_own: Tensor, weight: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
-                     shard: RankShard, backend, group=None) -> Tensor:
-    """One R-GCN layer on this rank's rows (``[cap, d_in] -> [cap, d_out]``)."""
-    return _PartitionedConvFunction.apply(x_own, weight, root, bias, shard, backend, group)
+                     shard: RankShard, backend, group=None, relu: bool = False) -> Tensor:
+    """One R-GCN layer on this rank's rows (``[cap, d_in] -> [cap, d_out]``), optionally with
+    the following ReLU fused into the transform."""
+    return _PartitionedConvFunction.apply(x_own, weight, root, bias, shard, backend, group, relu)
 
 
 class PartitionedEncoder:
@@ -209,8 +212,7 @@ class PartitionedEncoder:
     def forward(self) -> Tensor:
         c1, c2 = self.convs
         h = partitioned_conv(self.emb, c1.effective_weight(), c1.root, c1.bias, self.shard, self.backend,
-                             self.group)
-        h = torch.relu(h)
+                             self.group, relu=True)
         return partitioned_conv(h, c2.effective_weight(), c2.root, c2.bias, self.shard, self.backend,
                                 self.group)
 

@@ -19,10 +19,9 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch import Tensor
 
-from .conv import RGCNConv
+from .conv import RGCNConv, rgcn_encoder2
 from .head import LinkPredictor
 
 
@@ -51,9 +50,13 @@ class DrugDiseaseRGCN(nn.Module):
                 node_indices: Optional[Tensor] = None) -> Tensor:
         # the whole table is the layer-1 input (no lookup) unless a subset is asked for
         x = self.node_embeddings.weight if node_indices is None else self.node_embeddings(node_indices)
-        x = self.conv1(x, edge_index, edge_type)
-        x = self.dropout(F.relu(x))
-        return self.conv2(x, edge_index, edge_type)
+        if not (self.training and self.dropout.p > 0):
+            # dropout is the identity: conv1 -> relu -> conv2 as one fused autograd node
+            return rgcn_encoder2(x, edge_index, edge_type, self.conv1, self.conv2)
+        # training with dropout: the mask comes from torch's RNG stream, as in the reference
+        x = self.conv1(x, edge_index, edge_type, activation="relu")      # relu fused (rgcn.py:123-124)
+        x = self.dropout(x)                                              # rgcn.py:125
+        return self.conv2(x, edge_index, edge_type)                      # rgcn.py:128
 
     def get_node_embeddings(self, node_indices: Tensor) -> Tensor:
         return self.node_embeddings(node_indices)

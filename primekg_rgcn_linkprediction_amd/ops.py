@@ -256,22 +256,23 @@ def _check_layer(agg, x, weight, root, bias):
     return n, r, d_in, d_out
 
 
-def transform_fwd(agg, x, weight, root=None, bias=None) -> torch.Tensor:
-    """``sum_r agg[:, r] @ weight[r] + x @ root + bias`` as one fp32-MFMA GEMM."""
+def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False) -> torch.Tensor:
+    """``sum_r agg[:, r] @ weight[r] + x @ root + bias`` as one fp32-MFMA GEMM; ``relu``
+    fuses the activation that follows conv1 (``rgcn.py:124``) into the epilogue."""
     n, r, d_in, d_out = _check_layer(agg, x, weight, root, bias)
     lib = _lib.load()
     with torch.cuda.device(x.device):
         out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
-        nbytes = lib.rgcn_transform_workspace_bytes(r, d_in, d_out)
-        ws = _workspace(nbytes, x.device)
-        rc = lib.rgcn_transform_fwd(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), n, r, d_in,
-                                    d_out, _ptr(out), _ptr(ws), nbytes, _stream())
+        rc = lib.rgcn_transform_fwd(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu), n, r,
+                                    d_in, d_out, _ptr(out), _stream())
     _lib.check(rc, "rgcn_transform_fwd")
     return out
 
 
-def transform_bwd_input(gagg, g, weight, root=None) -> torch.Tensor:
-    """``grad_x = sum_r gagg[:, r] @ weight[r]^T + g @ root^T``."""
+def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None) -> torch.Tensor:
+    """``grad_x = sum_r gagg[:, r] @ weight[r]^T + g @ root^T``; with ``relu_mask`` (the
+    layer's input, when that input is the output of a fused-ReLU layer) the result is
+    additionally multiplied by ``relu_mask > 0``."""
     _need_gpu("g", g, torch.float32)
     _need_gpu("gagg", gagg, torch.float32)
     _need_gpu("weight", weight, torch.float32)
@@ -281,13 +282,15 @@ def transform_bwd_input(gagg, g, weight, root=None) -> torch.Tensor:
         raise ValueError("g must be [N, d_out] and gagg [N, R*d_out]")
     if root is not None:
         _need_gpu("root", root, torch.float32)
+    if relu_mask is not None:
+        _need_gpu("relu_mask", relu_mask, torch.float32)
+        if tuple(relu_mask.shape) != (n, d_in):
+            raise ValueError(f"relu_mask must be [{n}, {d_in}]")
     lib = _lib.load()
     with torch.cuda.device(g.device):
         gx = torch.empty(n, d_in, dtype=torch.float32, device=g.device)
-        nbytes = lib.rgcn_transform_workspace_bytes(r, d_in, d_out)
-        ws = _workspace(nbytes, g.device)
-        rc = lib.rgcn_transform_bwd_input(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root), n, r, d_in, d_out,
-                                          _ptr(gx), _ptr(ws), nbytes, _stream())
+        rc = lib.rgcn_transform_bwd_input(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root), _ptr(relu_mask), n, r,
+                                          d_in, d_out, _ptr(gx), _stream())
     _lib.check(rc, "rgcn_transform_bwd_input")
     return gx
 

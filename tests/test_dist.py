@@ -38,11 +38,12 @@ class OracleBackend:
             out = out / cnt.view(-1, 1)
         return out.view(s["n_key"], -1)
 
-    def transform_fwd(self, agg, x, weight, root, bias):
+    def transform_fwd(self, agg, x, weight, root, bias, relu=False):
         out = agg @ weight.reshape(-1, weight.size(2))
         if root is not None:
             out = out + x @ root
-        return out + bias if bias is not None else out
+        out = out + bias if bias is not None else out
+        return torch.relu(out) if relu else out
 
     def transform_bwd_input(self, gagg, g, weight, root):
         r, d_in, d_out = weight.shape

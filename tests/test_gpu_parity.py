@@ -10,7 +10,7 @@ import torch
 from conftest import LAYER_CASES, load_golden, need_gpu
 from oracle import rgcn_oracle as O
 from primekg_rgcn_linkprediction_amd import (DrugDiseaseModel, LinkPredictor, RGCNConv, distmult, ops,
-                                             rgcn_conv, synth)
+                                             rgcn_conv, rgcn_encoder2, synth)
 
 pytestmark = pytest.mark.gpu
 
@@ -344,16 +344,29 @@ def _encoder_vs_oracle(dev, ei, et, n, r, dims, num_bases=None, seed=0, fwd_atol
     (out_ref * cot).sum().backward()
     # HIP
     convs = [c.to(dev) for c in convs]
-    e_gpu = emb.to(dev).requires_grad_(True)
     eid, etd = ei.to(dev), et.to(dev)
-    h = torch.relu(convs[0](e_gpu, eid, etd))
-    out = convs[1](h, eid, etd)
-    (out * cot.to(dev)).sum().backward()
-    assert_fwd(out, out_ref.detach(), fwd_atol)
-    assert_grad(e_gpu.grad, e_ref.grad)
-    for c, rp in zip(convs, ref_p):
-        for k, v in c.named_parameters():
-            assert_grad(v.grad, rp[k].grad)
+    outs = []
+    # three routes to the same numbers: separate layers + torch relu, relu fused into conv1's
+    # epilogue, and the fused two-layer autograd node (relu backward in conv2's grad epilogue)
+    for route in ("layers", "fused_relu", "encoder2"):
+        e_gpu = emb.to(dev).requires_grad_(True)
+        for c in convs:
+            c.zero_grad(set_to_none=True)
+        if route == "layers":
+            out = convs[1](torch.relu(convs[0](e_gpu, eid, etd)), eid, etd)
+        elif route == "fused_relu":
+            out = convs[1](convs[0](e_gpu, eid, etd, activation="relu"), eid, etd)
+        else:
+            out = rgcn_encoder2(e_gpu, eid, etd, convs[0], convs[1])
+        (out * cot.to(dev)).sum().backward()
+        assert_fwd(out, out_ref.detach(), fwd_atol)
+        assert_grad(e_gpu.grad, e_ref.grad)
+        for c, rp in zip(convs, ref_p):
+            for k, v in c.named_parameters():
+                assert_grad(v.grad, rp[k].grad)
+        outs.append((out.detach(), e_gpu.grad.clone()))
+    for o, g in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(g, outs[0][1])    # same kernels, same bits
 
 
 def test_config_c1_two_layers_vs_oracle():
@@ -375,6 +388,30 @@ def test_config_c3_bases_on_real_subgraph():
     dev = need_gpu()
     z = load_golden("primekg_test_edges.npz")
     _encoder_vs_oracle(dev, z["edge_index"].long(), z["edge_type"].long(), 30926, 3, (64, 256, 256), num_bases=4)
+
+
+def test_encoder_training_mode_uses_torch_dropout_stream():
+    """train() with dropout 0.5 (the reference default, train.py:680): conv1+relu fused, the
+    mask drawn by torch's nn.Dropout exactly where rgcn.py:125 draws it."""
+    dev = need_gpu()
+    ei, et, n, r = synth.uniform_graph(300, 4000, 3, seed=2)
+    torch.manual_seed(2)
+    m = DrugDiseaseModel(n, r, 64, 128, dropout=0.5).to(dev).train()
+    eid, etd = ei.to(dev), et.to(dev)
+    torch.manual_seed(11)
+    got = m.encoder(eid, etd)
+    torch.manual_seed(11)
+    enc = m.encoder
+    h = torch.relu(enc.conv1(enc.node_embeddings.weight, eid, etd))
+    want = enc.conv2(torch.nn.functional.dropout(h, 0.5, True), eid, etd)
+    assert torch.equal(got, want)
+    got.sum().backward()                                   # backward through the unfused route runs
+    assert enc.node_embeddings.weight.grad.abs().sum() > 0
+    m.eval()
+    with torch.no_grad():
+        e1 = m.encoder(eid, etd)
+        e2 = enc.conv2(torch.relu(enc.conv1(enc.node_embeddings.weight, eid, etd)), eid, etd)
+    assert torch.equal(e1, e2)
 
 
 def test_functional_entry_and_r16():

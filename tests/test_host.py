@@ -44,7 +44,6 @@ def test_null_handle_and_bad_args_return_codes_without_a_gpu():
     lib = _lib.load()
     assert lib.rgcn_graph_num_edges(None) == -1
     assert lib.rgcn_aggregate_workspace_bytes(None, 0, 64) == 0
-    assert lib.rgcn_transform_workspace_bytes(3, 64, 128) == 4 * 64 * 128 * 4
     assert lib.rgcn_aggregate(None, 0, None, 64, None, None, 0, None) == _lib.RGCN_ERR_ARG
     assert lib.distmult_fwd(None, None, None, None, None, None, 4, 6, None, None) == _lib.RGCN_ERR_ARG
     assert lib.distmult_fwd(None, None, None, None, None, None, 0, 8, None, None) == _lib.RGCN_OK
