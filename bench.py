@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--edges", type=int, default=None, help="override E (default 849,456)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a HIP graph replay")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -153,13 +154,44 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    ops.GATHER_EVENTS = [] if world == 1 else None
+
+    # The step is a fixed sequence of launches on a static graph: capture it once into a
+    # HIP graph and replay it (same kernels, same work, no per-launch host cost).  Falls back
+    # to eager launches if capture is unavailable (and always at N > 1, where RCCL runs eager).
+    run, launch_mode = step, "eager"
+    if world == 1 and not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            hip_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(hip_graph):
+                step()
+            for _ in range(3):
+                hip_graph.replay()
+            torch.cuda.synchronize()
+            run, launch_mode = hip_graph.replay, "hipGraph replay"
+        except Exception as exc:                                   # pragma: no cover
+            print(f"bench: HIP graph capture failed ({exc!r}); timing eager launches", file=sys.stderr)
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     sync()
     elapsed = time.perf_counter() - t0
-    events, ops.GATHER_EVENTS = ops.GATHER_EVENTS, None
+
+    # Per-kernel durations of the gather, live, from HIP events on the launch stream: an eager
+    # pass of the same step (events cannot be read back from inside a captured graph).
+    events = None
+    if world == 1:
+        ops.GATHER_EVENTS = []
+        for _ in range(min(args.steps, 20)):
+            step()
+        torch.cuda.synchronize()
+        events, ops.GATHER_EVENTS = ops.GATHER_EVENTS, None
+        event_steps = min(args.steps, 20)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -176,7 +208,7 @@ def main():
         "config": {"workload": f"C2: PrimeKG-shaped synthetic graph, {n} nodes / {num_edges} edge columns / "
                                f"{r} relations, encoder {DIMS[0]}->{DIMS[1]}->{DIMS[2]}, 2 layers fwd+bwd, "
                                f"full graph per step, dropout 0",
-                   "parallelism": parallelism},
+                   "parallelism": parallelism, "launch": launch_mode},
         "bucket_ms": bucket_ms,
     }
 
@@ -190,9 +222,9 @@ def main():
             avg = sum(ts) / len(ts)
             nbytes = gather_bytes(num_edges, n, r, d, transposed)
             kernels.append({"kernel": f"k_aggregate<{d // 4},{'true' if transposed else 'false'}>",
-                            "d": d, "transposed": transposed, "launches_per_step": len(ts) // args.steps,
+                            "d": d, "transposed": transposed, "launches_per_step": len(ts) // event_steps,
                             "avg_us": avg * 1e6, "bytes": nbytes, "gbs": nbytes / avg / 1e9,
-                            "total_us_per_step": sum(ts) / args.steps * 1e6})
+                            "total_us_per_step": sum(ts) / event_steps * 1e6})
         dom = max(kernels, key=lambda k: k["total_us_per_step"])
         result["roofline"] = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": None, "kernel": dom["kernel"],

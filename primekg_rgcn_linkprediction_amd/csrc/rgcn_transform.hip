@@ -15,6 +15,7 @@
 // ds_read_b128 fetches the operands of four consecutive MFMAs and 9*i mod 16 is a
 // permutation of the 16-byte slots, so the read is bank-conflict free.
 #include <algorithm>
+#include <cstdlib>
 
 #include "rgcn_common.h"
 
@@ -203,20 +204,212 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
-// slab[s][kc][n] = sum over the node rows of split s of [A1 | A2][m][kc] * G[m][n]
-// (the reduction runs over the row index; LDS tiles are plain [m][128]).  Blocks of kc-tile 0
-// also produce the column sums of G (grad_bias partials).
+// Wave-specialised form of the GEMM above (same operands, same numerics: the k order of every
+// output element is unchanged, so results are bit-identical to k_gemm_nt).
+//
+// 512 threads: waves 0-3 only issue MFMAs (2 x 2 over a 128 x (64*TN) tile, TM = 2 row tiles
+// each), waves 4-7 only stage (global -> registers -> LDS).  Two LDS buffers and ONE barrier
+// per k-tile: during iteration t the MFMA waves read buffer t&1 while the loaders write tile
+// t+1 (fetched during iteration t-1) into the other buffer and issue the global loads of tile
+// t+2, so every global load has a whole MFMA phase (64 MFMAs x 64 cycles) to land and the
+// matrix pipe of each SIMD sees one wave that does nothing but ds_read + MFMA.
+// (With two ordinary workgroups per CU instead, the partner waves run in lockstep - both
+// stage, then both contend for the pipe - and the pipe idles ~40 % of the time.)
 // ---------------------------------------------------------------------------------------
+template <int TN, int BMODE, int EPI>
+__global__ __launch_bounds__(512) void k_gemm_nt_ws(const float* __restrict__ A1, int K1,
+                                                    const float* __restrict__ A2, int K2,
+                                                    const float* __restrict__ W,
+                                                    const float* __restrict__ Rt, int dk,
+                                                    const float* __restrict__ bias,
+                                                    const float* __restrict__ mask,
+                                                    float* __restrict__ C, int M, int N) {
+  constexpr int TM = 2, BM = 128, BN = 64 * TN, LT = 256;       // LT loader threads
+  constexpr int A_LD = BM * 8 / LT;                              // 4 float4 per loader thread
+  constexpr int B_LD = BN * 8 / LT;                              // 4 (BN = 128) or 2 (BN = 64)
+  constexpr int A_FLOATS = BM * LDS_S;
+  constexpr int B_FLOATS = (BMODE == B_KN) ? BK * BN : BN * LDS_S;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
+  float* sA0 = lds;
+  float* sB0 = lds + 2 * A_FLOATS;
+
+  const int K = K1 + K2;
+  const int nkt = (K + BK - 1) / BK;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const bool is_loader = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256;   // wave uniform
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ---- loader-side descriptors (harmless to compute in every wave)
+  const float* pa1[A_LD];
+  const float* pa2[A_LD];
+  bool oka[A_LD];
+  int ka[A_LD];
+#pragma unroll
+  for (int t = 0; t < A_LD; ++t) {
+    const int idx = tid + t * LT, row = idx >> 3, m = m0 + row;
+    ka[t] = (idx & 7) * 4;
+    oka[t] = m < M;
+    const size_t mm = oka[t] ? (size_t)m : 0;
+    pa1[t] = A1 + mm * K1 + ka[t];
+    pa2[t] = A2 + mm * K2 + ka[t] - K1;
+  }
+  int kb_[B_LD], nb_[B_LD], blk_r[B_LD], blk_o[B_LD];
+  bool okb[B_LD];
+#pragma unroll
+  for (int t = 0; t < B_LD; ++t) {
+    const int idx = tid + t * LT;
+    if (BMODE == B_KN) {
+      kb_[t] = idx / (BN / 4);
+      nb_[t] = n0 + (idx % (BN / 4)) * 4;
+      blk_r[t] = blk_o[t] = 0;
+    } else {
+      kb_[t] = (idx & 7) * 4;
+      nb_[t] = n0 + (idx >> 3);
+      blk_r[t] = kb_[t] / dk;
+      blk_o[t] = kb_[t] % dk;
+    }
+    okb[t] = nb_[t] < N;
+  }
+  float4 ra[A_LD], rb[B_LD];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int t = 0; t < A_LD; ++t) {
+      const int k = kt + ka[t];
+      float4 v = f4zero();
+      if (oka[t] && k < K) v = ldg4((k < K1 ? pa1[t] : pa2[t]) + kt);
+      ra[t] = v;
+    }
+#pragma unroll
+    for (int t = 0; t < B_LD; ++t) {
+      float4 v = f4zero();
+      const int k = kt + kb_[t];
+      if (BMODE == B_KN) {
+        if (okb[t] && k < K)
+          v = ldg4(k < K1 ? W + (size_t)k * N + nb_[t] : Rt + (size_t)(k - K1) * N + nb_[t]);
+      } else {
+        if (okb[t] && k < K)
+          v = ldg4(k < K1 ? W + ((size_t)blk_r[t] * N + nb_[t]) * dk + blk_o[t]
+                          : Rt + (size_t)nb_[t] * dk + (k - K1));
+        blk_o[t] += BK;
+        while (blk_o[t] >= dk) { blk_o[t] -= dk; ++blk_r[t]; }
+      }
+      rb[t] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* sA = sA0 + buf * A_FLOATS;
+    float* sB = sB0 + buf * B_FLOATS;
+#pragma unroll
+    for (int t = 0; t < A_LD; ++t) {
+      const int idx = tid + t * LT;
+      *reinterpret_cast<float4*>(&sA[(idx >> 3) * LDS_S + (idx & 7) * 4]) = ra[t];
+    }
+#pragma unroll
+    for (int t = 0; t < B_LD; ++t) {
+      const int idx = tid + t * LT;
+      if (BMODE == B_KN) *reinterpret_cast<float4*>(&sB[idx * 4]) = rb[t];
+      else *reinterpret_cast<float4*>(&sB[(idx >> 3) * LDS_S + (idx & 7) * 4]) = rb[t];
+    }
+  };
+
+  if (is_loader) {
+    load_tile(0);
+    store_tile(0);
+    if (nkt > 1) load_tile(BK);
+  }
+  __syncthreads();
+  for (int t = 0; t < nkt; ++t) {
+    if (is_loader) {
+      if (t + 1 < nkt) {
+        store_tile((t + 1) & 1);                      // tile t+1, fetched one iteration ago
+        if (t + 2 < nkt) load_tile((t + 2) * BK);
+      }
+    } else {
+      const float* sA = sA0 + (t & 1) * A_FLOATS;
+      const float* sB = sB0 + (t & 1) * B_FLOATS;
+#pragma unroll
+      for (int kb = 0; kb < BK; kb += 8) {
+        float4 fa[TM];
+        float fb[TN][4];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+          fa[a] = *reinterpret_cast<const float4*>(&sA[((wm * TM + a) * 32 + li) * LDS_S + kb + 4 * lh]);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          if (BMODE == B_KN) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fb[b][q] = sB[(kb + 4 * lh + q) * BN + (wn * TN + b) * 32 + li];
+          } else {
+            const float4 v = *reinterpret_cast<const float4*>(&sB[((wn * TN + b) * 32 + li) * LDS_S + kb + 4 * lh]);
+            fb[b][0] = v.x; fb[b][1] = v.y; fb[b][2] = v.z; fb[b][3] = v.w;
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b][0], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b][1], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b][2], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b][3], acc[a][b], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (is_loader) return;
+
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + (wn * TN + b) * 32 + li;
+      if (n >= N) continue;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M) {
+          float v = acc[a][b][r] + bv;
+          if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+          if (EPI == EPI_MASK) v = mask[(size_t)m * N + n] > 0.f ? v : 0.f;
+          C[(size_t)m * N + n] = v;
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// slab[s][kc][n] = sum over the node rows of split s of [A1 | A2][m][kc] * G[m][n]
+// (the reduction runs over the row index; LDS tiles are plain [m][TKC] / [m][128]).
+// Tile = (64*TA) kc x 128 n per workgroup.  The slab traffic of a launch is
+// (#workgroups x tile bytes), so the narrow TA = 1 tile halves it for the same parallelism.
+// Workgroups of kc-tile 0 also produce the column sums of G (grad_bias partials).
+// ---------------------------------------------------------------------------------------
+template <int TA>
 __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restrict__ A1, int K1,
                                                            const float* __restrict__ A2, int K2,
                                                            const float* __restrict__ G, int M, int N,
                                                            int n_tiles, int rows_per_split,
                                                            float* __restrict__ slab,
                                                            float* __restrict__ bias_part) {
-  __shared__ __attribute__((aligned(16))) float sA[32 * 128];
+  constexpr int TKC = 64 * TA;              // kc columns per workgroup
+  constexpr int AQ = TKC / 4;               // float4 per A-tile row
+  constexpr int A_LD = 32 * AQ / kThreads;  // float4 loads per thread (A tile): 2 or 4
+  __shared__ __attribute__((aligned(16))) float sA[32 * TKC];
   __shared__ __attribute__((aligned(16))) float sG[32 * 128];
   const int Kc = K1 + K2;
-  const int kc0 = (blockIdx.x / n_tiles) * 128, n0 = (blockIdx.x % n_tiles) * 128;
+  const int kc0 = (blockIdx.x / n_tiles) * TKC, n0 = (blockIdx.x % n_tiles) * 128;
   const int split = blockIdx.y;
   const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
@@ -225,33 +418,33 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restri
   const int li = lane & 31, lh = lane >> 5;
   const bool do_bias = (bias_part != nullptr) && (kc0 == 0) && (tid < 128);
 
-  floatx16 acc[2][2];
+  floatx16 acc[TA][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bsum = 0.f;
 
-  // per-thread descriptors: this thread always loads column quad cq of rows (tid>>5) + 8t
-  const int cq = (tid & 31) * 4, c = kc0 + cq, n = n0 + cq;
-  const bool okc = c < Kc, okn = n < N;
-  const float* pa = okc ? (c < K1 ? A1 + c : A2 + (c - K1)) : A1;
-  const int lda = (c < K1) ? K1 : K2;
+  // per-thread descriptors: fixed column quad, rows advance with the m-tile
+  const int ca = kc0 + (tid % AQ) * 4, ra0 = tid / AQ;           // A: rows ra0 + (256/AQ) * t
+  const int n = n0 + (tid & 31) * 4, rg0 = tid >> 5;             // G: rows rg0 + 8 * t
+  const bool okc = ca < Kc, okn = n < N;
+  const float* pa = okc ? (ca < K1 ? A1 + ca : A2 + (ca - K1)) : A1;
+  const int lda = (ca < K1) ? K1 : K2;
 
-  float4 ra[4], rg[4];
+  float4 ra[A_LD], rg[4];
   auto load_tile = [&](int mt) {
 #pragma unroll
+    for (int t = 0; t < A_LD; ++t) {
+      const int m = mt + ra0 + (kThreads / AQ) * t;
+      ra[t] = (okc && m < mend) ? ldg4(pa + (size_t)m * lda) : f4zero();
+    }
+#pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int m = mt + (tid >> 5) + 8 * t;
-      float4 va = f4zero(), vg = va;
-      if (m < mend) {
-        if (okc) va = ldg4(pa + (size_t)m * lda);
-        if (okn) vg = ldg4(G + (size_t)m * N + n);
-      }
-      ra[t] = va;
-      rg[t] = vg;
+      const int m = mt + rg0 + 8 * t;
+      rg[t] = (okn && m < mend) ? ldg4(G + (size_t)m * N + n) : f4zero();
     }
   };
 
@@ -259,11 +452,9 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restri
   for (int mt = mbeg; mt < mend; mt += 32) {
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int idx = tid + t * kThreads;     // row = idx >> 5 = (tid >> 5) + 8t, quad = tid & 31
-      *reinterpret_cast<float4*>(&sA[idx * 4]) = ra[t];
-      *reinterpret_cast<float4*>(&sG[idx * 4]) = rg[t];
-    }
+    for (int t = 0; t < A_LD; ++t) *reinterpret_cast<float4*>(&sA[(tid + t * kThreads) * 4]) = ra[t];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(&sG[(tid + t * kThreads) * 4]) = rg[t];
     __syncthreads();
     if (mt + 32 < mend) load_tile(mt + 32);
     if (do_bias) {
@@ -272,13 +463,13 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restri
     }
 #pragma unroll
     for (int mm = 0; mm < 32; mm += 2) {
-      float fa[2], fb[2];
+      float fa[TA], fb[2];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) fa[a] = sA[(mm + lh) * 128 + (wk * 2 + a) * 32 + li];
+      for (int a = 0; a < TA; ++a) fa[a] = sA[(mm + lh) * TKC + (wk * TA + a) * 32 + li];
 #pragma unroll
       for (int b = 0; b < 2; ++b) fb[b] = sG[(mm + lh) * 128 + (wn * 2 + b) * 32 + li];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < TA; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
@@ -287,14 +478,14 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restri
 
   float* out = slab + (size_t)split * Kc * N;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int nn = n0 + (wn * 2 + b) * 32 + li;
       if (nn >= N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int kc = kc0 + (wk * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int kc = kc0 + (wk * TA + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (kc < Kc) out[(size_t)kc * N + nn] = acc[a][b][r];
       }
     }
@@ -319,13 +510,12 @@ __global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restri
     const float* p = slab + (size_t)q * 4;
     const size_t stride = (size_t)Kc * N;
     int i = s0;
-    for (; i + 4 <= s1; i += 4) {
-      const float4 v0 = ldg4(p + (size_t)i * stride), v1 = ldg4(p + (size_t)(i + 1) * stride),
-                   v2 = ldg4(p + (size_t)(i + 2) * stride), v3 = ldg4(p + (size_t)(i + 3) * stride);
-      acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
-      acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
-      acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
-      acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+    for (; i + 8 <= s1; i += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ldg4(p + (size_t)(i + u) * stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
     for (; i < s1; ++i) {
       const float4 v = ldg4(p + (size_t)i * stride);
@@ -365,12 +555,23 @@ __global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restri
 
 struct SplitPlan { int kc_tiles, n_tiles, splits, rows_per_split; };
 
+constexpr int TN_TKC = 64;          // kc columns per workgroup of k_gemm_tn_slab<1>
+
+int tn_target_blocks() {            // workgroups per launch; slab bytes scale with it
+  static const int v = [] {
+    const char* e = getenv("RGCN_TN_BLOCKS");
+    const int x = e ? atoi(e) : 0;
+    return x > 0 ? x : 256;
+  }();
+  return v;
+}
+
 SplitPlan plan_splits(int64_t M, int64_t Kc, int64_t N) {
   SplitPlan p;
-  p.kc_tiles = (int)ceil_div64(Kc, 128);
+  p.kc_tiles = (int)ceil_div64(Kc, TN_TKC);
   p.n_tiles = (int)ceil_div64(N, 128);
   const int tiles = p.kc_tiles * p.n_tiles;
-  int64_t s = std::max<int64_t>(1, 512 / tiles);                // ~2 workgroups per CU
+  int64_t s = std::max<int64_t>(1, tn_target_blocks() / tiles);
   s = std::min<int64_t>(s, std::max<int64_t>(1, ceil_div64(M, 128)));
   int64_t rps = ceil_div64(ceil_div64(M, s), 32) * 32;
   if (rps < 32) rps = 32;
@@ -379,9 +580,27 @@ SplitPlan plan_splits(int64_t M, int64_t Kc, int64_t N) {
   return p;
 }
 
+bool use_plain_gemm() {              // RGCN_GEMM=plain selects the non-specialised kernel (A/B runs)
+  static const bool v = [] {
+    const char* e = getenv("RGCN_GEMM");
+    return e && e[0] == 'p';
+  }();
+  return v;
+}
+
 template <int BMODE, int EPI>
 void launch_nt(const float* A1, int K1, const float* A2, int K2, const float* W, const float* Rt, int dk,
                const float* bias, const float* mask, float* C, int M, int N, hipStream_t stream) {
+  if (!use_plain_gemm()) {
+    if (N <= 64) {
+      dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)ceil_div64(N, 64));
+      k_gemm_nt_ws<1, BMODE, EPI><<<grid, 512, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N);
+    } else {
+      dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)ceil_div64(N, 128));
+      k_gemm_nt_ws<2, BMODE, EPI><<<grid, 512, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N);
+    }
+    return;
+  }
   if (N <= 64) {
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
     k_gemm_nt<1, 1, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N);
@@ -454,7 +673,7 @@ int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, 
   const int K1 = (int)(R * d_in), K2 = grad_root ? (int)d_in : 0, Kc = K1 + K2;
   // the slab layout is sized for (R+1)*d_in rows; with grad_root == NULL only K1 are used
   SplitPlan p = plan_splits(N, (R + 1) * d_in, d_out);
-  p.kc_tiles = (int)ceil_div64(Kc, 128);
+  p.kc_tiles = (int)ceil_div64(Kc, TN_TKC);
   float* slab = (float*)workspace;
   float* bias_part = slab + (size_t)p.splits * (R + 1) * d_in * d_out;
   if (N == 0) {   // empty graph: all parameter grads are zero
@@ -464,7 +683,7 @@ int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, 
     return RGCN_OK;
   }
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
-  k_gemm_tn_slab<<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
+  k_gemm_tn_slab<1><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
                                                 p.rows_per_split, slab, grad_bias ? bias_part : nullptr);
   const int64_t nq = (int64_t)Kc * d_out / 4 + (d_out + 3) / 4;
   k_reduce_slabs<<<(unsigned)ceil_div64(nq, 64), kThreads, 0, stream>>>(slab, bias_part, p.splits, K1, Kc,

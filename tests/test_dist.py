@@ -92,9 +92,11 @@ def _worker(rank, world, port, n, e, r, dims, seed, q):
         out_own = enc.step(enc.shard_rows(cot))
         out = enc.gather_output(out_own)
         gemb = enc.gather_output(enc.emb.grad)
-        grads = {f"{i}.{k}": p.grad.clone() for i, c in enumerate(enc.convs) for k, p in c.named_parameters()}
+        grads = {f"{i}.{k}": p.grad.numpy().copy() for i, c in enumerate(enc.convs)
+                 for k, p in c.named_parameters()}
         balance = (enc.shard.num_in_edges, enc.shard.num_out_edges, enc.part.cap)
-        q.put((rank, out, gemb, grads, balance))
+        # numpy payloads are pickled by value: no shared-memory handle outlives this process
+        q.put((rank, out.numpy().copy(), gemb.numpy().copy(), grads, balance))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -113,6 +115,8 @@ def test_partitioned_encoder_gloo(world, n, e):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    results = [(rk, torch.from_numpy(o), torch.from_numpy(ge), {k: torch.from_numpy(v) for k, v in gr.items()}, b)
+               for rk, o, ge, gr, b in results]
     ei, et, emb, convs, cot = _make_problem(n, e, r, dims, seed)
     want_out, want_gemb, want_p = _oracle_full(ei, et, emb, convs, cot)
     total_in = 0
