@@ -55,6 +55,22 @@ def gather_bytes(num_edges, num_nodes, num_relations, d, weighted):
     return b
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, gfx950 correction applied: profiles/r01_pmc_counters.json);
+    None when the summary is absent.  Counters cannot be read from inside this process."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
+    try:
+        with open(path) as fh:
+            table = json.load(fh)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, entry in table.items():
+        if name.replace(" ", "") == kernel.replace(" ", ""):
+            return entry.get("hbm_bytes")
+    return None
+
+
 def cpu_baseline(ei, et, n, r, seconds):
     """PyG-equivalent CPU path (restated; torch_geometric unavailable offline): the oracle's
     op-for-op loop path incl. autograd, all host cores, same graph/seed/step definition.
@@ -227,7 +243,8 @@ def main():
                             "total_us_per_step": sum(ts) / event_steps * 1e6})
         dom = max(kernels, key=lambda k: k["total_us_per_step"])
         result["roofline"] = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": None, "kernel": dom["kernel"],
+                              "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["kernel"]),
+                              "kernel": dom["kernel"],
                               "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"]}
         result["gather_kernels"] = kernels
 

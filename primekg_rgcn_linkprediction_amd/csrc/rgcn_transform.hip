@@ -22,6 +22,7 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;   // 4 waves, arranged 2 (m) x 2 (n)
 constexpr int BK = 32;          // k-tile
@@ -204,189 +205,190 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
-// Wave-specialised form of the GEMM above (same operands, same numerics: the k order of every
-// output element is unchanged, so results are bit-identical to k_gemm_nt).
+// LDS-DMA form of the GEMM above for the production shapes (K1, K2 and, for B_BLK, dk
+// multiples of 32): same operands, same k order per output element => bit-identical results.
 //
-// 512 threads: waves 0-3 only issue MFMAs (2 x 2 over a 128 x (64*TN) tile, TM = 2 row tiles
-// each), waves 4-7 only stage (global -> registers -> LDS).  Two LDS buffers and ONE barrier
-// per k-tile: during iteration t the MFMA waves read buffer t&1 while the loaders write tile
-// t+1 (fetched during iteration t-1) into the other buffer and issue the global loads of tile
-// t+2, so every global load has a whole MFMA phase (64 MFMAs x 64 cycles) to land and the
-// matrix pipe of each SIMD sees one wave that does nothing but ds_read + MFMA.
-// (With two ordinary workgroups per CU instead, the partner waves run in lockstep - both
-// stage, then both contend for the pipe - and the pipe idles ~40 % of the time.)
+// Ablation of k_gemm_nt on C2 (K = 512, 30,926 x 128 outputs; 27 us of pure MFMA issue):
+// ~15 us are launch/prologue/epilogue and ~1.5k cycles per k-tile are staging instructions
+// (64-bit address VALU, vmcnt wait, ds_write, second barrier) that two lockstepped workgroups
+// per CU do not hide.  Here tiles go global -> LDS directly (`global_load_lds_dwordx4`: no
+// staging VGPRs, no ds_write, no address recomputation beyond one add), through a ring of
+// three LDS buffers with ONE raw s_barrier per k-tile and a counted vmcnt, so the loads of
+// k-tile t+2 are issued before the MFMAs of k-tile t and have two MFMA phases to land.
+// An LDS-DMA wave instruction writes 64 x 16 B linearly, so the 128-byte-row tiles (A, and B
+// in B_BLK mode) are stored unpadded and bank conflicts are removed by XOR-swizzling the
+// 16-byte chunk index with (row >> 1) & 7 - applied to the per-lane SOURCE address on the way
+// in and to the ds_read_b128 address on the way out.
 // ---------------------------------------------------------------------------------------
-template <int TN, int BMODE, int EPI>
-__global__ __launch_bounds__(512) void k_gemm_nt_ws(const float* __restrict__ A1, int K1,
-                                                    const float* __restrict__ A2, int K2,
-                                                    const float* __restrict__ W,
-                                                    const float* __restrict__ Rt, int dk,
-                                                    const float* __restrict__ bias,
-                                                    const float* __restrict__ mask,
-                                                    float* __restrict__ C, int M, int N) {
-  constexpr int TM = 2, BM = 128, BN = 64 * TN, LT = 256;       // LT loader threads
-  constexpr int A_LD = BM * 8 / LT;                              // 4 float4 per loader thread
-  constexpr int B_LD = BN * 8 / LT;                              // 4 (BN = 128) or 2 (BN = 64)
-  constexpr int A_FLOATS = BM * LDS_S;
-  constexpr int B_FLOATS = (BMODE == B_KN) ? BK * BN : BN * LDS_S;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_FLOATS + B_FLOATS)];
-  float* sA0 = lds;
-  float* sB0 = lds + 2 * A_FLOATS;
+__device__ inline void glds16(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
-  const int K = K1 + K2;
-  const int nkt = (K + BK - 1) / BK;
+template <int TN, int BMODE, int EPI>
+__global__ __launch_bounds__(kThreads) void k_gemm_nt_dma(const float* __restrict__ A1, int K1,
+                                                          const float* __restrict__ A2, int K2,
+                                                          const float* __restrict__ W,
+                                                          const float* __restrict__ Rt, int dk,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ mask,
+                                                          float* __restrict__ C, int M, int N) {
+  constexpr int BM = 64, BN = 64 * TN, NBUF = 3;
+  constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, BUF_FLOATS = A_FLOATS + B_FLOATS;
+  constexpr int A_PW = BM / 32;                 // A wave-instructions per wave and k-tile (8 rows each)
+  constexpr int B_PW = BN / 32;                 // B wave-instructions per wave and k-tile
+  constexpr int P = A_PW + B_PW;                // LDS-DMA instructions per thread and k-tile
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF_FLOATS];   // the ONLY LDS object
+
+  const int K = K1 + K2, nkt = K / BK;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const bool is_loader = __builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 256;   // wave uniform
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  floatx16 acc[TM][TN];
+  floatx16 acc[TN];
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+  for (int b = 0; b < TN; ++b)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
-  // ---- loader-side descriptors (harmless to compute in every wave)
-  const float* pa1[A_LD];
-  const float* pa2[A_LD];
-  bool oka[A_LD];
-  int ka[A_LD];
+  // per-lane source offsets, fixed over the k loop
+  size_t a_off1[A_PW], a_off2[A_PW];
 #pragma unroll
-  for (int t = 0; t < A_LD; ++t) {
-    const int idx = tid + t * LT, row = idx >> 3, m = m0 + row;
-    ka[t] = (idx & 7) * 4;
-    oka[t] = m < M;
-    const size_t mm = oka[t] ? (size_t)m : 0;
-    pa1[t] = A1 + mm * K1 + ka[t];
-    pa2[t] = A2 + mm * K2 + ka[t] - K1;
+  for (int j = 0; j < A_PW; ++j) {
+    const int row = (wave * A_PW + j) * 8 + (lane >> 3);
+    const int m = min(m0 + row, M - 1);                        // rows past M read a valid row; never stored
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    a_off1[j] = (size_t)m * K1 + chunk * 4;
+    a_off2[j] = (size_t)m * K2 + chunk * 4;
   }
-  int kb_[B_LD], nb_[B_LD], blk_r[B_LD], blk_o[B_LD];
-  bool okb[B_LD];
+  size_t b_off[B_PW];
+  bool b_ok[B_PW];
 #pragma unroll
-  for (int t = 0; t < B_LD; ++t) {
-    const int idx = tid + t * LT;
+  for (int j = 0; j < B_PW; ++j) {
+    if (BMODE == B_KN) {                                       // [k][BN]: BN/4 lanes per k row
+      constexpr int LPR = BN / 4, RPI = 64 / LPR;
+      const int krow = (wave * B_PW + j) * RPI + lane / LPR;
+      const int n = n0 + (lane % LPR) * 4;
+      b_ok[j] = n < N;
+      b_off[j] = (size_t)krow * N + n;
+    } else {                                                   // [n][32 k], swizzled like A
+      const int row = (wave * B_PW + j) * 8 + (lane >> 3);
+      const int n = min(n0 + row, N - 1);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      b_ok[j] = true;
+      b_off[j] = (size_t)n * dk + chunk * 4;
+    }
+  }
+
+  auto stage = [&](int kt, int buf) {
+    float* sA = lds + buf * BUF_FLOATS;
+    float* sB = sA + A_FLOATS;
+    const bool first = kt < K1;                                // whole k-tile lies in one operand
+    const float* abase = first ? A1 + kt : A2 + (kt - K1);
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j)
+      glds16(abase + (first ? a_off1[j] : a_off2[j]), sA + (wave * A_PW + j) * 8 * BK);
     if (BMODE == B_KN) {
-      kb_[t] = idx / (BN / 4);
-      nb_[t] = n0 + (idx % (BN / 4)) * 4;
-      blk_r[t] = blk_o[t] = 0;
+      constexpr int RPI = 64 / (BN / 4);
+      const float* bbase = first ? W + (size_t)kt * N : Rt + (size_t)(kt - K1) * N;
+#pragma unroll
+      for (int j = 0; j < B_PW; ++j)
+        if (b_ok[j]) glds16(bbase + b_off[j], sB + (wave * B_PW + j) * RPI * BN);
     } else {
-      kb_[t] = (idx & 7) * 4;
-      nb_[t] = n0 + (idx >> 3);
-      blk_r[t] = kb_[t] / dk;
-      blk_o[t] = kb_[t] % dk;
-    }
-    okb[t] = nb_[t] < N;
-  }
-  float4 ra[A_LD], rb[B_LD];
-  auto load_tile = [&](int kt) {
+      const float* bbase = first ? W + (size_t)(kt / dk) * N * dk + (kt % dk) : Rt + (kt - K1);
 #pragma unroll
-    for (int t = 0; t < A_LD; ++t) {
-      const int k = kt + ka[t];
-      float4 v = f4zero();
-      if (oka[t] && k < K) v = ldg4((k < K1 ? pa1[t] : pa2[t]) + kt);
-      ra[t] = v;
-    }
-#pragma unroll
-    for (int t = 0; t < B_LD; ++t) {
-      float4 v = f4zero();
-      const int k = kt + kb_[t];
-      if (BMODE == B_KN) {
-        if (okb[t] && k < K)
-          v = ldg4(k < K1 ? W + (size_t)k * N + nb_[t] : Rt + (size_t)(k - K1) * N + nb_[t]);
-      } else {
-        if (okb[t] && k < K)
-          v = ldg4(k < K1 ? W + ((size_t)blk_r[t] * N + nb_[t]) * dk + blk_o[t]
-                          : Rt + (size_t)nb_[t] * dk + (k - K1));
-        blk_o[t] += BK;
-        while (blk_o[t] >= dk) { blk_o[t] -= dk; ++blk_r[t]; }
-      }
-      rb[t] = v;
-    }
-  };
-  auto store_tile = [&](int buf) {
-    float* sA = sA0 + buf * A_FLOATS;
-    float* sB = sB0 + buf * B_FLOATS;
-#pragma unroll
-    for (int t = 0; t < A_LD; ++t) {
-      const int idx = tid + t * LT;
-      *reinterpret_cast<float4*>(&sA[(idx >> 3) * LDS_S + (idx & 7) * 4]) = ra[t];
-    }
-#pragma unroll
-    for (int t = 0; t < B_LD; ++t) {
-      const int idx = tid + t * LT;
-      if (BMODE == B_KN) *reinterpret_cast<float4*>(&sB[idx * 4]) = rb[t];
-      else *reinterpret_cast<float4*>(&sB[(idx >> 3) * LDS_S + (idx & 7) * 4]) = rb[t];
+      for (int j = 0; j < B_PW; ++j) glds16(bbase + b_off[j], sB + (wave * B_PW + j) * 8 * BK);
     }
   };
 
-  if (is_loader) {
-    load_tile(0);
-    store_tile(0);
-    if (nkt > 1) load_tile(BK);
-  }
-  __syncthreads();
-  for (int t = 0; t < nkt; ++t) {
-    if (is_loader) {
-      if (t + 1 < nkt) {
-        store_tile((t + 1) & 1);                      // tile t+1, fetched one iteration ago
-        if (t + 2 < nkt) load_tile((t + 2) * BK);
-      }
-    } else {
-      const float* sA = sA0 + (t & 1) * A_FLOATS;
-      const float* sB = sB0 + (t & 1) * B_FLOATS;
-#pragma unroll
-      for (int kb = 0; kb < BK; kb += 8) {
-        float4 fa[TM];
-        float fb[TN][4];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-          fa[a] = *reinterpret_cast<const float4*>(&sA[((wm * TM + a) * 32 + li) * LDS_S + kb + 4 * lh]);
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          if (BMODE == B_KN) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fb[b][q] = sB[(kb + 4 * lh + q) * BN + (wn * TN + b) * 32 + li];
-          } else {
-            const float4 v = *reinterpret_cast<const float4*>(&sB[((wn * TN + b) * 32 + li) * LDS_S + kb + 4 * lh]);
-            fb[b][0] = v.x; fb[b][1] = v.y; fb[b][2] = v.z; fb[b][3] = v.w;
-          }
-        }
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].x, fb[b][0], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].y, fb[b][1], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b][2], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b][3], acc[a][b], 0, 0, 0);
-          }
-      }
-    }
-    __syncthreads();
-  }
-  if (is_loader) return;
+  stage(0, 0);
+  if (nkt > 1) stage(BK, 1);
 
+  // Fragment reads are inline asm: hipcc cannot tell a ds_read from the in-flight LDS-DMA
+  // destinations apart and would drain vmcnt(0) before the first read of every k-tile.
+  // Byte addresses inside one buffer, fixed over the k loop (the XOR swizzle is not additive,
+  // so the four kb steps get one address register each):
+  const int arow = wm * 32 + li;
+  unsigned a_addr[4], b_addr[TN][4];
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+  for (int s4 = 0; s4 < 4; ++s4) {
+    a_addr[s4] = (unsigned)(arow * BK + (((2 * s4 + lh) ^ ((arow >> 1) & 7)) << 2)) * 4u;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const int n = n0 + (wn * TN + b) * 32 + li;
-      if (n >= N) continue;
-      const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < M) {
-          float v = acc[a][b][r] + bv;
-          if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-          if (EPI == EPI_MASK) v = mask[(size_t)m * N + n] > 0.f ? v : 0.f;
-          C[(size_t)m * N + n] = v;
-        }
+      if (BMODE == B_KN) {
+        b_addr[b][s4] = (unsigned)(A_FLOATS + (8 * s4 + 4 * lh) * BN + (wn * TN + b) * 32 + li) * 4u;
+      } else {
+        const int brow = (wn * TN + b) * 32 + li;
+        b_addr[b][s4] = (unsigned)(A_FLOATS + brow * BK + (((2 * s4 + lh) ^ ((brow >> 1) & 7)) << 2)) * 4u;
       }
     }
+  }
+  f32x4 fa[2];
+  f32x4 fb[2][TN];
+  auto read_frags = [&](int set, int s4, unsigned buf_bytes) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set]) : "v"(a_addr[s4] + buf_bytes));
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      if (BMODE == B_KN) {
+        const unsigned ad = b_addr[b][s4] + buf_bytes;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(fb[set][b].x) : "v"(ad));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[set][b].y) : "v"(ad), "n"(BN * 4));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[set][b].z) : "v"(ad), "n"(BN * 8));
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[set][b].w) : "v"(ad), "n"(BN * 12));
+      } else {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fb[set][b]) : "v"(b_addr[b][s4] + buf_bytes));
+      }
+    }
+  };
+  auto wait_frags = [&](int set) {       // lgkmcnt(0), tied to the registers the MFMAs will read
+    if (TN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set]), "+v"(fb[set][0]), "+v"(fb[set][TN - 1]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set]), "+v"(fb[set][0]));
+  };
+
+  for (int t = 0; t < nkt; ++t) {
+    // k-tile t landed for this wave (all but the newest P DMAs are done), then for all waves;
+    // the barrier also says every wave is done reading the buffer k-tile t+2 will overwrite
+    if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nkt) stage((t + 2) * BK, (t + 2) % NBUF);
+    const unsigned buf_bytes = (unsigned)((t % NBUF) * BUF_FLOATS) * 4u;
+    read_frags(0, 0, buf_bytes);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int cur = s4 & 1;
+      wait_frags(cur);
+      if (s4 + 1 < 4) read_frags(cur ^ 1, s4 + 1, buf_bytes);   // in flight behind this step's MFMAs
+      __builtin_amdgcn_sched_barrier(0);                        // keep the MFMAs below the reads just issued
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].x, fb[cur][b].x, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].y, fb[cur][b].y, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].z, fb[cur][b].z, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur].w, fb[cur][b].w, acc[b], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);                        // ... and above the next step's wait
+    }
+  }
+
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = n0 + (wn * TN + b) * 32 + li;
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < M) {
+        float v = acc[b][r] + bv;
+        if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+        if (EPI == EPI_MASK) v = mask[(size_t)m * N + n] > 0.f ? v : 0.f;
+        C[(size_t)m * N + n] = v;
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -492,6 +494,149 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restri
   if (do_bias && n0 + tid < N) bias_part[(size_t)split * N + n0 + tid] = bsum;
 }
 
+// LDS-DMA form of k_gemm_tn_slab<1> for the production shapes (K1, K2 multiples of 64): the
+// [32 m][64 kc] and [32 m][128 n] tiles go global -> LDS directly through a ring of three
+// buffers, one raw barrier per m-tile, counted vmcnt (see k_gemm_nt_dma).  Both tiles are read
+// with lanes along the contiguous dimension (ds_read_b32, conflict free), so no swizzle.
+// Same m order per output element => bit-identical to the register-staged kernel.
+__global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restrict__ A1, int K1,
+                                                          const float* __restrict__ A2, int K2,
+                                                          const float* __restrict__ G, int M, int N,
+                                                          int n_tiles, int rows_per_split,
+                                                          float* __restrict__ slab,
+                                                          float* __restrict__ bias_part) {
+  constexpr int TKC = 64, NBUF = 3, A_FLOATS = 32 * TKC, G_FLOATS = 32 * 128, BUF_FLOATS = A_FLOATS + G_FLOATS;
+  constexpr int A_PW = 2, G_PW = 4, P = A_PW + G_PW;            // LDS-DMA instructions per wave and m-tile
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF_FLOATS];   // the ONLY LDS object
+  const int Kc = K1 + K2;
+  const int kc0 = (blockIdx.x / n_tiles) * TKC, n0 = (blockIdx.x % n_tiles) * 128;
+  const int split = blockIdx.y;
+  const int mbeg = split * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+  const int nmt = (mend - mbeg + 31) / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const bool do_bias = (bias_part != nullptr) && (kc0 == 0) && (tid < 128);
+
+  floatx16 acc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  float bsum = 0.f;
+
+  // the 64-column kc tile lies in exactly one of the two A operands (K1 % 64 == 0)
+  const bool first = kc0 < K1;
+  const float* abase = first ? A1 + kc0 : A2 + (kc0 - K1);
+  const int lda = first ? K1 : K2;
+  // A: 16 lanes per row (4 rows per wave instruction); G: 32 lanes per row (2 rows per instruction)
+  const int a_row = lane >> 4, a_col = (lane & 15) * 4;
+  const int g_row = lane >> 5, g_col = (lane & 31) * 4;
+  const bool g_ok = n0 + g_col < N;
+
+  auto stage = [&](int mt, int buf) {
+    float* sA = lds + buf * BUF_FLOATS;
+    float* sG = sA + A_FLOATS;
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) {
+      const int r0 = (wave * A_PW + j) * 4;
+      const int m = min(mt + r0 + a_row, M - 1);               // tail rows are zeroed in LDS below
+      glds16(abase + (size_t)m * lda + a_col, sA + r0 * TKC);
+    }
+#pragma unroll
+    for (int j = 0; j < G_PW; ++j) {
+      const int r0 = (wave * G_PW + j) * 2;
+      const int m = min(mt + r0 + g_row, M - 1);
+      if (g_ok) glds16(G + (size_t)m * N + n0 + g_col, sG + r0 * 128);
+    }
+  };
+
+  if (nmt > 0) stage(mbeg, 0);
+  if (nmt > 1) stage(mbeg + 32, 1);
+  const unsigned a_addr = (unsigned)(lh * TKC + wk * 32 + li) * 4u;
+  const unsigned g_addr = (unsigned)(A_FLOATS + lh * 128 + wn * 64 + li) * 4u;
+  float fa[2][4], fg[2][4][2];
+  auto read_frags = [&](int set, int q4, unsigned buf_bytes) {   // rows 8*q4 .. 8*q4+7 (4 MFMA k-steps)
+    const unsigned aa = a_addr + buf_bytes + (unsigned)(q4 * 8 * TKC * 4);
+    const unsigned gg = g_addr + buf_bytes + (unsigned)(q4 * 8 * 128 * 4);
+    asm volatile("ds_read_b32 %0, %1" : "=v"(fa[set][0]) : "v"(aa));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[set][1]) : "v"(aa), "n"(2 * TKC * 4));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[set][2]) : "v"(aa), "n"(4 * TKC * 4));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[set][3]) : "v"(aa), "n"(6 * TKC * 4));
+    asm volatile("ds_read_b32 %0, %1" : "=v"(fg[set][0][0]) : "v"(gg));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fg[set][0][1]) : "v"(gg), "n"(32 * 4));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fg[set][1][0]) : "v"(gg), "n"(2 * 128 * 4));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fg[set][1][1]) : "v"(gg), "n"(2 * 128 * 4 + 32 * 4));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fg[set][2][0]) : "v"(gg), "n"(4 * 128 * 4));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fg[set][2][1]) : "v"(gg), "n"(4 * 128 * 4 + 32 * 4));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fg[set][3][0]) : "v"(gg), "n"(6 * 128 * 4));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fg[set][3][1]) : "v"(gg), "n"(6 * 128 * 4 + 32 * 4));
+  };
+  auto wait_frags = [&](int set) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fa[set][0]), "+v"(fa[set][1]), "+v"(fa[set][2]), "+v"(fa[set][3]), "+v"(fg[set][0][0]),
+                   "+v"(fg[set][0][1]), "+v"(fg[set][1][0]), "+v"(fg[set][1][1]), "+v"(fg[set][2][0]),
+                   "+v"(fg[set][2][1]), "+v"(fg[set][3][0]), "+v"(fg[set][3][1]));
+  };
+
+  for (int t = 0; t < nmt; ++t) {
+    const int mt = mbeg + t * 32;
+    if (t + 1 < nmt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* sA = lds + (t % NBUF) * BUF_FLOATS;
+    float* sG = sA + A_FLOATS;
+    if (mt + 32 > mend) {                      // ragged last tile: rows >= mend must contribute 0
+      for (int i = tid; i < 32 * TKC; i += kThreads)
+        if (mt + i / TKC >= mend) sA[i] = 0.f;
+      for (int i = tid; i < 32 * 128; i += kThreads)
+        if (mt + i / 128 >= mend) sG[i] = 0.f;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (t + 2 < nmt) stage(mt + 64, (t + 2) % NBUF);
+    if (do_bias) {
+      float v[32];
+#pragma unroll
+      for (int mm = 0; mm < 32; ++mm)
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[mm]) : "v"((unsigned)((sG - lds) + tid) * 4u), "n"(mm * 128 * 4));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int mm = 0; mm < 32; ++mm) bsum += v[mm];
+    }
+    const unsigned buf_bytes = (unsigned)((t % NBUF) * BUF_FLOATS) * 4u;
+    read_frags(0, 0, buf_bytes);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int cur = q4 & 1;
+      wait_frags(cur);
+      if (q4 + 1 < 4) read_frags(cur ^ 1, q4 + 1, buf_bytes);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s], fg[cur][s][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][s], fg[cur][s][1], acc[1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  float* out = slab + (size_t)split * Kc * N;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int nn = n0 + (wn * 2 + b) * 32 + li;
+    if (nn >= N) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kc = kc0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (kc < Kc) out[(size_t)kc * N + nn] = acc[b][r];
+    }
+  }
+  if (do_bias && n0 + tid < N) bias_part[(size_t)split * N + n0 + tid] = bsum;
+}
+
 // Fixed-order sum of the slabs (deterministic), split between grad_weight and grad_root.
 // 64 outputs (float4 each) x 4 slab groups per workgroup: group g sums slabs
 // [g*S/4, (g+1)*S/4) in order, then the four partials are added in group order.
@@ -580,7 +725,7 @@ SplitPlan plan_splits(int64_t M, int64_t Kc, int64_t N) {
   return p;
 }
 
-bool use_plain_gemm() {              // RGCN_GEMM=plain selects the non-specialised kernel (A/B runs)
+bool force_plain_gemm() {             // RGCN_GEMM=plain: register-staged kernel for every shape (A/B runs)
   static const bool v = [] {
     const char* e = getenv("RGCN_GEMM");
     return e && e[0] == 'p';
@@ -591,13 +736,15 @@ bool use_plain_gemm() {              // RGCN_GEMM=plain selects the non-speciali
 template <int BMODE, int EPI>
 void launch_nt(const float* A1, int K1, const float* A2, int K2, const float* W, const float* Rt, int dk,
                const float* bias, const float* mask, float* C, int M, int N, hipStream_t stream) {
-  if (!use_plain_gemm()) {
+  const bool dma_ok = (K1 % BK == 0) && (K2 % BK == 0) && (K1 + K2 > 0) && (BMODE == B_KN || dk % BK == 0) &&
+                      !force_plain_gemm();
+  if (dma_ok) {
     if (N <= 64) {
-      dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)ceil_div64(N, 64));
-      k_gemm_nt_ws<1, BMODE, EPI><<<grid, 512, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N);
+      dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
+      k_gemm_nt_dma<1, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N);
     } else {
-      dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)ceil_div64(N, 128));
-      k_gemm_nt_ws<2, BMODE, EPI><<<grid, 512, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N);
+      dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 128));
+      k_gemm_nt_dma<2, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N);
     }
     return;
   }
@@ -683,8 +830,12 @@ int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, 
     return RGCN_OK;
   }
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
-  k_gemm_tn_slab<1><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                p.rows_per_split, slab, grad_bias ? bias_part : nullptr);
+  if (K1 % 64 == 0 && K2 % 64 == 0 && !force_plain_gemm())
+    k_gemm_tn_dma<<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
+                                                 p.rows_per_split, slab, grad_bias ? bias_part : nullptr);
+  else
+    k_gemm_tn_slab<1><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
+                                                     p.rows_per_split, slab, grad_bias ? bias_part : nullptr);
   const int64_t nq = (int64_t)Kc * d_out / 4 + (d_out + 3) / 4;
   k_reduce_slabs<<<(unsigned)ceil_div64(nq, 64), kThreads, 0, stream>>>(slab, bias_part, p.splits, K1, Kc,
                                                                         (int)d_out, grad_weight, grad_root,

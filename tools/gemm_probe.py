@@ -33,3 +33,10 @@ for d_in, d_out in ((64, 128), (128, 128)):
 a = torch.randn(N, 512, device=dev); b = torch.randn(512, 128, device=dev)
 t = timeit(lambda: a @ b)
 print(f"torch.matmul [30926x512]x[512x128]: {t:7.2f} us  {2.0*N*512*128/t/1e6:6.1f} TF")
+# library reference for the parameter-gradient shape: [512 x 30926] x [30926 x 128]
+a = torch.randn(N, 512, device=dev); g2 = torch.randn(N, 128, device=dev)
+t = timeit(lambda: a.t() @ g2)
+print(f"torch.matmul A^T[512x30926] x G[30926x128]: {t:7.2f} us  {2.0*N*512*128/t/1e6:6.1f} TF")
+a = torch.randn(N, 256, device=dev)
+t = timeit(lambda: a.t() @ g2)
+print(f"torch.matmul A^T[256x30926] x G[30926x128]: {t:7.2f} us  {2.0*N*256*128/t/1e6:6.1f} TF")
