@@ -204,6 +204,9 @@ def main():
     if world == 1:
         ops.GATHER_EVENTS = []
         for _ in range(min(args.steps, 20)):
+            # a short device-side spin first, so that the host has queued the step's launches
+            # before they execute: the events then bracket back-to-back kernels, not launch gaps
+            torch.cuda._sleep(2_000_000)
             step()
         torch.cuda.synchronize()
         events, ops.GATHER_EVENTS = ops.GATHER_EVENTS, None
