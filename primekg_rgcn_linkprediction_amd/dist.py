@@ -132,7 +132,15 @@ class RankShard:
 
 
 def _all_gather_rows(own: Tensor, world: int, group) -> Tensor:
-    out = own.new_empty((own.size(0) * world,) + tuple(own.shape[1:]))
+    shape = (own.size(0) * world,) + tuple(own.shape[1:])
+    if own.is_cuda and dist.get_backend(group) == "gloo":
+        # test rigs only (several ranks sharing one GPU, where RCCL refuses to run): gloo has no
+        # device all-gather, so the exchange is staged through the host
+        host = own.detach().contiguous().cpu()
+        out_h = host.new_empty(shape)
+        dist.all_gather_into_tensor(out_h, host, group=group)
+        return out_h.to(own.device)
+    out = own.new_empty(shape)
     dist.all_gather_into_tensor(out, own.contiguous(), group=group)
     return out
 

@@ -81,18 +81,24 @@ def _oracle_full(ei, et, emb, convs, cot):
     return out.detach(), e.grad, ps
 
 
-def _worker(rank, world, port, n, e, r, dims, seed, q):
+def _worker(rank, world, port, n, e, r, dims, seed, q, use_hip=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ei, et, emb, convs, cot = _make_problem(n, e, r, dims, seed)
-        enc = rdist.PartitionedEncoder(ei, et, n, r, emb, convs, torch.device("cpu"), backend=OracleBackend())
-        out_own = enc.step(enc.shard_rows(cot))
-        out = enc.gather_output(out_own)
-        gemb = enc.gather_output(enc.emb.grad)
-        grads = {f"{i}.{k}": p.grad.numpy().copy() for i, c in enumerate(enc.convs)
+        if use_hip:        # every rank drives the real kernels on the one GPU of the box
+            dev = torch.device("cuda:0")
+            torch.cuda.set_device(dev)
+            enc = rdist.PartitionedEncoder(ei, et, n, r, emb, convs, dev)
+        else:
+            dev = torch.device("cpu")
+            enc = rdist.PartitionedEncoder(ei, et, n, r, emb, convs, dev, backend=OracleBackend())
+        out_own = enc.step(enc.shard_rows(cot).to(dev))
+        out = enc.gather_output(out_own).cpu()
+        gemb = enc.gather_output(enc.emb.grad).cpu()
+        grads = {f"{i}.{k}": p.grad.cpu().numpy().copy() for i, c in enumerate(enc.convs)
                  for k, p in c.named_parameters()}
         balance = (enc.shard.num_in_edges, enc.shard.num_out_edges, enc.part.cap)
         # numpy payloads are pickled by value: no shared-memory handle outlives this process
@@ -102,13 +108,12 @@ def _worker(rank, world, port, n, e, r, dims, seed, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,e", [(2, 101, 1500), (3, 64, 900)])
-def test_partitioned_encoder_gloo(world, n, e):
-    r, dims, seed = 3, (16, 32, 32), 5
+def _run_partitioned(world, n, e, r, dims, seed, use_hip):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(k, world, port, n, e, r, dims, seed, q)) for k in range(world)]
+    procs = [ctx.Process(target=_worker, args=(k, world, port, n, e, r, dims, seed, q, use_hip))
+             for k in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
@@ -117,6 +122,10 @@ def test_partitioned_encoder_gloo(world, n, e):
         assert p.exitcode == 0
     results = [(rk, torch.from_numpy(o), torch.from_numpy(ge), {k: torch.from_numpy(v) for k, v in gr.items()}, b)
                for rk, o, ge, gr, b in results]
+    return results
+
+
+def _check_partitioned(results, world, n, e, r, dims, seed):
     ei, et, emb, convs, cot = _make_problem(n, e, r, dims, seed)
     want_out, want_gemb, want_p = _oracle_full(ei, et, emb, convs, cot)
     total_in = 0
@@ -134,6 +143,21 @@ def test_partitioned_encoder_gloo(world, n, e):
     for k, v in results[0][3].items():
         for other in results[1:]:
             assert torch.equal(v, other[3][k])
+
+
+@pytest.mark.parametrize("world,n,e", [(2, 101, 1500), (3, 64, 900)])
+def test_partitioned_encoder_gloo(world, n, e):
+    r, dims, seed = 3, (16, 32, 32), 5
+    _check_partitioned(_run_partitioned(world, n, e, r, dims, seed, False), world, n, e, r, dims, seed)
+
+
+@pytest.mark.gpu
+def test_partitioned_encoder_hip_two_ranks():
+    """two processes, both on the box's one GPU, the product HIP backend in each; collectives
+    over gloo (RCCL refuses two ranks on one device) - the full multi-process path minus RCCL."""
+    need_gpu()
+    world, n, e, r, dims, seed = 2, 3000, 60000, 3, (64, 128, 128), 8
+    _check_partitioned(_run_partitioned(world, n, e, r, dims, seed, True), world, n, e, r, dims, seed)
 
 
 def test_partition_is_balanced_and_consistent():

@@ -424,3 +424,55 @@ def test_functional_entry_and_r16():
     bias = torch.randn(128, generator=gen)
     out = rgcn_conv(x.to(dev), ei.to(dev), et.to(dev), w.to(dev), root.to(dev), bias.to(dev), r)
     assert_fwd(out, O.rgcn_conv_ref(x, ei, et, w, root, bias))
+
+
+def test_config_c4_scale_on_one_gpu():
+    """BASELINE configs[3] shape (500k nodes / 20M edges / 16 relations, 64 -> 128) on ONE GPU:
+    size-independent properties over the whole graph + the oracle on a sample of rows."""
+    dev = need_gpu()
+    n, e, r, d_in, d_out = 500_000, 20_000_000, 16, 64, 128
+    ei, et, _, _ = synth.uniform_graph(n, e, r, seed=42)
+    eid, etd = ei.to(dev), et.to(dev)
+    g = ops.BucketedGraph(eid, etd, n, r)
+    rowptr, col, perm, cnt = g.arrays(False)
+    assert rowptr[-1].item() == e and rowptr[0].item() == 0
+    assert bool((rowptr[1:] >= rowptr[:-1]).all())
+    assert torch.equal(torch.sort(perm).values, torch.arange(e, device=dev))          # a permutation
+    key = (eid[1] * r + etd)[perm]
+    assert bool((key[1:] >= key[:-1]).all())                                           # bucketed
+    same = key[1:] == key[:-1]
+    assert bool((perm[1:][same] > perm[:-1][same]).all())                              # stable inside a segment
+    assert torch.equal(col.long(), eid[0][perm])
+    deg = torch.bincount(key, minlength=n * r)
+    assert torch.equal(cnt, deg.clamp(min=1).float())
+    del rowptr, col, key, same
+    # exactness on ones, determinism
+    ones = ops.aggregate(g, torch.ones(n, 8, device=dev)).view(n * r, 8)
+    assert torch.equal(ones, (deg > 0).float().view(-1, 1).expand(-1, 8))
+    del ones
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(n, d_in, generator=gen)
+    xd = x.to(dev)
+    agg = ops.aggregate(g, xd)
+    assert torch.equal(agg, ops.aggregate(g, xd))
+    w = torch.randn(r, d_in, d_out, generator=gen) * 0.05
+    root = torch.randn(d_in, d_out, generator=gen) * 0.05
+    bias = torch.randn(d_out, generator=gen)
+    out = ops.transform_fwd(agg, xd, w.to(dev), root.to(dev), bias.to(dev))
+    # oracle on 64 sampled destination rows (all their in-edges, original column order)
+    rows = torch.randint(0, n, (64,), generator=gen)
+    for i in rows.tolist()[:16]:
+        m = ei[1] == i
+        src, rel = ei[0][m], et[m]
+        want = torch.zeros(d_out)
+        for k in range(r):
+            s = x[src[rel == k]]
+            h = s.sum(0) / max(1, s.size(0)) if s.size(0) else torch.zeros(d_in)
+            want = want + h @ w[k]
+        want = want + x[i] @ root + bias
+        assert (out[i].cpu() - want).abs().max().item() <= 1e-5
+    # transposed structure: sum of weights into each destination segment is 1 (or 0 if empty)
+    _, col_t, _, w_t = g.arrays(True)
+    seg = col_t.long() * r + etd[g.arrays(True)[2]]
+    tot = torch.zeros(n * r, device=dev, dtype=torch.float64).index_add_(0, seg, w_t.double())
+    assert torch.allclose(tot, (deg > 0).double(), atol=1e-6)

@@ -1,0 +1,107 @@
+"""Training harness (primekg_rgcn_linkprediction_amd/train.py), SURVEY section 8f next row 1.
+
+CPU tier: sampler pinned bit-for-bit by the reference-run fixture, CLI surface, data helpers.
+GPU tier: real steps of the Trainer on the HIP model against the oracle stepping on the very
+same batches; a short run must learn."""
+import argparse
+
+import pytest
+import torch
+
+from conftest import load_golden, need_gpu
+from oracle import rgcn_oracle as O
+from primekg_rgcn_linkprediction_amd import train as T
+
+
+def test_negative_sampler_matches_reference_run():
+    z = load_golden("ref_negative_sampler.npz")
+    s = T.NegativeSampler(num_nodes=z["num_nodes"], num_neg_samples=z["num_neg"])
+    torch.manual_seed(z["seed"])
+    nh, nt, nr = s.sample(z["pos_head"], z["pos_tail"], z["pos_rel"])
+    assert torch.equal(nh, z["neg_head"]) and torch.equal(nt, z["neg_tail"]) and torch.equal(nr, z["neg_rel"])
+    # exactly one endpoint of every negative is the positive's (the other was redrawn)
+    ph, pt = z["pos_head"].repeat_interleave(2), z["pos_tail"].repeat_interleave(2)
+    assert bool(((nh == ph) | (nt == pt)).all())
+
+
+def test_cli_defaults_are_the_references():
+    a = T.parse_args([])
+    want = dict(data_dir="data/processed", output_dir="output", embedding_dim=64, hidden_dim=128, dropout=0.5,
+                decoder_dropout=0.1, num_bases=None, epochs=100, batch_size=1024, lr=0.001, weight_decay=0.0,
+                optimizer="adam", num_neg_samples=1, grad_clip=1.0, gradient_accumulation_steps=1, save_every=10,
+                early_stopping=0, seed=42)
+    for k, v in want.items():
+        assert getattr(a, k) == v, k
+    with pytest.raises(SystemExit):
+        T.parse_args(["--optimizer", "sgd"])
+
+
+def test_filter_edges_and_synthetic_split():
+    d = {"edge_index": torch.tensor([[0, 5, 2], [1, 1, 9]]), "edge_type": torch.tensor([0, 1, 2]),
+         "num_nodes": 5, "num_relations": 3}
+    f = T.filter_edges(d, 5, "t")
+    assert f["edge_index"].tolist() == [[0], [1]] and f["edge_type"].tolist() == [0]
+    tr, va, full, te = T.synthetic_data(num_edges=20000, seed=1)
+    assert tr["edge_index"].size(1) + va["edge_index"].size(1) == full["edge_index"].size(1) == 20000
+    assert bool((va["edge_type"] == 0).all()) and va["edge_index"].size(1) % 2 == 0
+    assert torch.equal(va["edge_index"][:, 0::2], va["edge_index"][:, 1::2].flip(0))   # pairs stay together
+    assert tr["num_nodes"] == 30926 and tr["num_relations"] == 3
+
+
+def _args(**kw):
+    a = T.parse_args([])
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+@pytest.mark.gpu
+def test_trainer_steps_match_oracle_on_the_same_batches(tmp_path):
+    """Five optimizer steps (Adam, clip 1.0, dropout 0) on the HIP model vs the oracle model
+    fed the recorded batches: per-step loss and the parameters afterwards agree."""
+    dev = need_gpu()
+    torch.manual_seed(0)
+    n, r = 400, 3
+    gen = torch.Generator().manual_seed(3)
+    ei = torch.randint(0, n, (2, 6000), generator=gen)
+    et = torch.randint(0, r, (6000,), generator=gen)
+    data = {"edge_index": ei, "edge_type": et, "num_nodes": n, "num_relations": r}
+    args = _args(dropout=0.0, decoder_dropout=0.0, batch_size=256, output_dir=str(tmp_path), device="cuda")
+    model = T.create_model(n, r, args)
+    ref_state = {k: v.clone() for k, v in model.state_dict().items()}
+    trainer = T.Trainer(model, data, data, data, dev, args)
+    log = []
+    trainer.train_epoch(on_step=lambda h, t, rl, lb, loss: log.append((h.cpu(), t.cpu(), rl.cpu(), lb.cpu(), loss.item())),
+                        max_steps=5)
+    # oracle replay
+    params = {k: v.clone().requires_grad_(True) for k, v in ref_state.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=args.lr)
+    conv = lambda i: {k: params[f"encoder.conv{i}.{k}"] for k in ("weight", "root", "bias")}   # noqa: E731
+    for h, t, rl, lb, loss_gpu in log:
+        emb = O.encoder_ref(params["encoder.node_embeddings.weight"], conv(1), conv(2), ei, et)
+        scores = O.distmult_ref(emb[h], emb[t], params["decoder.relation_embeddings.weight"][rl])
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(scores, lb)
+        assert abs(loss.item() - loss_gpu) <= 2e-5 * max(1.0, abs(loss.item()))
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), args.grad_clip)
+        opt.step()
+    for k, v in trainer.model.state_dict().items():
+        assert (v.cpu() - params[k].detach()).abs().max().item() <= 5e-5, k
+
+
+@pytest.mark.gpu
+def test_short_run_learns_and_checkpoints(tmp_path):
+    dev = need_gpu()
+    torch.manual_seed(1)
+    tr, va, full, _ = T.synthetic_data(num_edges=40000, seed=5)
+    args = _args(epochs=2, batch_size=1024, output_dir=str(tmp_path), save_every=1, device="cuda", lr=0.01)
+    trainer = T.Trainer(T.create_model(tr["num_nodes"], 3, args), tr, va, full, dev, args)
+    trainer.train()
+    assert trainer.train_losses[-1] < trainer.train_losses[0] < 0.75
+    assert trainer.val_accs[-1] > 0.6                           # held-out drug-gene pairs vs random corruptions
+    ck = torch.load(tmp_path / "models" / "final_model.pt", weights_only=False)
+    assert set(ck) >= {"epoch", "model_state_dict", "optimizer_state_dict", "best_val_loss", "best_val_acc",
+                       "train_losses", "val_losses", "train_accs", "val_accs", "args"}
+    assert "encoder.conv1.weight" in ck["model_state_dict"] and isinstance(ck["args"], argparse.Namespace)
+    assert (tmp_path / "models" / "best_model.pt").exists() and (tmp_path / "checkpoints" / "checkpoint_epoch_2.pt").exists()
