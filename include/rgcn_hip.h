@@ -175,6 +175,15 @@ int distmult_bwd(const float* grad_scores, const float* h, const int64_t* h_idx,
                  const int64_t* t_idx, const float* r, const int64_t* r_idx, int64_t batch,
                  int64_t d, float* grad_h, float* grad_t, float* grad_r, void* stream);
 
+/* Tail ranking for evaluation (LinkPredictor.score_all_tails rgcn.py:215-243 +
+ * compute_ranking_metrics evaluate.py:260-276, without materialising the [B, N] score matrix
+ * or sorting it): hr = head_emb * rel_emb rows [B, d]; scores[b, n] = <hr[b], emb[n]> on the
+ * fp32 MFMA; beaten_by[b] += #{ n != tail[b] : scores[b, n] > true_score[b] } (int atomics into
+ * a caller-zeroed buffer), so rank[b] = 1 + beaten_by[b].  d must be a multiple of 32. */
+int distmult_rank_tails(const float* hr, const float* emb, const float* true_score,
+                        const int64_t* tail, int64_t batch, int64_t num_entities, int64_t d,
+                        int32_t* beaten_by, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

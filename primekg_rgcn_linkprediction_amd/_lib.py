@@ -50,6 +50,7 @@ PROTOTYPES = {
     "rgcn_transform_bwd_params": (c_int, [_P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P,
                                           c_size_t, _P]),
     "distmult_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "distmult_rank_tails": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "distmult_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
 }
 

@@ -29,7 +29,7 @@ constexpr int BK = 32;          // k-tile
 constexpr int LDS_S = 36;       // row stride (floats) of k-contiguous LDS tiles (144 B)
 
 enum { B_KN = 0, B_BLK = 1 };            // how the B operand is addressed (see k_gemm_nt)
-enum { EPI_NONE = 0, EPI_RELU = 1, EPI_MASK = 2 };
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_MASK = 2, EPI_RANK = 3 };
 
 __device__ inline float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ inline float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_dma(const float* __restric
                                                           const float* __restrict__ Rt, int dk,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ mask,
-                                                          float* __restrict__ C, int M, int N) {
+                                                          float* __restrict__ C, int M, int N,
+                                                          const void* __restrict__ aux) {
   constexpr int BM = 64, BN = 64 * TN, NBUF = 3;
   constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, BUF_FLOATS = A_FLOATS + B_FLOATS;
   constexpr int A_PW = BM / 32;                 // A wave-instructions per wave and k-tile (8 rows each)
@@ -373,6 +374,31 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_dma(const float* __restric
     }
   }
 
+  if (EPI == EPI_RANK) {
+    // Ranking epilogue (evaluate.py:260-276 without the [B, N] score matrix): row m is a test
+    // triple, column n a candidate tail; count the candidates that beat the true tail's score
+    // (bias[m]), the true tail itself (aux[m]) excluded.  One ballot per accumulator register:
+    // lanes 0-31 / 32-63 hold 32 columns of two rows.
+    const int64_t* tails = reinterpret_cast<const int64_t*>(aux);
+    int* counts = reinterpret_cast<int*>(C);
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + (wn * TN + b) * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const bool in = (m < M) && (n < N);
+        const float ts = in ? bias[m] : 0.f;
+        const int64_t tl = in ? tails[m] : -1;
+        const unsigned long long hits = __ballot(in && (int64_t)n != tl && acc[b][r] > ts);
+        if (li == 0 && m < M) {
+          const int c = __popc(lh ? (unsigned)(hits >> 32) : (unsigned)hits);
+          if (c) atomicAdd(&counts[m], c);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int n = n0 + (wn * TN + b) * 32 + li;
@@ -741,10 +767,10 @@ void launch_nt(const float* A1, int K1, const float* A2, int K2, const float* W,
   if (dma_ok) {
     if (N <= 64) {
       dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
-      k_gemm_nt_dma<1, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N);
+      k_gemm_nt_dma<1, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N, nullptr);
     } else {
       dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 128));
-      k_gemm_nt_dma<2, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N);
+      k_gemm_nt_dma<2, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N, nullptr);
     }
     return;
   }
@@ -797,6 +823,22 @@ int rgcn_transform_bwd_input(const float* gagg, const float* g, const float* wei
   else
     launch_nt<B_BLK, EPI_NONE>(gagg, K1, g, K2, weight, root, (int)d_out, nullptr, nullptr, grad_x, (int)N,
                                (int)d_in, stream);
+  RGCN_HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+int distmult_rank_tails(const float* hr, const float* emb, const float* true_score, const int64_t* tail,
+                        int64_t batch, int64_t num_entities, int64_t d, int32_t* beaten_by, void* stream_) {
+  if (batch < 0 || num_entities <= 0 || d <= 0 || (d % BK)) return (d > 0 && (d % BK)) ? RGCN_ERR_UNSUPPORTED : RGCN_ERR_ARG;
+  if (batch == 0) return RGCN_OK;
+  if (!hr || !emb || !true_score || !tail || !beaten_by) return RGCN_ERR_ARG;
+  if (batch > INT32_MAX / 2 || num_entities > INT32_MAX / 2) return RGCN_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  // scores[b, n] = sum_k hr[b, k] * emb[n, k]: the B_BLK addressing with one block (r = 0, dk = d)
+  dim3 grid((unsigned)ceil_div64(batch, 64), (unsigned)ceil_div64(num_entities, 128));
+  k_gemm_nt_dma<2, B_BLK, EPI_RANK><<<grid, kThreads, 0, stream>>>(hr, (int)d, hr, 0, emb, emb, (int)d, true_score,
+                                                                    nullptr, reinterpret_cast<float*>(beaten_by),
+                                                                    (int)batch, (int)num_entities, tail);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

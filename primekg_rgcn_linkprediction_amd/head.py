@@ -100,6 +100,18 @@ class LinkPredictor(nn.Module):
         r, r_idx = self._relation_operand(relation_types)
         return distmult(node_embeddings, head_indices, node_embeddings, tail_indices, r, r_idx)
 
+    @torch.no_grad()
+    def rank_tails(self, head_embeddings: Tensor, relation_types: Tensor, all_tail_embeddings: Tensor,
+                   tail_indices: Tensor) -> Tensor:
+        """1-based rank of ``tail_indices[b]`` among all entities for ``(head, relation)``:
+        ``argsort(score_all_tails(...)[b], descending=True)`` position + 1, as
+        ``evaluate.py:266-274`` computes it, but from one fused MFMA pass that counts the
+        candidates beating the true tail's score (ties, measure zero in fp32, rank first)."""
+        hr = (head_embeddings * self.relation_embeddings(relation_types)).contiguous()
+        emb = all_tail_embeddings.contiguous()
+        true_score = (hr * emb[tail_indices]).sum(1)
+        return ops.distmult_rank_tails(hr, emb, true_score, tail_indices.contiguous())
+
     def score_all_tails(self, head_embeddings: Tensor, relation_types: Tensor,
                         all_tail_embeddings: Tensor) -> Tensor:
         """``(h * r) @ E^T`` -> [B, num_entities] (rgcn.py:215-243).  A plain library GEMM

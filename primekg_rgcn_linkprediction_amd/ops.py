@@ -359,3 +359,26 @@ def distmult_bwd(gs, h, h_idx, t, t_idx, r, r_idx, batch: int, grad_h, grad_t, g
         rc = lib.distmult_bwd(_ptr(gs), _ptr(h), _ptr(h_idx), _ptr(t), _ptr(t_idx), _ptr(r), _ptr(r_idx),
                               batch, d, _ptr(grad_h), _ptr(grad_t), _ptr(grad_r), _stream())
     _lib.check(rc, "distmult_bwd")
+
+
+def distmult_rank_tails(hr: torch.Tensor, emb: torch.Tensor, true_score: torch.Tensor,
+                        tail: torch.Tensor) -> torch.Tensor:
+    """``rank[b] = 1 + #{n != tail[b] : <hr[b], emb[n]> > true_score[b]}`` (int64 [B]): the
+    rank of the true tail among all entities without the [B, N] score matrix
+    (``evaluate.py:260-276``)."""
+    _need_gpu("hr", hr, torch.float32)
+    _need_gpu("emb", emb, torch.float32)
+    _need_gpu("true_score", true_score, torch.float32)
+    _need_gpu("tail", tail, torch.int64)
+    b, d = hr.shape
+    if emb.dim() != 2 or emb.size(1) != d or true_score.shape != (b,) or tail.shape != (b,):
+        raise ValueError("hr [B, d], emb [N, d], true_score [B], tail [B] expected")
+    if d % 32:
+        raise ValueError("embedding dim must be a multiple of 32 for the fused ranking kernel")
+    lib = _lib.load()
+    with torch.cuda.device(hr.device):
+        beaten = torch.zeros(b, dtype=torch.int32, device=hr.device)
+        rc = lib.distmult_rank_tails(_ptr(hr), _ptr(emb), _ptr(true_score), _ptr(tail), b, emb.size(0), d,
+                                     _ptr(beaten), _stream())
+    _lib.check(rc, "distmult_rank_tails")
+    return beaten.to(torch.int64) + 1

@@ -1,0 +1,60 @@
+"""Evaluation protocol (primekg_rgcn_linkprediction_amd/evaluate.py), SURVEY 8f next row 2."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, need_gpu
+from primekg_rgcn_linkprediction_amd import DrugDiseaseModel
+from primekg_rgcn_linkprediction_amd.evaluate import ModelEvaluator
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_ranks(scores, tails):
+    """evaluate.py:266-274 verbatim in spirit: position of the true tail in the descending sort"""
+    out = []
+    for i, t in enumerate(tails.tolist()):
+        order = torch.argsort(scores[i], descending=True)
+        out.append((order == t).nonzero(as_tuple=True)[0].item() + 1)
+    return torch.tensor(out)
+
+
+def test_fused_ranks_equal_argsort_ranks_on_the_reference_run_model():
+    dev = need_gpu()
+    z = load_golden("ref_model_eval.npz")
+    sd = {k[4:].replace("__", "."): v for k, v in z.items() if k.startswith("sd__")}
+    m = DrugDiseaseModel(100, 3, 64, 128)
+    m.load_state_dict(sd)
+    data = {"edge_index": z["edge_index"], "edge_type": z["edge_type"], "num_nodes": 100, "num_relations": 3}
+    test = {"edge_index": torch.stack([z["head"], z["tail"]]), "edge_type": z["rel"], "num_nodes": 100,
+            "num_relations": 3}
+    ev = ModelEvaluator(m, test, data, dev)
+    ranks = ev.tail_ranks().cpu()
+    want = _reference_ranks(z["all_scores"], z["tail"])       # all_scores come from the REFERENCE's predict_all_tails
+    assert torch.equal(ranks, want)
+    metrics = ev.compute_ranking_metrics((1, 10, 50))
+    assert abs(metrics["mrr"] - float(np.mean(1.0 / want.numpy()))) < 1e-12
+    assert metrics["hits@50"] == float((want <= 50).float().mean())
+
+
+def test_ranks_and_auc_on_a_larger_graph():
+    dev = need_gpu()
+    from primekg_rgcn_linkprediction_amd import train as T
+    torch.manual_seed(0)
+    tr, va, full, te = T.synthetic_data(num_edges=30000, seed=2)
+    m = DrugDiseaseModel(full["num_nodes"], 3, 64, 128)
+    ev = ModelEvaluator(m, te, full, dev, batch_size=1024)
+    ranks = ev.tail_ranks()
+    emb = ev.embeddings()
+    h, t, r = ev.test_edge_index[0], ev.test_edge_index[1], ev.test_edge_type
+    scores = m.decoder.score_all_tails(emb[h[:200]], r[:200], emb)
+    true = scores.gather(1, t[:200].view(-1, 1))
+    # tolerance band around the true score (the GEMM and the row-wise dot round differently)
+    lo = (scores > true + 1e-5).sum(1) + 1
+    hi = (scores > true - 1e-5).sum(1)
+    assert bool(((ranks[:200] >= lo) & (ranks[:200] <= hi.clamp(min=1))).all())
+    assert ranks.min() >= 1 and ranks.max() <= full["num_nodes"]
+    out = ev.evaluate()
+    assert 0.0 <= out["classification"]["auc_roc"] <= 1.0 and out["num_test_edges"] == te["edge_index"].size(1)
+    s, l = ev.compute_scores_and_labels(num_neg_samples=2)
+    assert s.shape == l.shape == (3 * out["num_test_edges"],) and l.sum() == out["num_test_edges"]
