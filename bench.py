@@ -39,7 +39,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--edges", type=int, default=None, help="override E (default 849,456)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of a HIP graph replay")
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches, never a HIP graph replay")
+    ap.add_argument("--graph", action="store_true", help="time the HIP graph replay even if eager calibrates faster")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -171,9 +172,18 @@ def main():
         step()
     sync()
 
-    # The step is a fixed sequence of launches on a static graph: capture it once into a
-    # HIP graph and replay it (same kernels, same work, no per-launch host cost).  Falls back
-    # to eager launches if capture is unavailable (and always at N > 1, where RCCL runs eager).
+    # The step is a fixed sequence of launches on a static graph.  It can be issued eagerly (the
+    # host runs ahead of the GPU) or replayed from ONE captured HIP graph (no per-launch host
+    # cost, robust against a busy host): same kernels and work either way.  A short untimed
+    # calibration picks the faster launch mode on this machine; --no-graph / --graph force one.
+    def timed(fn, k):
+        sync()
+        t = time.perf_counter()
+        for _ in range(k):
+            fn()
+        sync()
+        return (time.perf_counter() - t) / k
+
     run, launch_mode = step, "eager"
     if world == 1 and not args.no_graph:
         try:
@@ -188,7 +198,8 @@ def main():
             for _ in range(3):
                 hip_graph.replay()
             torch.cuda.synchronize()
-            run, launch_mode = hip_graph.replay, "hipGraph replay"
+            if args.graph or timed(hip_graph.replay, 10) < timed(step, 10):
+                run, launch_mode = hip_graph.replay, "hipGraph replay"
         except Exception as exc:                                   # pragma: no cover
             print(f"bench: HIP graph capture failed ({exc!r}); timing eager launches", file=sys.stderr)
     sync()

@@ -59,8 +59,8 @@ class HipBackend:
     def transform_fwd(self, agg, x, weight, root, bias, relu=False):
         return self.ops.transform_fwd(agg, x, weight, root, bias, relu)
 
-    def transform_bwd_input(self, gagg, g, weight, root):
-        return self.ops.transform_bwd_input(gagg, g, weight, root)
+    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None):
+        return self.ops.transform_bwd_input(gagg, g, weight, root, relu_mask)
 
     def transform_bwd_params(self, agg, x, g, num_relations, want_root, want_bias):
         return self.ops.transform_bwd_params(agg, x, g, num_relations, want_root, want_bias)
@@ -145,6 +145,85 @@ def _all_gather_rows(own: Tensor, world: int, group) -> Tensor:
     return out
 
 
+class _Gather:
+    """An all-gather of row slabs that may still be in flight: issue it, launch the work that
+    only needs this rank's rows, then ``.result()`` when the gathered rows are needed."""
+
+    def __init__(self, own: Tensor, world: int, group):
+        self.work = None
+        if own.is_cuda and dist.get_backend(group) == "gloo":
+            self.out = _all_gather_rows(own, world, group)          # host-staged test path: synchronous
+            return
+        self.out = own.new_empty((own.size(0) * world,) + tuple(own.shape[1:]))
+        self.work = dist.all_gather_into_tensor(self.out, own.contiguous(), group=group, async_op=True)
+
+    def result(self) -> Tensor:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.out
+
+
+def _flat_all_reduce(parts, group):
+    """one flat all-reduce for a layer's parameter-gradient partial sums -> (work, flat, parts)"""
+    parts = [t for t in parts if t is not None]
+    flat = torch.cat([t.reshape(-1) for t in parts])
+    return dist.all_reduce(flat, group=group, async_op=True), flat, parts
+
+
+def _unflatten(flat, parts, has_root, has_bias):
+    outs, off = [], 0
+    for t in parts:
+        outs.append(flat[off: off + t.numel()].view_as(t))
+        off += t.numel()
+    it = iter(outs)
+    return next(it), (next(it) if has_root else None), (next(it) if has_bias else None)
+
+
+class _PartitionedEncoder2Function(torch.autograd.Function):
+    """conv1 -> ReLU -> conv2 on this rank's rows as ONE autograd node (cf. conv._Encoder2Function):
+    four exchanges per step, each issued asynchronously and overlapped with the work that needs
+    only own rows (the parameter-gradient GEMMs), ReLU and its backward in the GEMM epilogues."""
+
+    @staticmethod
+    def forward(ctx, x, w1, root1, b1, w2, root2, b2, shard: RankShard, backend, group):
+        world = shard.part.world
+        x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
+        agg1 = backend.aggregate(shard.g_in, _Gather(x, world, group).result())
+        h = backend.transform_fwd(agg1, x, w1, root1, b1, True)
+        agg2 = backend.aggregate(shard.g_in, _Gather(h, world, group).result())
+        out = backend.transform_fwd(agg2, h, w2, root2, b2, False)
+        ctx.shard, ctx.backend, ctx.group = shard, backend, group
+        ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
+        ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, agg1, h, agg2, w1, root1, w2, root2 = ctx.saved_tensors
+        shard, backend, group = ctx.shard, ctx.backend, ctx.group
+        world, r = shard.part.world, shard.num_relations
+        has_root1, has_b1, has_root2, has_b2 = ctx.flags
+        g = g.contiguous()
+        g_all = _Gather(g, world, group)                                   # exchange in flight ...
+        red2 = _flat_all_reduce(backend.transform_bwd_params(agg2, h, g, r, has_root2, has_b2), group)
+        gagg2 = backend.aggregate(shard.g_out, g_all.result())             # ... behind the GEMM above
+        gz = backend.transform_bwd_input(gagg2, g, w2, root2, h)           # ReLU backward in the epilogue
+        gz_all = _Gather(gz, world, group)
+        red1 = _flat_all_reduce(backend.transform_bwd_params(agg1, x, gz, r, has_root1, has_b1), group)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gagg1 = backend.aggregate(shard.g_out, gz_all.result())
+            gx = backend.transform_bwd_input(gagg1, gz, w1, root1, None)
+        else:
+            gz_all.result()
+        red2[0].wait()
+        red1[0].wait()
+        gw2, groot2, gb2 = _unflatten(red2[1], red2[2], has_root2, has_b2)
+        gw1, groot1, gb1 = _unflatten(red1[1], red1[2], has_root1, has_b1)
+        return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None, None
+
+
 class _PartitionedConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_own, weight, root, bias, shard: RankShard, backend, group, relu=False):
@@ -175,7 +254,7 @@ class _PartitionedConvFunction(torch.autograd.Function):
         if need_x:
             g_all = _all_gather_rows(g_own, shard.part.world, group)
             gagg = backend.aggregate(shard.g_out, g_all)
-            gx = backend.transform_bwd_input(gagg, g_own, weight, root)
+            gx = backend.transform_bwd_input(gagg, g_own, weight, root, None)
         work.wait()
         outs, off = [], 0
         for t in parts:
@@ -218,6 +297,13 @@ class PartitionedEncoder:
         return self.part.shard_rows(full, self.rank)
 
     def forward(self) -> Tensor:
+        c1, c2 = self.convs
+        return _PartitionedEncoder2Function.apply(self.emb, c1.effective_weight(), c1.root, c1.bias,
+                                                  c2.effective_weight(), c2.root, c2.bias, self.shard,
+                                                  self.backend, self.group)
+
+    def forward_layers(self) -> Tensor:
+        """same result through the two per-layer autograd nodes (general API; used by tests)"""
         c1, c2 = self.convs
         h = partitioned_conv(self.emb, c1.effective_weight(), c1.root, c1.bias, self.shard, self.backend,
                              self.group, relu=True)

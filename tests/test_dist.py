@@ -45,10 +45,11 @@ class OracleBackend:
         out = out + bias if bias is not None else out
         return torch.relu(out) if relu else out
 
-    def transform_bwd_input(self, gagg, g, weight, root):
+    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None):
         r, d_in, d_out = weight.shape
         gx = sum(gagg[:, k * d_out:(k + 1) * d_out] @ weight[k].t() for k in range(r))
-        return gx + g @ root.t() if root is not None else gx
+        gx = gx + g @ root.t() if root is not None else gx
+        return gx * (relu_mask > 0) if relu_mask is not None else gx
 
     def transform_bwd_params(self, agg, x, g, num_relations, want_root, want_bias):
         gw = (agg.t() @ g).view(num_relations, x.size(1), g.size(1))
@@ -96,6 +97,8 @@ def _worker(rank, world, port, n, e, r, dims, seed, q, use_hip=False):
             dev = torch.device("cpu")
             enc = rdist.PartitionedEncoder(ei, et, n, r, emb, convs, dev, backend=OracleBackend())
         out_own = enc.step(enc.shard_rows(cot).to(dev))
+        with torch.no_grad():                       # the per-layer nodes give the same rows
+            assert torch.allclose(enc.forward_layers(), out_own, rtol=1e-6, atol=1e-6)
         out = enc.gather_output(out_own).cpu()
         gemb = enc.gather_output(enc.emb.grad).cpu()
         grads = {f"{i}.{k}": p.grad.cpu().numpy().copy() for i, c in enumerate(enc.convs)
