@@ -15,7 +15,7 @@
 //
 // Segments longer than 64 edges leave one partial row per run; k_reduce_partials sums the
 // (contiguous) partial rows of a segment with a whole workgroup per item (up to 512 rows:
-// 1024/G row slots in parallel, LDS combine in slot order), so even a 30k-edge hub costs one
+// 256/G row slots in parallel, LDS combine in slot order), so even a 30k-edge hub costs one
 // extra short launch and the result is run-to-run deterministic.
 #include "rgcn_common.h"
 
@@ -91,14 +91,12 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
 // Slot s of SLOTS = 256/G sums rows begin+s, begin+s+SLOTS, ... in order; the slots are then
 // added in slot order through LDS.  Reads and writes of `partial` never alias inside one
 // launch: a level reads rows written by the level below and writes rows of its own range.
-constexpr int kReduceThreads = 1024;   // 1024/G row slots per item: two load rounds cover 512 rows at d = 128
-
 template <int G>
-__global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const rgcn_item* __restrict__ items,
-                                                                    const float* __restrict__ cnt,
-                                                                    float* __restrict__ agg, float* partial, int d) {
-  constexpr int SLOTS = kReduceThreads / G;
-  __shared__ float4 red[kReduceThreads];
+__global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* __restrict__ items,
+                                                              const float* __restrict__ cnt,
+                                                              float* __restrict__ agg, float* partial, int d) {
+  constexpr int SLOTS = kThreads / G;
+  __shared__ float4 red[kThreads];
   const rgcn_item it = items[blockIdx.x];
   const int gl = (int)threadIdx.x % G, slot = (int)threadIdx.x / G;
   const int c4 = (gl + (int)blockIdx.y * G) * 4;
@@ -149,7 +147,7 @@ void launch_level(const rgcn_csr* c, int level, bool weighted, const float* x, c
       k_aggregate<G, false><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, nullptr, cnt, agg, partial, d);
   } else {
     dim3 grid((unsigned)nitems, gy);
-    k_reduce_partials<G><<<grid, kReduceThreads, 0, stream>>>(c->items[level], cnt, agg, partial, d);
+    k_reduce_partials<G><<<grid, kThreads, 0, stream>>>(c->items[level], cnt, agg, partial, d);
   }
 }
 

@@ -399,18 +399,6 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_dma(const float* __restric
     }
     return;
   }
-  float mk[TN][16];
-  if (EPI == EPI_MASK) {                       // all mask loads in flight before the first use
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int n = n0 + (wn * TN + b) * 32 + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        mk[b][r] = (m < M && n < N) ? mask[(size_t)m * N + n] : 0.f;
-      }
-    }
-  }
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int n = n0 + (wn * TN + b) * 32 + li;
@@ -422,7 +410,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_dma(const float* __restric
       if (m < M) {
         float v = acc[b][r] + bv;
         if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-        if (EPI == EPI_MASK) v = mk[b][r] > 0.f ? v : 0.f;
+        if (EPI == EPI_MASK) v = mask[(size_t)m * N + n] > 0.f ? v : 0.f;
         C[(size_t)m * N + n] = v;
       }
     }
