@@ -211,17 +211,18 @@ def main():
 
     # Per-kernel durations of the gather, live, from HIP events on the launch stream: an eager
     # pass of the same step (events cannot be read back from inside a captured graph).
-    events = None
-    if world == 1:
-        ops.GATHER_EVENTS = []
-        for _ in range(min(args.steps, 20)):
-            # a short device-side spin first, so that the host has queued the step's launches
-            # before they execute: the events then bracket back-to-back kernels, not launch gaps
+    # (At N > 1 every rank runs the pass - the exchanges are collective - and rank 0 reports the
+    # gather over its own shard, whose edge count sizes the algorithmic bytes.)
+    event_steps = min(args.steps, 20)
+    ops.GATHER_EVENTS = []
+    for _ in range(event_steps):
+        # a short device-side spin first, so that the host has queued the step's launches
+        # before they execute: the events then bracket back-to-back kernels, not launch gaps
+        if world == 1:
             torch.cuda._sleep(2_000_000)
-            step()
-        torch.cuda.synchronize()
-        events, ops.GATHER_EVENTS = ops.GATHER_EVENTS, None
-        event_steps = min(args.steps, 20)
+        step()
+    sync()
+    events, ops.GATHER_EVENTS = ops.GATHER_EVENTS, None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -242,15 +243,17 @@ def main():
         "bucket_ms": bucket_ms,
     }
 
-    if world == 1 and events:
+    if events:
         # per instantiation of the gather kernel: average duration from the live HIP events
-        per = {}
-        for transposed, d, beg, end in events:
+        per, shape = {}, {}
+        for transposed, d, edges, segments, beg, end in events:
             per.setdefault((transposed, d), []).append(beg.elapsed_time(end) * 1e-3)   # seconds
+            shape[(transposed, d)] = (edges, segments)
         kernels = []
         for (transposed, d), ts in sorted(per.items()):
             avg = sum(ts) / len(ts)
-            nbytes = gather_bytes(num_edges, n, r, d, transposed)
+            edges, segments = shape[(transposed, d)]
+            nbytes = gather_bytes(edges, segments // r, r, d, transposed)
             kernels.append({"kernel": f"k_aggregate<{d // 4},{'true' if transposed else 'false'}>",
                             "d": d, "transposed": transposed, "launches_per_step": len(ts) // event_steps,
                             "avg_us": avg * 1e6, "bytes": nbytes, "gbs": nbytes / avg / 1e9,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 2
+#define RGCN_ABI_VERSION 3
 
 enum {
   RGCN_OK = 0,
@@ -86,6 +86,15 @@ int64_t rgcn_graph_num_relations(const rgcn_graph* g);
 /* number of aggregate launches (tree levels) one rgcn_aggregate call issues */
 int rgcn_graph_num_levels(const rgcn_graph* g, int transposed);
 
+/* Relation occupancy of 32-row tiles: bit r of mask[t] is set iff some row of [32t, 32t+32)
+ * has a non-empty (row, r) segment in that direction's structure; NULL when R > 32.  Typed
+ * relations (PrimeKG: drug-gene edges never reach a disease node) leave whole row ranges of
+ * agg exactly zero for a relation; passing this mask as `tile_mask` to the transforms below
+ * lets them skip those all-zero tiles (results are unchanged: only 0 * w products are dropped).
+ * Use the forward mask with rgcn_transform_fwd / _bwd_params (their A operand is the forward
+ * aggregate) and the transposed mask with rgcn_transform_bwd_input.  Owned by the handle. */
+const uint32_t* rgcn_graph_tile_mask(const rgcn_graph* g, int transposed, int64_t* num_row_tiles);
+
 /* Device views of the bucketed arrays (for parity tests and sidecar files):
  *   rowptr int32[N*R+1], col int32[E], perm int64[E] (original column of each bucketed
  *   edge), val float32: cnt[N*R] = max(1, segment size) when transposed == 0,
@@ -129,8 +138,8 @@ int rgcn_aggregate_level(const rgcn_graph* g, int transposed, int level, const f
  * out = max(out, 0).
  * ---------------------------------------------------------------------------------- */
 int rgcn_transform_fwd(const float* agg, const float* x, const float* weight, const float* root,
-                       const float* bias, int relu, int64_t num_nodes, int64_t num_relations,
-                       int64_t d_in, int64_t d_out, float* out, void* stream);
+                       const float* bias, int relu, const uint32_t* tile_mask, int64_t num_nodes,
+                       int64_t num_relations, int64_t d_in, int64_t d_out, float* out, void* stream);
 
 /* Autograd of A6 with respect to the layer input (row A7):
  *   grad_x[N, d_in] = sum_r gagg[:, r, :] @ weight[r]^T + g @ root^T
@@ -139,9 +148,9 @@ int rgcn_transform_fwd(const float* agg, const float* x, const float* weight, co
  * layer, pass x itself; the epilogue then writes grad_x * (x > 0), i.e. the gradient with
  * respect to that producer's pre-activation (autograd of rgcn.py:124). */
 int rgcn_transform_bwd_input(const float* gagg, const float* g, const float* weight,
-                             const float* root, const float* relu_mask, int64_t num_nodes,
-                             int64_t num_relations, int64_t d_in, int64_t d_out, float* grad_x,
-                             void* stream);
+                             const float* root, const float* relu_mask, const uint32_t* tile_mask,
+                             int64_t num_nodes, int64_t num_relations, int64_t d_in, int64_t d_out,
+                             float* grad_x, void* stream);
 
 /* Autograd of A6 with respect to the parameters (row A7):
  *   grad_weight[r] = agg[:, r, :]^T @ g,  grad_root = x^T @ g,  grad_bias = colsum(g)
@@ -149,10 +158,10 @@ int rgcn_transform_bwd_input(const float* gagg, const float* g, const float* wei
  * (deterministic; no float atomics).  grad_root / grad_bias may be NULL. */
 size_t rgcn_transform_bwd_params_workspace_bytes(int64_t num_nodes, int64_t num_relations,
                                                  int64_t d_in, int64_t d_out);
-int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, int64_t num_nodes,
-                              int64_t num_relations, int64_t d_in, int64_t d_out,
-                              float* grad_weight, float* grad_root, float* grad_bias,
-                              void* workspace, size_t workspace_bytes, void* stream);
+int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g,
+                              const uint32_t* tile_mask, int64_t num_nodes, int64_t num_relations,
+                              int64_t d_in, int64_t d_out, float* grad_weight, float* grad_root,
+                              float* grad_bias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DistMult head (rows C1 + C2; rgcn.py:325-326 row gathers + rgcn.py:207-211):

@@ -43,7 +43,7 @@ class _RGCNConvFunction(torch.autograd.Function):
         root_c = root.contiguous() if root is not None else None
         bias_c = bias.contiguous() if bias is not None else None
         agg = ops.aggregate(graph, x, transposed=False)                     # rows A3 + A4
-        out = ops.transform_fwd(agg, x, weight, root_c, bias_c, relu=relu)  # row A6 (+ fused ReLU)
+        out = ops.transform_fwd(agg, x, weight, root_c, bias_c, relu=relu, graph=graph)  # row A6 (+ fused ReLU)
         ctx.graph, ctx.relu = graph, relu
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
         ctx.save_for_backward(x, agg, weight, root_c, out if relu else None)
@@ -60,10 +60,10 @@ class _RGCNConvFunction(torch.autograd.Function):
         gx = gw = groot = gbias = None
         if need_w or (need_root and ctx.has_root) or (need_bias and ctx.has_bias):
             gw, groot, gbias = ops.transform_bwd_params(
-                agg, x, g, graph.num_relations, want_root=ctx.has_root, want_bias=ctx.has_bias)
+                agg, x, g, graph.num_relations, want_root=ctx.has_root, want_bias=ctx.has_bias, graph=graph)
         if need_x:
             gagg = ops.aggregate(graph, g, transposed=True)                 # autograd of A3 + A4
-            gx = ops.transform_bwd_input(gagg, g, weight, root)             # autograd of A6 wrt x
+            gx = ops.transform_bwd_input(gagg, g, weight, root, graph=graph)  # autograd of A6 wrt x
         return gx, gw, groot, gbias, None, None
 
 
@@ -77,9 +77,9 @@ class _Encoder2Function(torch.autograd.Function):
     def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph):
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
         agg1 = ops.aggregate(graph, x)
-        h = ops.transform_fwd(agg1, x, w1, root1, b1, relu=True)
+        h = ops.transform_fwd(agg1, x, w1, root1, b1, relu=True, graph=graph)
         agg2 = ops.aggregate(graph, h)
-        out = ops.transform_fwd(agg2, h, w2, root2, b2)
+        out = ops.transform_fwd(agg2, h, w2, root2, b2, graph=graph)
         ctx.graph = graph
         ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
         ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2)
@@ -91,14 +91,16 @@ class _Encoder2Function(torch.autograd.Function):
         graph, r = ctx.graph, ctx.graph.num_relations
         has_root1, has_b1, has_root2, has_b2 = ctx.flags
         g = g.contiguous()
-        gw2, groot2, gb2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2)
+        gw2, groot2, gb2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2,
+                                                    graph=graph)
         gagg2 = ops.aggregate(graph, g, transposed=True)
-        gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h)      # d loss / d (pre-ReLU of conv1)
-        gw1, groot1, gb1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1)
+        gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph)   # d loss / d (pre-ReLU of conv1)
+        gw1, groot1, gb1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1,
+                                                    graph=graph)
         gx = None
         if ctx.needs_input_grad[0]:
             gagg1 = ops.aggregate(graph, gz, transposed=True)
-            gx = ops.transform_bwd_input(gagg1, gz, w1, root1)
+            gx = ops.transform_bwd_input(gagg1, gz, w1, root1, graph=graph)
         return gx, gw1, groot1, gb1, gw2, groot2, gb2, None
 
 

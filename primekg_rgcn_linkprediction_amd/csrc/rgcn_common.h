@@ -39,6 +39,11 @@ struct rgcn_csr {
   rgcn_item* items[RGCN_MAX_LEVELS] = {};
   int64_t num_items[RGCN_MAX_LEVELS] = {};
   int64_t num_partials = 0;   // rows of partial-sum workspace (all levels)
+  // bit r of tile_mask[t]: some row of rows [32t, 32t+32) has a non-empty (row, r) segment.
+  // Typed relations leave whole row ranges without a relation (drug-gene edges never reach a
+  // disease row): the transforms skip the all-zero k/m-tiles these bits expose.  NULL if R > 32.
+  uint32_t* tile_mask = nullptr;
+  int64_t num_row_tiles = 0;
 };
 
 struct rgcn_graph {

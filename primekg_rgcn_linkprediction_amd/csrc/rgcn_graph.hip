@@ -140,6 +140,7 @@ void free_csr(rgcn_csr* c) {
   (void)hipFree(c->col);
   (void)hipFree(c->perm);
   (void)hipFree(c->val);
+  (void)hipFree(c->tile_mask);
   for (int l = 0; l < RGCN_MAX_LEVELS; ++l) (void)hipFree(c->items[l]);
   *c = rgcn_csr();
 }
@@ -215,6 +216,15 @@ int plan_structure(rgcn_csr* c, int64_t R, hipStream_t stream) {
   std::vector<int32_t> rp((size_t)NR + 1);
   RGCN_HIP_TRY(hipMemcpyAsync(rp.data(), c->rowptr, (NR + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   RGCN_HIP_TRY(hipStreamSynchronize(stream));
+  if (R <= 32 && c->n_key > 0) {          // relation occupancy per 32-row tile
+    c->num_row_tiles = ceil_div64(c->n_key, 32);
+    std::vector<uint32_t> mask((size_t)c->num_row_tiles, 0u);
+    for (int64_t i = 0; i < c->n_key; ++i)
+      for (int64_t r = 0; r < R; ++r)
+        if (rp[i * R + r + 1] > rp[i * R + r]) mask[(size_t)(i >> 5)] |= 1u << r;
+    RGCN_HIP_TRY(hipMalloc((void**)&c->tile_mask, mask.size() * sizeof(uint32_t)));
+    RGCN_HIP_TRY(hipMemcpy(c->tile_mask, mask.data(), mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   return build_plan(rp, NR, c);
 }
 
@@ -352,6 +362,13 @@ int64_t rgcn_graph_num_nodes(const rgcn_graph* g) { return g ? g->N : -1; }
 int64_t rgcn_graph_num_relations(const rgcn_graph* g) { return g ? g->R : -1; }
 int rgcn_graph_num_levels(const rgcn_graph* g, int transposed) {
   return g ? g->dir[transposed ? 1 : 0].num_levels : -1;
+}
+
+const uint32_t* rgcn_graph_tile_mask(const rgcn_graph* g, int transposed, int64_t* num_row_tiles) {
+  if (!g) return nullptr;
+  const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
+  if (num_row_tiles) *num_row_tiles = c->num_row_tiles;
+  return c->tile_mask;
 }
 
 int rgcn_graph_arrays(const rgcn_graph* g, int transposed, const int32_t** rowptr, const int32_t** col,

@@ -233,7 +233,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_dma(const float* __restric
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ mask,
                                                           float* __restrict__ C, int M, int N,
-                                                          const void* __restrict__ aux) {
+                                                          const void* __restrict__ aux,
+                                                          const uint32_t* __restrict__ tile_mask, int kseg) {
   constexpr int BM = 64, BN = 64 * TN, NBUF = 3;
   constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK, BUF_FLOATS = A_FLOATS + B_FLOATS;
   constexpr int A_PW = BM / 32;                 // A wave-instructions per wave and k-tile (8 rows each)
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_dma(const float* __restric
   constexpr int P = A_PW + B_PW;                // LDS-DMA instructions per thread and k-tile
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF_FLOATS];   // the ONLY LDS object
 
-  const int K = K1 + K2, nkt = K / BK;
+  const int K = K1 + K2;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -304,8 +305,23 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_dma(const float* __restric
     }
   };
 
-  stage(0, 0);
-  if (nkt > 1) stage(BK, 1);
+  // Relation occupancy of this workgroup's 64 rows (two 32-row tiles of the bucketed structure
+  // the A1 operand came from): k-tiles of a relation none of these rows has are exact zeros in
+  // A1 and are skipped, DMA and MFMAs alike.  The k-tiles of A2 (root / self term) always run.
+  unsigned rel_mask = 0xffffffffu;
+  if (tile_mask) {
+    const int t32 = m0 >> 5;
+    rel_mask = tile_mask[t32] | ((t32 + 1) * 32 < M ? tile_mask[t32 + 1] : 0u);
+    rel_mask = __builtin_amdgcn_readfirstlane(rel_mask);
+  }
+  auto next_kt = [&](int kt) {                 // next active k-tile start after kt (K when none)
+    kt += BK;
+    while (kt < K1 && !((rel_mask >> (kt / kseg)) & 1u)) kt = (kt / kseg + 1) * kseg;
+    return min(kt, K);
+  };
+  int kt_a = next_kt(-BK), kt_b = next_kt(kt_a), kt_c = K;
+  if (kt_a < K) stage(kt_a, 0);
+  if (kt_b < K) stage(kt_b, 1);
 
   // Fragment reads are inline asm: hipcc cannot tell a ds_read from the in-flight LDS-DMA
   // destinations apart and would drain vmcnt(0) before the first read of every k-tile.
@@ -348,13 +364,16 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_dma(const float* __restric
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[set]), "+v"(fb[set][0]));
   };
 
-  for (int t = 0; t < nkt; ++t) {
-    // k-tile t landed for this wave (all but the newest P DMAs are done), then for all waves;
-    // the barrier also says every wave is done reading the buffer k-tile t+2 will overwrite
-    if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+  for (int t = 0; kt_a < K; ++t) {
+    // k-tile kt_a landed for this wave (all but the newest P DMAs are done), then for all waves;
+    // the barrier also says every wave is done reading the buffer the next stage() overwrites
+    if (kt_b < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < nkt) stage((t + 2) * BK, (t + 2) % NBUF);
+    kt_c = kt_b < K ? next_kt(kt_b) : K;
+    if (kt_c < K) stage(kt_c, (t + 2) % NBUF);
+    kt_a = kt_b;
+    kt_b = kt_c;
     const unsigned buf_bytes = (unsigned)((t % NBUF) * BUF_FLOATS) * 4u;
     read_frags(0, 0, buf_bytes);
 #pragma unroll
@@ -530,7 +549,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
                                                           const float* __restrict__ G, int M, int N,
                                                           int n_tiles, int rows_per_split,
                                                           float* __restrict__ slab,
-                                                          float* __restrict__ bias_part) {
+                                                          float* __restrict__ bias_part,
+                                                          const uint32_t* __restrict__ tile_mask, int kseg) {
   constexpr int TKC = 64, NBUF = 3, A_FLOATS = 32 * TKC, G_FLOATS = 32 * 128, BUF_FLOATS = A_FLOATS + G_FLOATS;
   constexpr int A_PW = 2, G_PW = 4, P = A_PW + G_PW;            // LDS-DMA instructions per wave and m-tile
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF_FLOATS];   // the ONLY LDS object
@@ -539,12 +559,22 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
   const int split = blockIdx.y;
   const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
-  const int nmt = (mend - mbeg + 31) / 32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const bool do_bias = (bias_part != nullptr) && (kc0 == 0) && (tid < 128);
+  // column sums of G ride with the first kc tile of the always-dense A2 (root) part, or with
+  // kc tile 0 when there is no A2; that workgroup must see every row
+  const bool bias_block = (bias_part != nullptr) && (kc0 == (K2 > 0 ? K1 : 0));
+  const bool do_bias = bias_block && (tid < 128);
+  // 32-row m-tiles in which no row has this kc tile's relation are exact zeros in A1: skipped
+  const bool sparse = tile_mask != nullptr && kc0 < K1 && !bias_block;
+  const int rel = sparse ? kc0 / kseg : 0;
+  auto next_mt = [&](int mt) {
+    mt += 32;
+    while (sparse && mt < mend && !((tile_mask[mt >> 5] >> rel) & 1u)) mt += 32;
+    return min(mt, mend + 31);
+  };
 
   floatx16 acc[2];
 #pragma unroll
@@ -579,8 +609,9 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
     }
   };
 
-  if (nmt > 0) stage(mbeg, 0);
-  if (nmt > 1) stage(mbeg + 32, 1);
+  int mt_a = next_mt(mbeg - 32), mt_b = mt_a < mend ? next_mt(mt_a) : mend, mt_c = mend;
+  if (mt_a < mend) stage(mt_a, 0);
+  if (mt_b < mend) stage(mt_b, 1);
   const unsigned a_addr = (unsigned)(lh * TKC + wk * 32 + li) * 4u;
   const unsigned g_addr = (unsigned)(A_FLOATS + lh * 128 + wn * 64 + li) * 4u;
   float fa[2][4], fg[2][4][2];
@@ -607,9 +638,9 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
                    "+v"(fg[set][2][1]), "+v"(fg[set][3][0]), "+v"(fg[set][3][1]));
   };
 
-  for (int t = 0; t < nmt; ++t) {
-    const int mt = mbeg + t * 32;
-    if (t + 1 < nmt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+  for (int t = 0; mt_a < mend; ++t) {
+    const int mt = mt_a;
+    if (mt_b < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     float* sA = lds + (t % NBUF) * BUF_FLOATS;
@@ -622,7 +653,10 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
-    if (t + 2 < nmt) stage(mt + 64, (t + 2) % NBUF);
+    mt_c = mt_b < mend ? next_mt(mt_b) : mend;
+    if (mt_c < mend) stage(mt_c, (t + 2) % NBUF);
+    mt_a = mt_b;
+    mt_b = mt_c;
     if (do_bias) {
       float v[32];
 #pragma unroll
@@ -759,18 +793,30 @@ bool force_plain_gemm() {             // RGCN_GEMM=plain: register-staged kernel
   return v;
 }
 
+bool use_tile_masks() {               // RGCN_TILE_MASK=0 disables the relation-occupancy skipping (A/B runs)
+  static const bool v = [] {
+    const char* e = getenv("RGCN_TILE_MASK");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
 template <int BMODE, int EPI>
 void launch_nt(const float* A1, int K1, const float* A2, int K2, const float* W, const float* Rt, int dk,
-               const float* bias, const float* mask, float* C, int M, int N, hipStream_t stream) {
+               const float* bias, const float* mask, float* C, int M, int N, const uint32_t* tile_mask, int kseg,
+               hipStream_t stream) {
   const bool dma_ok = (K1 % BK == 0) && (K2 % BK == 0) && (K1 + K2 > 0) && (BMODE == B_KN || dk % BK == 0) &&
                       !force_plain_gemm();
   if (dma_ok) {
+    if (!use_tile_masks() || kseg <= 0 || kseg % BK != 0) tile_mask = nullptr;
     if (N <= 64) {
       dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
-      k_gemm_nt_dma<1, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N, nullptr);
+      k_gemm_nt_dma<1, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N,
+                                                                  nullptr, tile_mask, kseg);
     } else {
       dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 128));
-      k_gemm_nt_dma<2, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N, nullptr);
+      k_gemm_nt_dma<2, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N,
+                                                                  nullptr, tile_mask, kseg);
     }
     return;
   }
@@ -792,8 +838,8 @@ bool bad_dims(int64_t n, int64_t r, int64_t di, int64_t dout) {
 extern "C" {
 
 int rgcn_transform_fwd(const float* agg, const float* x, const float* weight, const float* root,
-                       const float* bias, int relu, int64_t N, int64_t R, int64_t d_in, int64_t d_out,
-                       float* out, void* stream_) {
+                       const float* bias, int relu, const uint32_t* tile_mask, int64_t N, int64_t R,
+                       int64_t d_in, int64_t d_out, float* out, void* stream_) {
   if (bad_dims(N, R, d_in, d_out) || !out) return RGCN_ERR_ARG;
   if (N == 0) return RGCN_OK;
   if (!agg || !x || !weight) return RGCN_ERR_ARG;
@@ -801,16 +847,18 @@ int rgcn_transform_fwd(const float* agg, const float* x, const float* weight, co
   hipStream_t stream = (hipStream_t)stream_;
   const int K1 = (int)(R * d_in), K2 = root ? (int)d_in : 0;
   if (relu)
-    launch_nt<B_KN, EPI_RELU>(agg, K1, x, K2, weight, root, 0, bias, nullptr, out, (int)N, (int)d_out, stream);
+    launch_nt<B_KN, EPI_RELU>(agg, K1, x, K2, weight, root, 0, bias, nullptr, out, (int)N, (int)d_out, tile_mask,
+                              (int)d_in, stream);
   else
-    launch_nt<B_KN, EPI_NONE>(agg, K1, x, K2, weight, root, 0, bias, nullptr, out, (int)N, (int)d_out, stream);
+    launch_nt<B_KN, EPI_NONE>(agg, K1, x, K2, weight, root, 0, bias, nullptr, out, (int)N, (int)d_out, tile_mask,
+                              (int)d_in, stream);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
 
 int rgcn_transform_bwd_input(const float* gagg, const float* g, const float* weight, const float* root,
-                             const float* relu_mask, int64_t N, int64_t R, int64_t d_in, int64_t d_out,
-                             float* grad_x, void* stream_) {
+                             const float* relu_mask, const uint32_t* tile_mask, int64_t N, int64_t R,
+                             int64_t d_in, int64_t d_out, float* grad_x, void* stream_) {
   if (bad_dims(N, R, d_in, d_out) || !grad_x) return RGCN_ERR_ARG;
   if (N == 0) return RGCN_OK;
   if (!gagg || !g || !weight) return RGCN_ERR_ARG;
@@ -819,10 +867,10 @@ int rgcn_transform_bwd_input(const float* gagg, const float* g, const float* wei
   const int K1 = (int)(R * d_out), K2 = root ? (int)d_out : 0;
   if (relu_mask)
     launch_nt<B_BLK, EPI_MASK>(gagg, K1, g, K2, weight, root, (int)d_out, nullptr, relu_mask, grad_x, (int)N,
-                               (int)d_in, stream);
+                               (int)d_in, tile_mask, (int)d_out, stream);
   else
     launch_nt<B_BLK, EPI_NONE>(gagg, K1, g, K2, weight, root, (int)d_out, nullptr, nullptr, grad_x, (int)N,
-                               (int)d_in, stream);
+                               (int)d_in, tile_mask, (int)d_out, stream);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -838,7 +886,7 @@ int distmult_rank_tails(const float* hr, const float* emb, const float* true_sco
   dim3 grid((unsigned)ceil_div64(batch, 64), (unsigned)ceil_div64(num_entities, 128));
   k_gemm_nt_dma<2, B_BLK, EPI_RANK><<<grid, kThreads, 0, stream>>>(hr, (int)d, hr, 0, emb, emb, (int)d, true_score,
                                                                     nullptr, reinterpret_cast<float*>(beaten_by),
-                                                                    (int)batch, (int)num_entities, tail);
+                                                                    (int)batch, (int)num_entities, tail, nullptr, 0);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -850,9 +898,10 @@ size_t rgcn_transform_bwd_params_workspace_bytes(int64_t N, int64_t R, int64_t d
   return ((size_t)p.splits * Kc * d_out + (size_t)p.splits * d_out) * sizeof(float);
 }
 
-int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, int64_t N, int64_t R,
-                              int64_t d_in, int64_t d_out, float* grad_weight, float* grad_root,
-                              float* grad_bias, void* workspace, size_t workspace_bytes, void* stream_) {
+int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, const uint32_t* tile_mask,
+                              int64_t N, int64_t R, int64_t d_in, int64_t d_out, float* grad_weight,
+                              float* grad_root, float* grad_bias, void* workspace, size_t workspace_bytes,
+                              void* stream_) {
   if (bad_dims(N, R, d_in, d_out) || !grad_weight) return RGCN_ERR_ARG;
   if (N > 0 && (!agg || !x || !g)) return RGCN_ERR_ARG;
   if (N > INT32_MAX / 2 || (R + 1) * d_in > (1 << 24) || d_out > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
@@ -874,7 +923,9 @@ int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, 
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
   if (K1 % 64 == 0 && K2 % 64 == 0 && !force_plain_gemm())
     k_gemm_tn_dma<<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                 p.rows_per_split, slab, grad_bias ? bias_part : nullptr);
+                                                 p.rows_per_split, slab, grad_bias ? bias_part : nullptr,
+                                                 (use_tile_masks() && d_in % 64 == 0) ? tile_mask : nullptr,
+                                                 (int)d_in);
   else
     k_gemm_tn_slab<1><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
                                                      p.rows_per_split, slab, grad_bias ? bias_part : nullptr);

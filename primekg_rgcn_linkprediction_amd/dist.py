@@ -56,14 +56,16 @@ class HipBackend:
     def aggregate(self, shard, x):
         return self.ops.aggregate(shard, x)
 
-    def transform_fwd(self, agg, x, weight, root, bias, relu=False):
-        return self.ops.transform_fwd(agg, x, weight, root, bias, relu)
+    # `shard` = the structure the aggregate operand was built over (its relation-occupancy mask
+    # lets the kernels skip all-zero tiles); backends without that notion ignore it
+    def transform_fwd(self, agg, x, weight, root, bias, relu=False, shard=None):
+        return self.ops.transform_fwd(agg, x, weight, root, bias, relu, shard)
 
-    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None):
-        return self.ops.transform_bwd_input(gagg, g, weight, root, relu_mask)
+    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None, shard=None):
+        return self.ops.transform_bwd_input(gagg, g, weight, root, relu_mask, shard)
 
-    def transform_bwd_params(self, agg, x, g, num_relations, want_root, want_bias):
-        return self.ops.transform_bwd_params(agg, x, g, num_relations, want_root, want_bias)
+    def transform_bwd_params(self, agg, x, g, num_relations, want_root, want_bias, shard=None):
+        return self.ops.transform_bwd_params(agg, x, g, num_relations, want_root, want_bias, shard)
 
 
 class NodePartition:
@@ -190,9 +192,9 @@ class _PartitionedEncoder2Function(torch.autograd.Function):
         world = shard.part.world
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
         agg1 = backend.aggregate(shard.g_in, _Gather(x, world, group).result())
-        h = backend.transform_fwd(agg1, x, w1, root1, b1, True)
+        h = backend.transform_fwd(agg1, x, w1, root1, b1, True, shard.g_in)
         agg2 = backend.aggregate(shard.g_in, _Gather(h, world, group).result())
-        out = backend.transform_fwd(agg2, h, w2, root2, b2, False)
+        out = backend.transform_fwd(agg2, h, w2, root2, b2, False, shard.g_in)
         ctx.shard, ctx.backend, ctx.group = shard, backend, group
         ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
         ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2)
@@ -206,15 +208,15 @@ class _PartitionedEncoder2Function(torch.autograd.Function):
         has_root1, has_b1, has_root2, has_b2 = ctx.flags
         g = g.contiguous()
         g_all = _Gather(g, world, group)                                   # exchange in flight ...
-        red2 = _flat_all_reduce(backend.transform_bwd_params(agg2, h, g, r, has_root2, has_b2), group)
+        red2 = _flat_all_reduce(backend.transform_bwd_params(agg2, h, g, r, has_root2, has_b2, shard.g_in), group)
         gagg2 = backend.aggregate(shard.g_out, g_all.result())             # ... behind the GEMM above
-        gz = backend.transform_bwd_input(gagg2, g, w2, root2, h)           # ReLU backward in the epilogue
+        gz = backend.transform_bwd_input(gagg2, g, w2, root2, h, shard.g_out)   # ReLU backward in the epilogue
         gz_all = _Gather(gz, world, group)
-        red1 = _flat_all_reduce(backend.transform_bwd_params(agg1, x, gz, r, has_root1, has_b1), group)
+        red1 = _flat_all_reduce(backend.transform_bwd_params(agg1, x, gz, r, has_root1, has_b1, shard.g_in), group)
         gx = None
         if ctx.needs_input_grad[0]:
             gagg1 = backend.aggregate(shard.g_out, gz_all.result())
-            gx = backend.transform_bwd_input(gagg1, gz, w1, root1, None)
+            gx = backend.transform_bwd_input(gagg1, gz, w1, root1, None, shard.g_out)
         else:
             gz_all.result()
         red2[0].wait()
@@ -231,7 +233,7 @@ class _PartitionedConvFunction(torch.autograd.Function):
         weight = weight.contiguous()
         x_all = _all_gather_rows(x_own, shard.part.world, group)           # the layer's one exchange
         agg = backend.aggregate(shard.g_in, x_all)
-        out = backend.transform_fwd(agg, x_own, weight, root, bias, relu)
+        out = backend.transform_fwd(agg, x_own, weight, root, bias, relu, shard.g_in)
         ctx.shard, ctx.backend, ctx.group, ctx.relu = shard, backend, group, relu
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
         ctx.save_for_backward(x_own, agg, weight, root, out if relu else None)
@@ -246,7 +248,7 @@ class _PartitionedConvFunction(torch.autograd.Function):
         g_own = g_own.contiguous()
         need_x = ctx.needs_input_grad[0]
         gw, groot, gbias = backend.transform_bwd_params(agg, x_own, g_own, shard.num_relations,
-                                                        ctx.has_root, ctx.has_bias)
+                                                        ctx.has_root, ctx.has_bias, shard.g_in)
         parts = [t for t in (gw, groot, gbias) if t is not None]
         flat = torch.cat([t.reshape(-1) for t in parts])
         work = dist.all_reduce(flat, group=group, async_op=True)            # overlaps the gather below
@@ -254,7 +256,7 @@ class _PartitionedConvFunction(torch.autograd.Function):
         if need_x:
             g_all = _all_gather_rows(g_own, shard.part.world, group)
             gagg = backend.aggregate(shard.g_out, g_all)
-            gx = backend.transform_bwd_input(gagg, g_own, weight, root, None)
+            gx = backend.transform_bwd_input(gagg, g_own, weight, root, None, shard.g_out)
         work.wait()
         outs, off = [], 0
         for t in parts:

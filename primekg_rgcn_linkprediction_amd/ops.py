@@ -72,6 +72,7 @@ class BucketedGraph:
         self.num_nodes, self.num_relations = int(num_nodes), int(num_relations)
         self.num_other_nodes = self.num_nodes      # rows of the gathered input
         self.bipartite = False
+        self.weighted_shard = False
         self.num_edges = int(edge_index.size(1))
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -104,6 +105,7 @@ class BucketedGraph:
         self.num_nodes, self.num_relations = int(num_key_nodes), int(num_relations)
         self.num_other_nodes = int(num_other_nodes)
         self.bipartite = True
+        self.weighted_shard = edge_weight is not None
         self.num_edges = int(key_node.size(0))
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -120,6 +122,13 @@ class BucketedGraph:
         if self._handle is None:
             raise RuntimeError("BucketedGraph was destroyed")
         return self._handle
+
+    def tile_mask_ptr(self, transposed: bool) -> Optional[int]:
+        """device pointer (as int) of the relation-occupancy mask of 32-row tiles, or None"""
+        if self.bipartite and transposed:
+            raise ValueError("a shard structure has one direction only (transposed=False)")
+        ptr = _lib.load().rgcn_graph_tile_mask(self.handle, int(transposed), None)
+        return ptr or None
 
     def num_levels(self, transposed: bool) -> int:
         return _lib.load().rgcn_graph_num_levels(self.handle, int(transposed))
@@ -183,7 +192,7 @@ def clear_graph_cache() -> None:
 # ----------------------------------------------------------------------------------
 # aggregate (rows A3 + A4 / their autograd)
 # ----------------------------------------------------------------------------------
-# bench.py sets this to a list to collect (transposed, d, start_event, end_event) per
+# bench.py sets this to a list to collect (weighted, d, edges, segments, start_event, end_event) per
 # level-0 gather launch; None (the default) means one C call per aggregate, no events.
 GATHER_EVENTS = None
 
@@ -223,7 +232,8 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False) -
                                                     _ptr(out), _ptr(ws), nbytes, _stream())
                 if level == 0:
                     end.record()
-                    GATHER_EVENTS.append((bool(transposed), d, beg, end))
+                    weighted = bool(transposed) or (graph.bipartite and graph.weighted_shard)
+                    GATHER_EVENTS.append((weighted, d, graph.num_edges, graph.num_nodes * graph.num_relations, beg, end))
     _lib.check(rc, "rgcn_aggregate")
     return out
 
@@ -256,20 +266,33 @@ def _check_layer(agg, x, weight, root, bias):
     return n, r, d_in, d_out
 
 
-def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False) -> torch.Tensor:
+def _mask_for(graph: Optional[BucketedGraph], transposed: bool, n: int, r: int) -> Optional[int]:
+    """relation-occupancy mask of the structure the aggregate came from (None = dense)"""
+    if graph is None:
+        return None
+    if graph.num_nodes != n or graph.num_relations != r:
+        raise ValueError("graph does not match the operand shapes")
+    return graph.tile_mask_ptr(transposed and not graph.bipartite)
+
+
+def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
+                  graph: Optional[BucketedGraph] = None) -> torch.Tensor:
     """``sum_r agg[:, r] @ weight[r] + x @ root + bias`` as one fp32-MFMA GEMM; ``relu``
-    fuses the activation that follows conv1 (``rgcn.py:124``) into the epilogue."""
+    fuses the activation that follows conv1 (``rgcn.py:124``) into the epilogue.  ``graph``
+    (the structure ``agg`` was aggregated over) lets the kernel skip the k-tiles of relations
+    that a whole 64-row tile does not have - exact zeros in ``agg``."""
     n, r, d_in, d_out = _check_layer(agg, x, weight, root, bias)
     lib = _lib.load()
     with torch.cuda.device(x.device):
         out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
-        rc = lib.rgcn_transform_fwd(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu), n, r,
-                                    d_in, d_out, _ptr(out), _stream())
+        rc = lib.rgcn_transform_fwd(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu),
+                                    _mask_for(graph, False, n, r), n, r, d_in, d_out, _ptr(out), _stream())
     _lib.check(rc, "rgcn_transform_fwd")
     return out
 
 
-def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None) -> torch.Tensor:
+def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
+                        graph: Optional[BucketedGraph] = None) -> torch.Tensor:
     """``grad_x = sum_r gagg[:, r] @ weight[r]^T + g @ root^T``; with ``relu_mask`` (the
     layer's input, when that input is the output of a fused-ReLU layer) the result is
     additionally multiplied by ``relu_mask > 0``."""
@@ -289,13 +312,14 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None) -> torch.Ten
     lib = _lib.load()
     with torch.cuda.device(g.device):
         gx = torch.empty(n, d_in, dtype=torch.float32, device=g.device)
-        rc = lib.rgcn_transform_bwd_input(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root), _ptr(relu_mask), n, r,
-                                          d_in, d_out, _ptr(gx), _stream())
+        rc = lib.rgcn_transform_bwd_input(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root), _ptr(relu_mask),
+                                          _mask_for(graph, True, n, r), n, r, d_in, d_out, _ptr(gx), _stream())
     _lib.check(rc, "rgcn_transform_bwd_input")
     return gx
 
 
-def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, want_bias: bool = True):
+def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, want_bias: bool = True,
+                         graph: Optional[BucketedGraph] = None):
     """``(grad_weight[R, d_in, d_out], grad_root | None, grad_bias | None)``."""
     _need_gpu("x", x, torch.float32)
     _need_gpu("agg", agg, torch.float32)
@@ -312,7 +336,8 @@ def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, 
         gbias = torch.empty(d_out, dtype=torch.float32, device=x.device) if want_bias else None
         nbytes = lib.rgcn_transform_bwd_params_workspace_bytes(n, r, d_in, d_out)
         ws = _workspace(nbytes, x.device)
-        rc = lib.rgcn_transform_bwd_params(_ptr(agg), _ptr(x), _ptr(g), n, r, d_in, d_out, _ptr(gw),
+        rc = lib.rgcn_transform_bwd_params(_ptr(agg), _ptr(x), _ptr(g), _mask_for(graph, False, n, r), n, r, d_in,
+                                           d_out, _ptr(gw),
                                            _ptr(groot), _ptr(gbias), _ptr(ws), nbytes, _stream())
     _lib.check(rc, "rgcn_transform_bwd_params")
     return gw, groot, gbias

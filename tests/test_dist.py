@@ -38,20 +38,20 @@ class OracleBackend:
             out = out / cnt.view(-1, 1)
         return out.view(s["n_key"], -1)
 
-    def transform_fwd(self, agg, x, weight, root, bias, relu=False):
+    def transform_fwd(self, agg, x, weight, root, bias, relu=False, shard=None):
         out = agg @ weight.reshape(-1, weight.size(2))
         if root is not None:
             out = out + x @ root
         out = out + bias if bias is not None else out
         return torch.relu(out) if relu else out
 
-    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None):
+    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None, shard=None):
         r, d_in, d_out = weight.shape
         gx = sum(gagg[:, k * d_out:(k + 1) * d_out] @ weight[k].t() for k in range(r))
         gx = gx + g @ root.t() if root is not None else gx
         return gx * (relu_mask > 0) if relu_mask is not None else gx
 
-    def transform_bwd_params(self, agg, x, g, num_relations, want_root, want_bias):
+    def transform_bwd_params(self, agg, x, g, num_relations, want_root, want_bias, shard=None):
         gw = (agg.t() @ g).view(num_relations, x.size(1), g.size(1))
         return gw, (x.t() @ g if want_root else None), (g.sum(0) if want_bias else None)
 

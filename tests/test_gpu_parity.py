@@ -476,3 +476,39 @@ def test_config_c4_scale_on_one_gpu():
     seg = col_t.long() * r + etd[g.arrays(True)[2]]
     tot = torch.zeros(n * r, device=dev, dtype=torch.float64).index_add_(0, seg, w_t.double())
     assert torch.allclose(tot, (deg > 0).double(), atol=1e-6)
+
+
+@pytest.mark.parametrize("d_in,d_out", [(64, 128), (128, 128), (128, 64)])
+def test_relation_occupancy_masks_change_nothing(d_in, d_out):
+    """Typed relations leave whole 32-row tiles without a relation; with the structure's
+    occupancy mask the transforms skip those all-zero tiles.  Results must equal the dense
+    kernels bit for bit, and the masks must be exactly the occupancy of the bucketed graph."""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=120000, seed=3)
+    g = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
+    for transposed in (False, True):
+        rowptr = g.arrays(transposed)[0].cpu().long()
+        deg = (rowptr[1:] - rowptr[:-1]).view(n, r)
+        occ = torch.nn.functional.pad(deg > 0, (0, 0, 0, (-n) % 32)).view(-1, 32, r).any(1)     # [tiles, r]
+        assert g.tile_mask_ptr(transposed) is not None
+        assert not bool(occ.all())                      # the typed graph does have empty (tile, relation) pairs
+    gen = torch.Generator().manual_seed(d_in)
+    x = torch.randn(n, d_in, generator=gen).to(dev)
+    gr = torch.randn(n, d_out, generator=gen).to(dev)
+    w = (torch.randn(r, d_in, d_out, generator=gen) * 0.1).to(dev)
+    root = (torch.randn(d_in, d_out, generator=gen) * 0.1).to(dev)
+    bias = torch.randn(d_out, generator=gen).to(dev)
+    agg = ops.aggregate(g, x)
+    gagg = ops.aggregate(g, gr, transposed=True)
+    assert torch.equal(ops.transform_fwd(agg, x, w, root, bias, graph=g), ops.transform_fwd(agg, x, w, root, bias))
+    assert torch.equal(ops.transform_fwd(agg, x, w, None, bias, relu=True, graph=g),
+                       ops.transform_fwd(agg, x, w, None, bias, relu=True))
+    assert torch.equal(ops.transform_bwd_input(gagg, gr, w, root, graph=g), ops.transform_bwd_input(gagg, gr, w, root))
+    a = ops.transform_bwd_params(agg, x, gr, r, graph=g)
+    b = ops.transform_bwd_params(agg, x, gr, r)
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    a = ops.transform_bwd_params(agg, x, gr, r, want_root=False, graph=g)
+    b = ops.transform_bwd_params(agg, x, gr, r, want_root=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    # a tile really is skipped somewhere: disease rows [0, 5593) have no relation 0 or 2
+    assert float(agg[:5568].view(-1, r, d_in)[:, 0].abs().max()) == 0.0
