@@ -120,12 +120,19 @@ def main():
 
     from primekg_rgcn_linkprediction_amd import RGCNConv, _lib, ops, rgcn_encoder2, synth
     _lib.load()                                           # fail loudly if the HIP library is missing
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  (Rehearsal on a 1-GPU box: RGCN_BENCH_BACKEND=gloo lets several ranks
+    # share cuda:0 with host-staged exchanges - RCCL refuses two ranks on one device.)
+    backend = os.environ.get("RGCN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     ei, et, n, r = synth.primekg_like(num_edges=args.edges or synth.PRIMEKG_EDGES, seed=42)
     num_edges = ei.size(1)
@@ -260,7 +267,8 @@ def main():
                             "total_us_per_step": sum(ts) / event_steps * 1e6})
         dom = max(kernels, key=lambda k: k["total_us_per_step"])
         result["roofline"] = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": dom["gbs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(dom["kernel"]),
+                              "frac": dom["gbs"] / HBM_PEAK_GBS,
+                              "traffic": pmc_traffic(dom["kernel"]) if world == 1 else None,
                               "kernel": dom["kernel"],
                               "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"]}
         result["gather_kernels"] = kernels
