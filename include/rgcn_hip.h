@@ -122,6 +122,11 @@ int rgcn_graph_export(const rgcn_graph* g, int transposed, int32_t* rowptr, int3
 size_t rgcn_aggregate_workspace_bytes(const rgcn_graph* g, int transposed, int64_t d);
 int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the gathered table stored as IEEE fp16 (x_f16: half[N, d], d % 8 == 0) and fp32
+ * accumulation / output: half the bytes per gathered row (BASELINE.json configs[4], "fp16
+ * features + fp32 accumulate").  agg and the workspace stay fp32. */
+int rgcn_aggregate_f16(const rgcn_graph* g, int transposed, const void* x_f16, int64_t d, float* agg,
+                       void* workspace, size_t workspace_bytes, void* stream);
 /* One launch of the above (level in [0, rgcn_graph_num_levels)); calling the levels in order
  * equals rgcn_aggregate.  Lets a profiler bracket the level-0 gather kernel by itself. */
 int rgcn_aggregate_level(const rgcn_graph* g, int transposed, int level, const float* x, int64_t d,

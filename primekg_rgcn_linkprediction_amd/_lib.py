@@ -43,6 +43,7 @@ PROTOTYPES = {
     "rgcn_graph_export": (c_int, [c_void_p, c_int, _P, _P, _P, _P, _P]),
     "rgcn_aggregate_workspace_bytes": (c_size_t, [c_void_p, c_int, _I64]),
     "rgcn_aggregate": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, _P]),
+    "rgcn_aggregate_f16": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, _P]),
     "rgcn_aggregate_level": (c_int, [c_void_p, c_int, c_int, _P, _I64, _P, _P, c_size_t, _P]),
     "rgcn_graph_tile_mask": (c_void_p, [c_void_p, c_int, POINTER(c_int64)]),
     "rgcn_transform_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _I64, _I64, _I64, _I64, _P, _P]),

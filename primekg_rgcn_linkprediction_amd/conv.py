@@ -32,17 +32,23 @@ def _glorot(t: Optional[Tensor]) -> None:
         t.data.uniform_(-bound, bound)
 
 
+def _table(x: Tensor, gather_dtype) -> Tensor:
+    """the row table the gather reads: x itself, or its fp16 copy (configs[4])"""
+    return x if gather_dtype in (None, torch.float32) else x.to(gather_dtype)
+
+
 class _RGCNConvFunction(torch.autograd.Function):
     """x, weight[R, d_in, d_out], root, bias -> out (optionally relu(out)), on a bucketed graph."""
 
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
-                graph: ops.BucketedGraph, relu: bool = False) -> Tensor:
+                graph: ops.BucketedGraph, relu: bool = False, gather_dtype=None) -> Tensor:
         x = x.contiguous()
         weight = weight.contiguous()
         root_c = root.contiguous() if root is not None else None
         bias_c = bias.contiguous() if bias is not None else None
-        agg = ops.aggregate(graph, x, transposed=False)                     # rows A3 + A4
+        ctx.gather_dtype = gather_dtype
+        agg = ops.aggregate(graph, _table(x, gather_dtype), transposed=False)   # rows A3 + A4
         out = ops.transform_fwd(agg, x, weight, root_c, bias_c, relu=relu, graph=graph)  # row A6 (+ fused ReLU)
         ctx.graph, ctx.relu = graph, relu
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
@@ -62,9 +68,9 @@ class _RGCNConvFunction(torch.autograd.Function):
             gw, groot, gbias = ops.transform_bwd_params(
                 agg, x, g, graph.num_relations, want_root=ctx.has_root, want_bias=ctx.has_bias, graph=graph)
         if need_x:
-            gagg = ops.aggregate(graph, g, transposed=True)                 # autograd of A3 + A4
+            gagg = ops.aggregate(graph, _table(g, ctx.gather_dtype), transposed=True)   # autograd of A3 + A4
             gx = ops.transform_bwd_input(gagg, g, weight, root, graph=graph)  # autograd of A6 wrt x
-        return gx, gw, groot, gbias, None, None
+        return gx, gw, groot, gbias, None, None, None
 
 
 class _Encoder2Function(torch.autograd.Function):
@@ -74,11 +80,12 @@ class _Encoder2Function(torch.autograd.Function):
     conv1's pre-activation directly), so no elementwise kernel runs between the layers."""
 
     @staticmethod
-    def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph):
+    def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph, gather_dtype=None):
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
-        agg1 = ops.aggregate(graph, x)
+        ctx.gather_dtype = gather_dtype
+        agg1 = ops.aggregate(graph, _table(x, gather_dtype))
         h = ops.transform_fwd(agg1, x, w1, root1, b1, relu=True, graph=graph)
-        agg2 = ops.aggregate(graph, h)
+        agg2 = ops.aggregate(graph, _table(h, gather_dtype))
         out = ops.transform_fwd(agg2, h, w2, root2, b2, graph=graph)
         ctx.graph = graph
         ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
@@ -93,15 +100,15 @@ class _Encoder2Function(torch.autograd.Function):
         g = g.contiguous()
         gw2, groot2, gb2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2,
                                                     graph=graph)
-        gagg2 = ops.aggregate(graph, g, transposed=True)
+        gagg2 = ops.aggregate(graph, _table(g, ctx.gather_dtype), transposed=True)
         gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph)   # d loss / d (pre-ReLU of conv1)
         gw1, groot1, gb1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1,
                                                     graph=graph)
         gx = None
         if ctx.needs_input_grad[0]:
-            gagg1 = ops.aggregate(graph, gz, transposed=True)
+            gagg1 = ops.aggregate(graph, _table(gz, ctx.gather_dtype), transposed=True)
             gx = ops.transform_bwd_input(gagg1, gz, w1, root1, graph=graph)
-        return gx, gw1, groot1, gb1, gw2, groot2, gb2, None
+        return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None
 
 
 def _check_x(x: Tensor) -> None:
@@ -110,16 +117,23 @@ def _check_x(x: Tensor) -> None:
                         f"PyG's RGCNConv is not used by the reference and not implemented")
 
 
+def _check_gather_dtype(gather_dtype) -> None:
+    if gather_dtype not in (None, torch.float32, torch.float16):
+        raise ValueError(f"gather_dtype must be None, torch.float32 or torch.float16, got {gather_dtype}")
+
+
 def rgcn_conv(x: Tensor, edge_index: Tensor, edge_type: Tensor, weight: Tensor,
               root: Optional[Tensor], bias: Optional[Tensor], num_relations: int,
-              activation: Optional[str] = None) -> Tensor:
+              activation: Optional[str] = None, gather_dtype=None) -> Tensor:
     """Functional form on effective weights ``[R, d_in, d_out]``; ``activation='relu'`` fuses
-    the ReLU into the layer."""
+    the ReLU into the layer; ``gather_dtype=torch.float16`` gathers from an fp16 copy of the row
+    table (fp32 accumulate; BASELINE configs[4])."""
     _check_x(x)
+    _check_gather_dtype(gather_dtype)
     if activation not in (None, "relu"):
         raise ValueError(f"activation must be None or 'relu', got {activation!r}")
     graph = ops.bucket(edge_index, edge_type, x.size(0), num_relations)
-    return _RGCNConvFunction.apply(x, weight, root, bias, graph, activation == "relu")
+    return _RGCNConvFunction.apply(x, weight, root, bias, graph, activation == "relu", gather_dtype)
 
 
 def rgcn_encoder2(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: "RGCNConv",
@@ -128,7 +142,8 @@ def rgcn_encoder2(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: "RGCN
     _check_x(x)
     graph = ops.bucket(edge_index, edge_type, x.size(0), conv1.num_relations)
     return _Encoder2Function.apply(x, conv1.effective_weight(), conv1.root, conv1.bias,
-                                   conv2.effective_weight(), conv2.root, conv2.bias, graph)
+                                   conv2.effective_weight(), conv2.root, conv2.bias, graph,
+                                   conv1.gather_dtype)
 
 
 class RGCNConv(nn.Module):
@@ -143,8 +158,10 @@ class RGCNConv(nn.Module):
     def __init__(self, in_channels: Union[int, Tuple[int, int]], out_channels: int,
                  num_relations: int, num_bases: Optional[int] = None,
                  num_blocks: Optional[int] = None, aggr: str = "mean", root_weight: bool = True,
-                 is_sorted: bool = False, bias: bool = True, **kwargs):
+                 is_sorted: bool = False, bias: bool = True, gather_dtype=None, **kwargs):
         super().__init__()
+        _check_gather_dtype(gather_dtype)
+        self.gather_dtype = gather_dtype    # None/float32, or float16: fp16 row table, fp32 accumulate
         if num_bases is not None and num_blocks is not None:
             raise ValueError("Can not apply both basis-decomposition and "
                              "block-diagonal-decomposition at the same time.")
@@ -210,7 +227,7 @@ class RGCNConv(nn.Module):
         if x.dim() != 2 or x.size(1) != self.in_channels_l:
             raise ValueError(f"x must be [N, {self.in_channels_l}], got {tuple(x.shape)}")
         return rgcn_conv(x, edge_index, edge_type, self.effective_weight(), self.root, self.bias,
-                         self.num_relations, activation)
+                         self.num_relations, activation, self.gather_dtype)
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}({self.in_channels_l}, {self.out_channels}, "

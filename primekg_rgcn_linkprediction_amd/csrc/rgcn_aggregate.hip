@@ -17,6 +17,8 @@
 // (contiguous) partial rows of a segment with a whole workgroup per item (up to 512 rows:
 // 256/G row slots in parallel, LDS combine in slot order), so even a 30k-edge hub costs one
 // extra short launch and the result is run-to-run deterministic.
+#include <hip/hip_fp16.h>
+
 #include "rgcn_common.h"
 
 namespace {
@@ -87,6 +89,78 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
   }
 }
 
+// fp16 feature table, fp32 accumulate (BASELINE.json configs[4]): the same walk with 8 halves
+// (16 B) per lane, so a row costs half the bytes (132 / 260 B per edge at d = 64 / 128) and a
+// wave64 carries 64 / (d/8) items.  Sums, partial rows and the output stay fp32.
+template <int G, bool WEIGHTED>
+__global__ __launch_bounds__(kThreads) void k_aggregate_h(
+    const __half* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
+    const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
+    float* __restrict__ agg, float* __restrict__ partial, int d) {
+  const int64_t item_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
+  const int c8 = ((int)threadIdx.x % G + (int)blockIdx.y * G) * 8;
+  if (item_id >= nitems || c8 >= d) return;
+  const rgcn_item it = items[item_id];
+
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  int idx_n[kUnroll];
+  float wt_n[kUnroll];
+#pragma unroll
+  for (int u = 0; u < kUnroll; ++u) {
+    const bool ok = it.begin + u < it.end;
+    idx_n[u] = ok ? col[it.begin + u] : -1;
+    wt_n[u] = ok ? (WEIGHTED ? w[it.begin + u] : 1.f) : 0.f;
+  }
+  for (int e = it.begin; e < it.end; e += kUnroll) {
+    int idx[kUnroll];
+    float wt[kUnroll];
+    uint4 v[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      idx[u] = idx_n[u];
+      wt[u] = wt_n[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      v[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (idx[u] >= 0) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)idx[u] * d + c8);
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const int en = e + kUnroll + u;
+      const bool ok = en < it.end;
+      idx_n[u] = ok ? col[en] : -1;
+      wt_n[u] = ok ? (WEIGHTED ? w[en] : 1.f) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const __half2* h2 = reinterpret_cast<const __half2*>(&v[u]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float2 f = __half22float2(h2[k]);
+        if (WEIGHTED) {
+          acc[2 * k] += f.x * wt[u];
+          acc[2 * k + 1] += f.y * wt[u];
+        } else {
+          acc[2 * k] += f.x;
+          acc[2 * k + 1] += f.y;
+        }
+      }
+    }
+  }
+  float* out = (it.flags & 1) ? agg : partial;
+  if ((it.flags & 1) && cnt) {
+    const float c = cnt[it.dst];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] /= c;
+  }
+  float4* o4 = reinterpret_cast<float4*>(out + (size_t)it.dst * d + c8);
+  o4[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  o4[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
 // One workgroup per item: rows [begin, end) of `partial` (contiguous) -> one row.
 // Slot s of SLOTS = 256/G sums rows begin+s, begin+s+SLOTS, ... in order; the slots are then
 // added in slot order through LDS.  Reads and writes of `partial` never alias inside one
@@ -151,9 +225,21 @@ void launch_level(const rgcn_csr* c, int level, bool weighted, const float* x, c
   }
 }
 
+template <int G>
+void launch_level0_h(const rgcn_csr* c, bool weighted, const __half* x, const float* cnt, float* agg, float* partial,
+                     int d, hipStream_t stream) {
+  const int64_t nitems = c->num_items[0];
+  if (nitems == 0) return;
+  dim3 grid((unsigned)ceil_div64(nitems, kThreads / G), (unsigned)ceil_div64(d, 8 * G));
+  if (weighted)
+    k_aggregate_h<G, true><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, c->val, cnt, agg, partial, d);
+  else
+    k_aggregate_h<G, false><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, nullptr, cnt, agg, partial, d);
+}
+
 int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, const float* x, int64_t d,
-                     float* agg, void* workspace, size_t workspace_bytes, void* stream_) {
-  if (!g || !agg || d <= 0 || (d & 3)) return RGCN_ERR_ARG;
+                     float* agg, void* workspace, size_t workspace_bytes, void* stream_, bool half_in = false) {
+  if (!g || !agg || d <= 0 || (d & 3) || (half_in && (d & 7))) return RGCN_ERR_ARG;
   const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
   if (!c->rowptr) return RGCN_ERR_ARG;   // direction not built
   if (c->n_key == 0) return RGCN_OK;
@@ -169,6 +255,18 @@ int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, c
   const bool weighted = c->weighted;
   const int q = (int)(d / 4);
   for (int l = first; l < last; ++l) {
+    if (l == 0 && half_in) {                    // fp16 table: 8 columns per lane
+      const __half* xh = reinterpret_cast<const __half*>(x);
+      const int q8 = (int)(d / 8);
+      if (q8 <= 1) launch_level0_h<1>(c, weighted, xh, cnt, agg, partial, (int)d, stream);
+      else if (q8 <= 2) launch_level0_h<2>(c, weighted, xh, cnt, agg, partial, (int)d, stream);
+      else if (q8 <= 4) launch_level0_h<4>(c, weighted, xh, cnt, agg, partial, (int)d, stream);
+      else if (q8 <= 8) launch_level0_h<8>(c, weighted, xh, cnt, agg, partial, (int)d, stream);
+      else if (q8 <= 16) launch_level0_h<16>(c, weighted, xh, cnt, agg, partial, (int)d, stream);
+      else if (q8 <= 32) launch_level0_h<32>(c, weighted, xh, cnt, agg, partial, (int)d, stream);
+      else launch_level0_h<64>(c, weighted, xh, cnt, agg, partial, (int)d, stream);
+      continue;
+    }
     if (q <= 1) launch_level<1>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
     else if (q <= 2) launch_level<2>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
     else if (q <= 4) launch_level<4>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
@@ -195,6 +293,13 @@ int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t 
   if (!g) return RGCN_ERR_ARG;
   return aggregate_levels(g, transposed, 0, g->dir[transposed ? 1 : 0].num_levels, x, d, agg, workspace,
                           workspace_bytes, stream);
+}
+
+int rgcn_aggregate_f16(const rgcn_graph* g, int transposed, const void* x_f16, int64_t d, float* agg,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g) return RGCN_ERR_ARG;
+  return aggregate_levels(g, transposed, 0, g->dir[transposed ? 1 : 0].num_levels,
+                          reinterpret_cast<const float*>(x_f16), d, agg, workspace, workspace_bytes, stream, true);
 }
 
 int rgcn_aggregate_level(const rgcn_graph* g, int transposed, int level, const float* x, int64_t d, float* agg,

@@ -29,7 +29,8 @@ class DrugDiseaseRGCN(nn.Module):
     """Two-layer R-GCN encoder over a learnable node-embedding table."""
 
     def __init__(self, num_nodes: int, num_relations: int, embedding_dim: int = 64,
-                 hidden_dim: int = 128, dropout: float = 0.5, num_bases: Optional[int] = None):
+                 hidden_dim: int = 128, dropout: float = 0.5, num_bases: Optional[int] = None,
+                 gather_dtype=None):
         super().__init__()
         self.num_nodes = num_nodes
         self.num_relations = num_relations
@@ -37,9 +38,9 @@ class DrugDiseaseRGCN(nn.Module):
         self.hidden_dim = hidden_dim
         self.node_embeddings = nn.Embedding(num_nodes, embedding_dim)
         self.conv1 = RGCNConv(in_channels=embedding_dim, out_channels=hidden_dim,
-                              num_relations=num_relations, num_bases=num_bases)
+                              num_relations=num_relations, num_bases=num_bases, gather_dtype=gather_dtype)
         self.conv2 = RGCNConv(in_channels=hidden_dim, out_channels=hidden_dim,
-                              num_relations=num_relations, num_bases=num_bases)
+                              num_relations=num_relations, num_bases=num_bases, gather_dtype=gather_dtype)
         self.dropout = nn.Dropout(dropout)
         self._init_embeddings()
 
@@ -67,14 +68,14 @@ class DrugDiseaseModel(nn.Module):
 
     def __init__(self, num_nodes: int, num_relations: int, embedding_dim: int = 64,
                  hidden_dim: int = 128, dropout: float = 0.5, decoder_dropout: float = 0.0,
-                 num_bases: Optional[int] = None):
+                 num_bases: Optional[int] = None, gather_dtype=None):
         super().__init__()
         self.num_nodes = num_nodes
         self.num_relations = num_relations
         self.hidden_dim = hidden_dim
         self.encoder = DrugDiseaseRGCN(num_nodes=num_nodes, num_relations=num_relations,
                                        embedding_dim=embedding_dim, hidden_dim=hidden_dim,
-                                       dropout=dropout, num_bases=num_bases)
+                                       dropout=dropout, num_bases=num_bases, gather_dtype=gather_dtype)
         self.decoder = LinkPredictor(num_relations=num_relations, embedding_dim=hidden_dim,
                                      dropout=decoder_dropout)
 

@@ -201,8 +201,10 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False) -
     """``[N, R*d]``: per-(dst, rel) mean of source rows (``transposed=False``) or the
     1/cnt-weighted sum over out-edges per (src, rel) (``transposed=True``).  For a shard
     (``BucketedGraph.from_shard``) x holds the gathered rows of all ranks and the result has
-    the rank's own rows."""
-    _need_gpu("x", x, torch.float32)
+    the rank's own rows.  ``x`` may be float16 (BASELINE configs[4]: fp16 feature table, half
+    the bytes per gathered row); sums and the result are fp32 either way."""
+    half_in = isinstance(x, torch.Tensor) and x.dtype == torch.float16
+    _need_gpu("x", x, torch.float16 if half_in else torch.float32)
     if graph.bipartite and transposed:
         raise ValueError("a shard structure has one direction only (transposed=False)")
     if x.dim() != 2 or x.size(0) != graph.num_other_nodes:
@@ -210,14 +212,17 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False) -
     if x.device != graph.device:
         raise RuntimeError("x and the bucketed graph are on different devices")
     d = x.size(1)
-    if d % 4:
-        raise ValueError(f"feature dim {d} must be a multiple of 4")
+    if d % (8 if half_in else 4):
+        raise ValueError(f"feature dim {d} must be a multiple of {8 if half_in else 4}")
     lib = _lib.load()
     with torch.cuda.device(x.device):
         out = torch.empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
         nbytes = lib.rgcn_aggregate_workspace_bytes(graph.handle, int(transposed), d)
         ws = _workspace(nbytes, x.device)
-        if GATHER_EVENTS is None:
+        if half_in:
+            rc = lib.rgcn_aggregate_f16(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
+                                        _stream())
+        elif GATHER_EVENTS is None:
             rc = lib.rgcn_aggregate(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
                                     _stream())
         else:

@@ -238,7 +238,8 @@ def create_model(num_nodes: int, num_relations: int, args: argparse.Namespace) -
     model = DrugDiseaseModel(num_nodes=num_nodes, num_relations=num_relations,
                              embedding_dim=args.embedding_dim, hidden_dim=args.hidden_dim,
                              dropout=args.dropout, decoder_dropout=args.decoder_dropout,
-                             num_bases=args.num_bases)
+                             num_bases=args.num_bases,
+                             gather_dtype=torch.float16 if getattr(args, "fp16_gather", False) else None)
     logger.info("Model created with %s parameters",
                 f"{sum(p.numel() for p in model.parameters() if p.requires_grad):,}")
     return model
@@ -266,6 +267,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--early_stopping", type=int, default=0)
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--fp16_gather", action="store_true",
+                   help="gather neighbour rows from an fp16 copy of the feature table (fp32 accumulate)")
     p.add_argument("--synthetic", action="store_true",
                    help="train on a PrimeKG-shaped synthetic graph instead of --data_dir")
     p.add_argument("--synthetic_edges", type=int, default=100_000)

@@ -512,3 +512,48 @@ def test_relation_occupancy_masks_change_nothing(d_in, d_out):
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
     # a tile really is skipped somewhere: disease rows [0, 5593) have no relation 0 or 2
     assert float(agg[:5568].view(-1, r, d_in)[:, 0].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ BASELINE configs[4]: fp16 feature table
+@pytest.mark.parametrize("d", [8, 64, 128, 256])
+def test_fp16_gather_equals_fp32_gather_of_the_rounded_table(d):
+    """half the bytes per row, same arithmetic: converting fp16 -> fp32 is exact and the
+    summation order is unchanged, so the result equals the fp32 kernel on the rounded table."""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=60000, seed=d)
+    g = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
+    x16 = torch.randn(n, d, generator=torch.Generator().manual_seed(d)).to(dev).half()
+    for transposed in (False, True):
+        assert torch.equal(ops.aggregate(g, x16, transposed), ops.aggregate(g, x16.float(), transposed))
+    with pytest.raises(ValueError):
+        ops.aggregate(g, torch.zeros(n, 12, device=dev, dtype=torch.float16))     # d % 8
+
+
+def test_config_c5_fp16_features_vs_fp32_oracle():
+    """configs[4]: PrimeKG shape, fp16 feature table + fp32 accumulate vs the fp32 oracle:
+    <= 2e-3 relative (SURVEY 8d parity gate)."""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(seed=42)
+    torch.manual_seed(5)
+    emb = torch.nn.init.xavier_uniform_(torch.empty(n, 64))
+    convs = [RGCNConv(64, 128, r, gather_dtype=torch.float16), RGCNConv(128, 128, r, gather_dtype=torch.float16)]
+    cot = torch.randn(n, 128)
+    ref_p = [{k: v.detach().clone().requires_grad_(True) for k, v in c.named_parameters()} for c in convs]
+    e_ref = emb.clone().requires_grad_(True)
+    out_ref = O.encoder_ref(e_ref, ref_p[0], ref_p[1], ei, et)
+    (out_ref * cot).sum().backward()
+    convs = [c.to(dev) for c in convs]
+    e_gpu = emb.to(dev).requires_grad_(True)
+    out = rgcn_encoder2(e_gpu, ei.to(dev), et.to(dev), convs[0], convs[1])
+    (out * cot.to(dev)).sum().backward()
+    assert rel_err(out, out_ref.detach()) <= 2e-3
+    assert rel_err(e_gpu.grad, e_ref.grad) <= 2e-3
+    for c, rp in zip(convs, ref_p):
+        for k, v in c.named_parameters():
+            assert rel_err(v.grad, rp[k].grad) <= 2e-3, k
+    # and it is not the fp32 path in disguise
+    convs32 = [RGCNConv(64, 128, r).to(dev), RGCNConv(128, 128, r).to(dev)]
+    for a, b in zip(convs32, convs):
+        a.load_state_dict(b.state_dict())
+    out32 = rgcn_encoder2(emb.to(dev), ei.to(dev), et.to(dev), convs32[0], convs32[1])
+    assert not torch.equal(out32, out.detach())
