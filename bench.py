@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="time eager launches, never a HIP graph replay")
     ap.add_argument("--graph", action="store_true", help="time the HIP graph replay even if eager calibrates faster")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--fp16-gather", action="store_true",
+                    help="BASELINE configs[4]: forward gathers read an fp16 copy of the feature table "
+                         "(fp32 accumulate); NOT the headline configuration")
     return ap.parse_args()
 
 
@@ -138,7 +141,8 @@ def main():
     num_edges = ei.size(1)
     torch.manual_seed(0)
     emb_cpu = torch.nn.init.xavier_uniform_(torch.empty(n, DIMS[0]))
-    convs = [RGCNConv(DIMS[0], DIMS[1], r), RGCNConv(DIMS[1], DIMS[2], r)]
+    gdt = torch.float16 if args.fp16_gather else None
+    convs = [RGCNConv(DIMS[0], DIMS[1], r, gather_dtype=gdt), RGCNConv(DIMS[1], DIMS[2], r, gather_dtype=gdt)]
     cot_cpu = torch.randn(n, DIMS[2])
 
     if world == 1:
@@ -242,7 +246,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if not args.fp16_gather else "f16 feature table, f32 accumulate/transform",
+        "data": "synthetic",
         "config": {"workload": f"C2: PrimeKG-shaped synthetic graph, {n} nodes / {num_edges} edge columns / "
                                f"{r} relations, encoder {DIMS[0]}->{DIMS[1]}->{DIMS[2]}, 2 layers fwd+bwd, "
                                f"full graph per step, dropout 0",

@@ -33,7 +33,9 @@ def _glorot(t: Optional[Tensor]) -> None:
 
 
 def _table(x: Tensor, gather_dtype) -> Tensor:
-    """the row table the gather reads: x itself, or its fp16 copy (configs[4])"""
+    """the FEATURE table the forward gather reads: x itself, or its fp16 copy (configs[4]:
+    "fp16 features + fp32 accumulate").  Gradient tables stay fp32: they span many orders of
+    magnitude and would need loss scaling to survive fp16."""
     return x if gather_dtype in (None, torch.float32) else x.to(gather_dtype)
 
 
@@ -68,7 +70,7 @@ class _RGCNConvFunction(torch.autograd.Function):
             gw, groot, gbias = ops.transform_bwd_params(
                 agg, x, g, graph.num_relations, want_root=ctx.has_root, want_bias=ctx.has_bias, graph=graph)
         if need_x:
-            gagg = ops.aggregate(graph, _table(g, ctx.gather_dtype), transposed=True)   # autograd of A3 + A4
+            gagg = ops.aggregate(graph, g, transposed=True)                 # autograd of A3 + A4 (fp32 grads)
             gx = ops.transform_bwd_input(gagg, g, weight, root, graph=graph)  # autograd of A6 wrt x
         return gx, gw, groot, gbias, None, None, None
 
@@ -100,13 +102,13 @@ class _Encoder2Function(torch.autograd.Function):
         g = g.contiguous()
         gw2, groot2, gb2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2,
                                                     graph=graph)
-        gagg2 = ops.aggregate(graph, _table(g, ctx.gather_dtype), transposed=True)
+        gagg2 = ops.aggregate(graph, g, transposed=True)
         gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph)   # d loss / d (pre-ReLU of conv1)
         gw1, groot1, gb1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1,
                                                     graph=graph)
         gx = None
         if ctx.needs_input_grad[0]:
-            gagg1 = ops.aggregate(graph, _table(gz, ctx.gather_dtype), transposed=True)
+            gagg1 = ops.aggregate(graph, gz, transposed=True)
             gx = ops.transform_bwd_input(gagg1, gz, w1, root1, graph=graph)
         return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None
 
@@ -126,8 +128,8 @@ def rgcn_conv(x: Tensor, edge_index: Tensor, edge_type: Tensor, weight: Tensor,
               root: Optional[Tensor], bias: Optional[Tensor], num_relations: int,
               activation: Optional[str] = None, gather_dtype=None) -> Tensor:
     """Functional form on effective weights ``[R, d_in, d_out]``; ``activation='relu'`` fuses
-    the ReLU into the layer; ``gather_dtype=torch.float16`` gathers from an fp16 copy of the row
-    table (fp32 accumulate; BASELINE configs[4])."""
+    the ReLU into the layer; ``gather_dtype=torch.float16`` makes the forward gather read an fp16
+    copy of the feature table (fp32 accumulate; BASELINE configs[4]); gradients stay fp32."""
     _check_x(x)
     _check_gather_dtype(gather_dtype)
     if activation not in (None, "relu"):

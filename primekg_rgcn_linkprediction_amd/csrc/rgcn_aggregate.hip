@@ -28,8 +28,8 @@ constexpr int kUnroll = 8;
 
 __device__ inline float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ inline void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-__device__ inline void f4fma(float4& a, const float4& b, float s) {
-  a.x += b.x * s; a.y += b.y * s; a.z += b.z * s; a.w += b.w * s;
+__device__ inline void f4fma(float4& a, const float4& b, float s) {   // explicit fma: one rounding, in every build
+  a.x = fmaf(b.x, s, a.x); a.y = fmaf(b.y, s, a.y); a.z = fmaf(b.z, s, a.z); a.w = fmaf(b.w, s, a.w);
 }
 
 template <int G, bool WEIGHTED>
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(kThreads) void k_aggregate_h(
       for (int k = 0; k < 4; ++k) {
         const float2 f = __half22float2(h2[k]);
         if (WEIGHTED) {
-          acc[2 * k] += f.x * wt[u];
-          acc[2 * k + 1] += f.y * wt[u];
+          acc[2 * k] = fmaf(f.x, wt[u], acc[2 * k]);
+          acc[2 * k + 1] = fmaf(f.y, wt[u], acc[2 * k + 1]);
         } else {
           acc[2 * k] += f.x;
           acc[2 * k + 1] += f.y;
