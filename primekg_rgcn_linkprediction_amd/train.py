@@ -73,7 +73,15 @@ class Trainer:
         opt = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW}.get(args.optimizer)
         if opt is None:
             raise ValueError(f"Unknown optimizer: {args.optimizer}")
-        self.optimizer = opt(self.model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        # whole-step HIP graph (sampler -> encoder -> head -> BCE -> backward -> clip -> Adam ->
+        # running metrics) for the full-size batches of an epoch; needs a device-side Adam step count
+        self.use_hip_graph = (device.type == "cuda" and not getattr(args, "no_hip_graph", False)
+                              and max(1, getattr(args, "gradient_accumulation_steps", 1)) == 1)
+        # on the GPU: the single-kernel update (same rule; the default one runs ~10 list kernels
+        # per step, ~125 us here), with its step count on the device when the step is captured
+        extra = {"fused": True, "capturable": self.use_hip_graph} if device.type == "cuda" else {}
+        self.optimizer = opt(self.model.parameters(), lr=args.lr, weight_decay=args.weight_decay, **extra)
+        self._graph = self._loss_sum = None
         self.criterion = nn.BCEWithLogitsLoss()
         self.neg_sampler = NegativeSampler(train_data["num_nodes"], args.num_neg_samples)
         self.best_val_loss, self.best_val_acc = float("inf"), 0.0
@@ -100,35 +108,78 @@ class Trainer:
         return torch.cat([head, nh]), torch.cat([tail, nt]), torch.cat([rel, nr]), labels
 
     # -- one epoch ----------------------------------------------------------------------
+    def _step(self, head, tail, rel, accum: int = 1, update: bool = True):
+        """One batch of positives: negatives, forward over the train graph, BCE, backward and
+        (when ``update``) clip + optimizer step; running loss / hits stay on the device."""
+        heads, tails, rels, labels = self._with_negatives(head, tail, rel)
+        scores = self.model(self.train_edge_index, self.train_edge_type, heads, tails, rels)
+        loss = self.criterion(scores, labels)
+        (loss / accum if accum > 1 else loss).backward()
+        if update:
+            if self.args.grad_clip > 0:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.args.grad_clip)
+            self.optimizer.step()
+        with torch.no_grad():                       # device-side bookkeeping, no host sync
+            self._loss_sum += loss.detach().double() * labels.numel()
+            self._correct += ((scores.detach() > 0) == (labels > 0.5)).sum()
+        return heads, tails, rels, labels, loss.detach()
+
+    def _capture_step(self, batch: int) -> None:
+        """Record ``_step`` on the batch ``order[cursor : cursor+batch]`` (``order``, ``cursor`` and
+        the running sums are device-resident and keep their addresses), so a full-size batch is
+        one graph replay with no host work besides setting the cursor.  Called after at least
+        one eager step (graph bucketed, optimizer state allocated)."""
+        self._arange = torch.arange(batch, device=self.device)
+        graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            idx = self._order.index_select(0, self._arange + self._cursor)
+            self._static = self._step(self.train_edge_index[0].index_select(0, idx),
+                                      self.train_edge_index[1].index_select(0, idx),
+                                      self.train_edge_type.index_select(0, idx))
+        self.optimizer.zero_grad(set_to_none=True)      # eager steps get fresh grads; replays use the graph's own
+        self._graph, self._graph_batch = graph, batch
+
     def train_epoch(self, on_step: Optional[Callable] = None, max_steps: Optional[int] = None):
         """-> (mean loss per sample, accuracy).  ``on_step(heads, tails, rels, labels, loss)`` is
         an instrumentation hook (tests); ``max_steps`` truncates the epoch."""
         self.model.train()
         accum = max(1, getattr(self.args, "gradient_accumulation_steps", 1))
-        loss_sum = torch.zeros((), device=self.device, dtype=torch.float64)
-        correct = torch.zeros((), device=self.device, dtype=torch.int64)
-        seen = 0
-        self.optimizer.zero_grad()
-        batches = list(self._batches(self.train_edge_index, self.train_edge_type, shuffle=True))
+        bsz, e = self.args.batch_size, self.train_edge_index.size(1)
+        if self._loss_sum is None:
+            self._loss_sum = torch.zeros((), device=self.device, dtype=torch.float64)
+            self._correct = torch.zeros((), device=self.device, dtype=torch.int64)
+            self._order = torch.empty(e, device=self.device, dtype=torch.int64)
+            self._cursor = torch.zeros((), device=self.device, dtype=torch.int64)
+        self._loss_sum.zero_()
+        self._correct.zero_()
+        # the permutation is drawn on the host like the reference's torch.randperm(num_edges)
+        self._order.copy_(torch.randperm(e))
+        steps = -(-e // bsz)
         if max_steps is not None:
-            batches = batches[:max_steps]
-        for step, (head, tail, rel) in enumerate(batches):
-            heads, tails, rels, labels = self._with_negatives(head, tail, rel)
-            scores = self.model(self.train_edge_index, self.train_edge_type, heads, tails, rels)
-            loss = self.criterion(scores, labels)
-            (loss / accum).backward()
-            if (step + 1) % accum == 0 or step + 1 == len(batches):
-                if self.args.grad_clip > 0:
-                    torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.args.grad_clip)
-                self.optimizer.step()
-                self.optimizer.zero_grad()
-            with torch.no_grad():                       # device-side bookkeeping, no host sync
-                loss_sum += loss.detach().double() * labels.numel()
-                correct += ((scores.detach() > 0) == (labels > 0.5)).sum()
-            seen += labels.numel()
+            steps = min(steps, max_steps)
+        seen = 0
+        self.optimizer.zero_grad(set_to_none=True)
+        for step in range(steps):
+            lo, hi = step * bsz, min((step + 1) * bsz, e)
+            replayable = self.use_hip_graph and hi - lo == bsz
+            if replayable and step >= 1 and (self._graph is None or self._graph_batch != bsz):
+                self._capture_step(bsz)
+            if replayable and self._graph is not None and self._graph_batch == bsz:
+                self._cursor.fill_(lo)
+                self._graph.replay()
+                out = self._static
+            else:
+                idx = self._order[lo:hi]
+                last = (step + 1) % accum == 0 or step + 1 == steps
+                out = self._step(self.train_edge_index[0, idx], self.train_edge_index[1, idx],
+                                 self.train_edge_type[idx], accum=accum, update=last)
+                if last:
+                    self.optimizer.zero_grad(set_to_none=True)
+            seen += (hi - lo) * (1 + self.neg_sampler.num_neg_samples)
             if on_step is not None:
-                on_step(heads, tails, rels, labels, loss.detach())
-        return (loss_sum / max(seen, 1)).item(), correct.item() / max(seen, 1)
+                on_step(*out)
+        return (self._loss_sum / max(seen, 1)).item(), self._correct.item() / max(seen, 1)
 
     @torch.no_grad()
     def validate(self):
@@ -269,6 +320,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--fp16_gather", action="store_true",
                    help="gather neighbour rows from an fp16 copy of the feature table (fp32 accumulate)")
+    p.add_argument("--no_hip_graph", action="store_true",
+                   help="launch every training step eagerly instead of replaying one captured HIP graph")
     p.add_argument("--synthetic", action="store_true",
                    help="train on a PrimeKG-shaped synthetic graph instead of --data_dir")
     p.add_argument("--synthetic_edges", type=int, default=100_000)

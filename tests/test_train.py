@@ -56,9 +56,11 @@ def _args(**kw):
 
 
 @pytest.mark.gpu
-def test_trainer_steps_match_oracle_on_the_same_batches(tmp_path):
+@pytest.mark.parametrize("hip_graph", [False, True])
+def test_trainer_steps_match_oracle_on_the_same_batches(tmp_path, hip_graph):
     """Five optimizer steps (Adam, clip 1.0, dropout 0) on the HIP model vs the oracle model
-    fed the recorded batches: per-step loss and the parameters afterwards agree."""
+    fed the recorded batches: per-step loss and the parameters afterwards agree -- launched
+    eagerly, and with steps 2-5 as replays of the captured whole-step HIP graph."""
     dev = need_gpu()
     torch.manual_seed(0)
     n, r = 400, 3
@@ -66,13 +68,16 @@ def test_trainer_steps_match_oracle_on_the_same_batches(tmp_path):
     ei = torch.randint(0, n, (2, 6000), generator=gen)
     et = torch.randint(0, r, (6000,), generator=gen)
     data = {"edge_index": ei, "edge_type": et, "num_nodes": n, "num_relations": r}
-    args = _args(dropout=0.0, decoder_dropout=0.0, batch_size=256, output_dir=str(tmp_path), device="cuda")
+    args = _args(dropout=0.0, decoder_dropout=0.0, batch_size=256, output_dir=str(tmp_path), device="cuda",
+                 no_hip_graph=not hip_graph)
     model = T.create_model(n, r, args)
     ref_state = {k: v.clone() for k, v in model.state_dict().items()}
     trainer = T.Trainer(model, data, data, data, dev, args)
     log = []
     trainer.train_epoch(on_step=lambda h, t, rl, lb, loss: log.append((h.cpu(), t.cpu(), rl.cpu(), lb.cpu(), loss.item())),
                         max_steps=5)
+    assert (trainer._graph is not None) == hip_graph
+    assert len(log) == 5 and len({tuple(h.tolist()) for h, *_ in log}) == 5      # five different batches
     # oracle replay
     params = {k: v.clone().requires_grad_(True) for k, v in ref_state.items()}
     opt = torch.optim.Adam(list(params.values()), lr=args.lr)

@@ -7,7 +7,7 @@ from primekg_rgcn_linkprediction_amd import train as T
 
 dev = torch.device("cuda:0")
 tr, va, full, te = T.synthetic_data(num_edges=1_708_556, seed=42)    # 2 x 854,278 kg rows; ~1.68M train columns
-args = T.parse_args(["--epochs", "1", "--output_dir", "/tmp/epoch_probe"])
+args = T.parse_args(["--epochs", "1", "--output_dir", "/tmp/epoch_probe"] + sys.argv[1:])   # e.g. --no_hip_graph
 torch.manual_seed(42)
 trainer = T.Trainer(T.create_model(tr["num_nodes"], 3, args), tr, va, full, dev, args)
 steps = (tr["edge_index"].size(1) + args.batch_size - 1) // args.batch_size
