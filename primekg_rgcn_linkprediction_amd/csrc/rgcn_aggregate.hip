@@ -25,6 +25,10 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kUnroll = 8;
+#ifndef RGCN_REDUCE_UNROLL
+#define RGCN_REDUCE_UNROLL 16
+#endif
+constexpr int kReduceUnroll = RGCN_REDUCE_UNROLL;   // contiguous partial rows in flight per slot of the hub reduce
 
 __device__ inline float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ inline void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
@@ -177,16 +181,16 @@ __global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* _
   const bool live = c4 < d;
   float4 acc = f4zero();
   if (live) {
-    for (int r0 = it.begin + slot; r0 < it.end; r0 += SLOTS * kUnroll) {
-      float4 v[kUnroll];
+    for (int r0 = it.begin + slot; r0 < it.end; r0 += SLOTS * kReduceUnroll) {
+      float4 v[kReduceUnroll];
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
+      for (int u = 0; u < kReduceUnroll; ++u) {
         const int row = r0 + u * SLOTS;
         v[u] = f4zero();
         if (row < it.end) v[u] = *reinterpret_cast<const float4*>(partial + (size_t)row * d + c4);
       }
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) f4add(acc, v[u]);
+      for (int u = 0; u < kReduceUnroll; ++u) f4add(acc, v[u]);
     }
   }
   red[threadIdx.x] = acc;
