@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 3
+#define RGCN_ABI_VERSION 4
 
 enum {
   RGCN_OK = 0,
@@ -105,6 +105,17 @@ int rgcn_graph_arrays(const rgcn_graph* g, int transposed, const int32_t** rowpt
  * above; any destination may be NULL. */
 int rgcn_graph_export(const rgcn_graph* g, int transposed, int32_t* rowptr, int32_t* col,
                       int64_t* perm, float* val, void* stream);
+
+/* Rebuild a handle from the arrays rgcn_graph_export wrote for both directions of a square
+ * graph (SURVEY section 8f "next" row 3: the bucketed structure persisted next to the
+ * reference's dict `.pt` graph file, `src/preprocess.py:256-261`, so that start-up skips the
+ * sort).  All pointers are device pointers and are copied.  Index arrays are validated on the
+ * device (rowptr non-decreasing from 0 to num_edges, col in [0, num_nodes), perm in
+ * [0, num_edges)); RGCN_ERR_RANGE otherwise.  cnt / w_t are taken as given. */
+int rgcn_graph_import(int64_t num_edges, int64_t num_nodes, int64_t num_relations,
+                      const int32_t* rowptr, const int32_t* col, const int64_t* perm, const float* cnt,
+                      const int32_t* rowptr_t, const int32_t* col_t, const int64_t* perm_t,
+                      const float* w_t, void* stream, rgcn_graph** out);
 
 /* ------------------------------------------------------------------------------------
  * Gather + per-(node, relation) aggregation (rows A3 + A4, and their autograd, row A7).

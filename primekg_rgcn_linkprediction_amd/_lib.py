@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_p
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -41,6 +41,7 @@ PROTOTYPES = {
     "rgcn_graph_arrays": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                   POINTER(c_void_p), POINTER(c_void_p)]),
     "rgcn_graph_export": (c_int, [c_void_p, c_int, _P, _P, _P, _P, _P]),
+    "rgcn_graph_import": (c_int, [_I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, POINTER(c_void_p)]),
     "rgcn_aggregate_workspace_bytes": (c_size_t, [c_void_p, c_int, _I64]),
     "rgcn_aggregate": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, _P]),
     "rgcn_aggregate_f16": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, _P]),

@@ -288,6 +288,47 @@ int create_bipartite_impl(const int64_t* key_node, const int64_t* other_node, co
   return RGCN_OK;
 }
 
+// structure check of an imported CSR: anything the gather would dereference
+__global__ void k_validate_csr(const int32_t* rowptr, int64_t NR, const int32_t* col, const int64_t* perm,
+                               int64_t E, int64_t n_other, int* flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool bad = false;
+  if (i < NR) bad |= rowptr[i] > rowptr[i + 1] || rowptr[i] < 0;
+  if (i == 0) bad |= rowptr[0] != 0 || (int64_t)rowptr[NR] != E;
+  if (i < E) bad |= col[i] < 0 || col[i] >= n_other || perm[i] < 0 || perm[i] >= E;
+  if (bad) *flag = 1;
+}
+
+int import_csr(const int32_t* rowptr, const int32_t* col, const int64_t* perm, const float* val, bool weighted,
+               int64_t E, int64_t N, int64_t R, int* flag, hipStream_t stream, rgcn_csr* c) {
+  const int64_t NR = N * R;
+  c->n_key = N;
+  c->n_other = N;
+  c->weighted = weighted;
+  RGCN_HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), stream));
+  k_validate_csr<<<grid_for(std::max(NR, E) + 1), kThreads, 0, stream>>>(rowptr, NR, col, perm, E, N, flag);
+  int host_flag = 0;
+  RGCN_HIP_TRY(hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+  RGCN_HIP_TRY(hipStreamSynchronize(stream));
+  if (host_flag) return RGCN_ERR_RANGE;
+  const size_t nval = (size_t)(weighted ? E : std::max<int64_t>(NR, 1));
+  RGCN_HIP_TRY(hipMalloc((void**)&c->rowptr, (NR + 1) * sizeof(int32_t)));
+  RGCN_HIP_TRY(hipMemcpyAsync(c->rowptr, rowptr, (NR + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+  if (E > 0) {
+    RGCN_HIP_TRY(hipMalloc((void**)&c->col, E * sizeof(int32_t)));
+    RGCN_HIP_TRY(hipMalloc((void**)&c->perm, E * sizeof(int64_t)));
+    RGCN_HIP_TRY(hipMemcpyAsync(c->col, col, E * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+    RGCN_HIP_TRY(hipMemcpyAsync(c->perm, perm, E * sizeof(int64_t), hipMemcpyDeviceToDevice, stream));
+  }
+  if (!weighted || E > 0) {
+    RGCN_HIP_TRY(hipMalloc((void**)&c->val, nval * sizeof(float)));
+    if (NR > 0 || weighted)
+      RGCN_HIP_TRY(hipMemcpyAsync(c->val, val, (weighted ? (size_t)E : (size_t)NR) * sizeof(float),
+                                  hipMemcpyDeviceToDevice, stream));
+  }
+  return plan_structure(c, R, stream);
+}
+
 bool too_big(int64_t n_key, int64_t n_other, int64_t R, int64_t E) {
   const int64_t lim = ((int64_t)1 << 31) - 1;
   return n_key * R >= lim || n_other >= lim || E >= lim;
@@ -342,6 +383,37 @@ int rgcn_graph_create_bipartite(const int64_t* key_node, const int64_t* other_no
   if (!g) return RGCN_ERR_HIP;
   int rc = create_bipartite_impl(key_node, other_node, edge_type, num_edges, num_key_nodes, num_other_nodes,
                                  num_relations, edge_weight, (hipStream_t)stream, g);
+  if (rc != RGCN_OK) {
+    rgcn_graph_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return RGCN_OK;
+}
+
+int rgcn_graph_import(int64_t num_edges, int64_t num_nodes, int64_t num_relations, const int32_t* rowptr,
+                      const int32_t* col, const int64_t* perm, const float* cnt, const int32_t* rowptr_t,
+                      const int32_t* col_t, const int64_t* perm_t, const float* w_t, void* stream_,
+                      rgcn_graph** out) {
+  if (!out) return RGCN_ERR_ARG;
+  *out = nullptr;
+  if (num_edges < 0 || num_nodes < 0 || num_relations <= 0 || !rowptr || !rowptr_t) return RGCN_ERR_ARG;
+  if (num_nodes * num_relations > 0 && !cnt) return RGCN_ERR_ARG;
+  if (num_edges > 0 && (!col || !perm || !col_t || !perm_t || !w_t)) return RGCN_ERR_ARG;
+  if (too_big(num_nodes, num_nodes, num_relations, num_edges)) return RGCN_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  rgcn_graph* g = new (std::nothrow) rgcn_graph();
+  if (!g) return RGCN_ERR_HIP;
+  g->E = num_edges; g->N = num_nodes; g->R = num_relations;
+  int* flag = nullptr;
+  int rc = hipMalloc((void**)&flag, sizeof(int)) == hipSuccess ? RGCN_OK : RGCN_ERR_HIP;
+  if (rc == RGCN_OK)
+    rc = import_csr(rowptr, col, perm, cnt, false, num_edges, num_nodes, num_relations, flag, stream, &g->dir[0]);
+  if (rc == RGCN_OK)
+    rc = import_csr(rowptr_t, col_t, perm_t, w_t, true, num_edges, num_nodes, num_relations, flag, stream,
+                    &g->dir[1]);
+  if (rc == RGCN_OK && hipStreamSynchronize(stream) != hipSuccess) rc = RGCN_ERR_HIP;
+  (void)hipFree(flag);
   if (rc != RGCN_OK) {
     rgcn_graph_destroy(g);
     return rc;

@@ -70,6 +70,11 @@ class Trainer:
         self.val_edge_type = val_data["edge_type"].to(device)
         self.full_edge_index = full_graph["edge_index"].to(device)
         self.full_edge_type = full_graph["edge_type"].to(device)
+        if device.type == "cuda":      # bucket now (or import the persisted structure, --bucket_cache)
+            from . import ops
+            for d, ei, et in ((train_data, self.train_edge_index, self.train_edge_type),
+                              (full_graph, self.full_edge_index, self.full_edge_type)):
+                ops.bucket(ei, et, d["num_nodes"], d["num_relations"], sidecar=d.get("sidecar"))
         opt = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW}.get(args.optimizer)
         if opt is None:
             raise ValueError(f"Unknown optimizer: {args.optimizer}")
@@ -256,16 +261,20 @@ def filter_edges(data: Dict, num_nodes: int, name: str = "") -> Dict:
     return data
 
 
-def load_data(data_dir: str):
+def load_data(data_dir: str, bucket_cache: bool = False):
     """``{train,val,test}_data.pt``, ``full_graph.pt``: dicts {edge_index int64[2,E], edge_type
     int64[E], num_nodes, num_relations} (``preprocess.py:256-261``); tensors only, so they are
-    read with ``weights_only=True``.  ``mappings.pt`` holds Python dicts and is not needed to train."""
+    read with ``weights_only=True``.  ``mappings.pt`` holds Python dicts and is not needed to train.
+    ``bucket_cache``: keep the bucketed CSR-by-relation structure of the two message-passing
+    graphs in ``<name>.bucketed.pt`` next to them (checked against the columns on load)."""
     root = Path(data_dir)
-    parts = {k: torch.load(root / f, weights_only=True) for k, f in
-             (("train", "train_data.pt"), ("val", "val_data.pt"), ("test", "test_data.pt"),
-              ("full", "full_graph.pt"))}
+    files = (("train", "train_data.pt"), ("val", "val_data.pt"), ("test", "test_data.pt"), ("full", "full_graph.pt"))
+    parts = {k: torch.load(root / f, weights_only=True) for k, f in files}
     n = parts["train"]["num_nodes"]
     parts = {k: filter_edges(v, n, k) for k, v in parts.items()}
+    if bucket_cache:
+        for k, f in files:
+            parts[k] = dict(parts[k], sidecar=str(root / f.replace(".pt", ".bucketed.pt")))
     return parts["train"], parts["val"], parts["full"], parts["test"]
 
 
@@ -320,6 +329,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--fp16_gather", action="store_true",
                    help="gather neighbour rows from an fp16 copy of the feature table (fp32 accumulate)")
+    p.add_argument("--bucket_cache", action="store_true",
+                   help="persist / reuse the bucketed graph structure next to the .pt files in --data_dir")
     p.add_argument("--no_hip_graph", action="store_true",
                    help="launch every training step eagerly instead of replaying one captured HIP graph")
     p.add_argument("--synthetic", action="store_true",
@@ -350,7 +361,7 @@ def main(argv=None) -> None:
     if args.synthetic:
         train_data, val_data, full_graph, _ = synthetic_data(args.synthetic_edges, args.seed)
     else:
-        train_data, val_data, full_graph, _ = load_data(args.data_dir)
+        train_data, val_data, full_graph, _ = load_data(args.data_dir, args.bucket_cache)
     model = create_model(train_data["num_nodes"], train_data["num_relations"], args)
     Trainer(model, train_data, val_data, full_graph, device, args).train()
 

@@ -110,6 +110,74 @@ def test_graph_cache_hits_and_invalidates():
     ops.clear_graph_cache()
 
 
+
+# ------------------------------------------------------------------ persisted structure (section 8f row 3)
+def test_sidecar_round_trip_is_bitwise_and_skips_nothing(tmp_path):
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=60000, seed=3)
+    ei, et = ei.to(dev), et.to(dev)
+    a = ops.BucketedGraph(ei, et, n, r)
+    a.save(tmp_path / "g.bucketed.pt")
+    b = ops.BucketedGraph.load(tmp_path / "g.bucketed.pt", dev)
+    for transposed in (False, True):
+        for x, y in zip(a.arrays(transposed), b.arrays(transposed)):
+            assert torch.equal(x, y)
+        assert a.num_levels(transposed) == b.num_levels(transposed)
+    x = torch.randn(n, 64, device=dev)
+    for transposed in (False, True):
+        assert torch.equal(ops.aggregate(a, x, transposed), ops.aggregate(b, x, transposed))
+    # layer through the imported structure == layer through the sorted one (tile masks included)
+    torch.manual_seed(0)
+    conv = RGCNConv(64, 128, r).to(dev)
+    with torch.no_grad():
+        ya = ops.transform_fwd(ops.aggregate(a, x), x, conv.weight, conv.root, conv.bias, graph=a)
+        yb = ops.transform_fwd(ops.aggregate(b, x), x, conv.weight, conv.root, conv.bias, graph=b)
+    assert torch.equal(ya, yb)
+
+
+def test_sidecar_is_used_checked_and_rewritten(tmp_path):
+    dev = need_gpu()
+    ops.clear_graph_cache()
+    path = tmp_path / "train_data.bucketed.pt"
+    ei, et, n, r = synth.uniform_graph(300, 4000, 3, seed=8)
+    ei, et = ei.to(dev), et.to(dev)
+    g1 = ops.bucket(ei, et, n, r, sidecar=path)                # sorts, writes the file
+    assert path.exists()
+    ops.clear_graph_cache()
+    g2 = ops.bucket(ei, et, n, r, sidecar=path)                # imports
+    assert all(torch.equal(x, y) for x, y in zip(g1.arrays(False), g2.arrays(False)))
+    # a file that belongs to other columns is detected and replaced
+    ops.clear_graph_cache()
+    ei2 = ei.clone()
+    ei2[0, 7] = (ei2[0, 7] + 1) % n
+    g3 = ops.bucket(ei2, et, n, r, sidecar=path)
+    want = ops.BucketedGraph(ei2, et, n, r)
+    assert all(torch.equal(x, y) for x, y in zip(g3.arrays(False), want.arrays(False)))
+    ops.clear_graph_cache()
+    g4 = ops.bucket(ei2, et, n, r, sidecar=path)               # the rewritten file now matches
+    assert all(torch.equal(x, y) for x, y in zip(g4.arrays(True), want.arrays(True)))
+    ops.clear_graph_cache()
+
+
+def test_import_rejects_arrays_that_are_not_a_csr(tmp_path):
+    dev = need_gpu()
+    ei, et, n, r = synth.uniform_graph(40, 500, 2, seed=2)
+    good = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r).state()
+    for key, edit in (("col", lambda t: t.__setitem__(3, n)),              # source id out of range
+                      ("rowptr", lambda t: t.__setitem__(5, t[4] - 1 if t[4] > 0 else 10**6)),   # not monotone
+                      ("perm_t", lambda t: t.__setitem__(0, -1)),
+                      ("rowptr_t", lambda t: t.__setitem__(-1, 499))):      # does not end at E
+        bad = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in good.items()}
+        edit(bad[key])
+        with pytest.raises(IndexError):
+            ops.BucketedGraph.from_state(bad, dev)
+    bad = dict(good, col=good["col"][:-1])
+    with pytest.raises(ValueError):
+        ops.BucketedGraph.from_state(bad, dev)                  # wrong length never reaches the device
+    with pytest.raises(ValueError):
+        ops.BucketedGraph.from_state(dict(good, format="x"), dev)
+    ops.BucketedGraph.from_state(good, dev)
+
 # ------------------------------------------------------------------ aggregate (A3 + A4)
 @pytest.mark.parametrize("case", LAYER_CASES)
 def test_aggregate_golden(case):
