@@ -234,6 +234,26 @@ def distmult_all_tails_ref(head_emb, rel_emb_rows, all_emb):
     return (head_emb * rel_emb_rows) @ all_emb.t()
 
 
+def cosine_scores_ref(embeddings, drug_indices, disease_indices):
+    """numpy float32, as ``src/compare_methods.py:384-397`` (RGCNMethod.predict_all):
+    normalise rows, dot, map [-1, 1] -> [0, 1].  -> [n_drug, n_disease]"""
+    import numpy as np
+    emb = np.asarray(embeddings, dtype=np.float32)
+    a, b = emb[np.asarray(drug_indices)], emb[np.asarray(disease_indices)]
+    a = a / np.linalg.norm(a, axis=1, keepdims=True)
+    b = b / np.linalg.norm(b, axis=1, keepdims=True)
+    return (np.dot(a, b.T) + 1) / 2
+
+
+def top_drugs_ref(embeddings, disease_idx, drug_indices, top_k=10, threshold=0.0):
+    """as ``src/case_studies.py:236-284``: scores of all candidate drugs, filter by threshold,
+    stable sort by score descending, first top_k.  -> [(drug_idx, score)]"""
+    scores = cosine_scores_ref(embeddings, drug_indices, [disease_idx])[:, 0]
+    predictions = [(int(drug_indices[i]), float(scores[i])) for i in range(len(scores)) if scores[i] >= threshold]
+    predictions.sort(key=lambda p: p[1], reverse=True)
+    return predictions[:top_k]
+
+
 def encoder_ref(emb_weight, conv1: dict, conv2: dict, edge_index, edge_type,
                 dropout_p: float = 0.0, training: bool = False):
     """conv1 -> relu -> dropout -> conv2 (rgcn.py:117-130); convN are dicts of

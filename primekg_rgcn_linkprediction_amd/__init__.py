@@ -8,7 +8,7 @@ behind a C ABI (``include/rgcn_hip.h`` -> ``librgcn_hip.so``).  See DESIGN.md.
 from .conv import RGCNConv, rgcn_conv, rgcn_encoder2
 from .head import LinkPredictor, distmult
 from .model import DrugDiseaseModel, DrugDiseaseRGCN
-from . import ops, synth
+from . import consumers, ops, synth
 
 __all__ = ["RGCNConv", "rgcn_conv", "rgcn_encoder2", "LinkPredictor", "distmult", "DrugDiseaseModel",
-           "DrugDiseaseRGCN", "ops", "synth"]
+           "DrugDiseaseRGCN", "consumers", "ops", "synth"]

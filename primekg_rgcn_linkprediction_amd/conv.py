@@ -76,20 +76,28 @@ class _RGCNConvFunction(torch.autograd.Function):
 
 
 class _Encoder2Function(torch.autograd.Function):
-    """conv1 -> ReLU -> conv2 (``src/models/rgcn.py:123-128`` with dropout inactive) as one
-    autograd node: the ReLU rides in conv1's GEMM epilogue, and its backward rides in the
-    epilogue of conv2's input-gradient GEMM (which then emits the gradient with respect to
-    conv1's pre-activation directly), so no elementwise kernel runs between the layers."""
+    """conv1 -> ReLU -> [dropout] -> conv2 (``src/models/rgcn.py:123-128``) as one autograd
+    node: the ReLU rides in conv1's GEMM epilogue, and its backward rides in the epilogue of
+    conv2's input-gradient GEMM (which then emits the gradient with respect to conv1's
+    pre-activation directly), so no elementwise kernel runs between the layers.
+
+    With ``p > 0`` the mask is drawn by torch's own dropout kernel from torch's RNG stream,
+    exactly where ``rgcn.py:125`` draws it.  Its backward costs nothing extra: the dropped
+    activations ``hd = relu(z) * m / (1-p)`` are positive exactly where the unit is both active
+    and kept, so ``hd`` is the epilogue mask, and the factor ``1/(1-p)`` is folded into the
+    (small) weight operand of that GEMM."""
 
     @staticmethod
-    def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph, gather_dtype=None):
+    def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph, gather_dtype=None, p: float = 0.0):
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
         ctx.gather_dtype = gather_dtype
         agg1 = ops.aggregate(graph, _table(x, gather_dtype))
         h = ops.transform_fwd(agg1, x, w1, root1, b1, relu=True, graph=graph)
+        if p > 0:
+            h = torch.native_dropout(h, p, True)[0]
         agg2 = ops.aggregate(graph, _table(h, gather_dtype))
         out = ops.transform_fwd(agg2, h, w2, root2, b2, graph=graph)
-        ctx.graph = graph
+        ctx.graph, ctx.p = graph, p
         ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
         ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2)
         return out
@@ -103,6 +111,9 @@ class _Encoder2Function(torch.autograd.Function):
         gw2, groot2, gb2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2,
                                                     graph=graph)
         gagg2 = ops.aggregate(graph, g, transposed=True)
+        if ctx.p > 0:
+            scale = 1.0 / (1.0 - ctx.p)
+            w2, root2 = w2 * scale, (root2 * scale if root2 is not None else None)
         gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph)   # d loss / d (pre-ReLU of conv1)
         gw1, groot1, gb1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1,
                                                     graph=graph)
@@ -110,7 +121,7 @@ class _Encoder2Function(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gagg1 = ops.aggregate(graph, gz, transposed=True)
             gx = ops.transform_bwd_input(gagg1, gz, w1, root1, graph=graph)
-        return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None
+        return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None, None
 
 
 def _check_x(x: Tensor) -> None:
@@ -139,13 +150,16 @@ def rgcn_conv(x: Tensor, edge_index: Tensor, edge_type: Tensor, weight: Tensor,
 
 
 def rgcn_encoder2(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: "RGCNConv",
-                  conv2: "RGCNConv") -> Tensor:
-    """``conv2(relu(conv1(x)))`` through the fused two-layer autograd node."""
+                  conv2: "RGCNConv", dropout_p: float = 0.0) -> Tensor:
+    """``conv2(dropout(relu(conv1(x)), dropout_p))`` through the fused two-layer autograd node
+    (``dropout_p`` = 0: no dropout, e.g. eval mode)."""
     _check_x(x)
+    if not 0.0 <= dropout_p < 1.0:
+        raise ValueError(f"dropout_p must be in [0, 1), got {dropout_p}")
     graph = ops.bucket(edge_index, edge_type, x.size(0), conv1.num_relations)
     return _Encoder2Function.apply(x, conv1.effective_weight(), conv1.root, conv1.bias,
                                    conv2.effective_weight(), conv2.root, conv2.bias, graph,
-                                   conv1.gather_dtype)
+                                   conv1.gather_dtype, float(dropout_p))
 
 
 class RGCNConv(nn.Module):

@@ -51,13 +51,14 @@ class DrugDiseaseRGCN(nn.Module):
                 node_indices: Optional[Tensor] = None) -> Tensor:
         # the whole table is the layer-1 input (no lookup) unless a subset is asked for
         x = self.node_embeddings.weight if node_indices is None else self.node_embeddings(node_indices)
-        if not (self.training and self.dropout.p > 0):
-            # dropout is the identity: conv1 -> relu -> conv2 as one fused autograd node
-            return rgcn_encoder2(x, edge_index, edge_type, self.conv1, self.conv2)
-        # training with dropout: the mask comes from torch's RNG stream, as in the reference
-        x = self.conv1(x, edge_index, edge_type, activation="relu")      # relu fused (rgcn.py:123-124)
-        x = self.dropout(x)                                              # rgcn.py:125
-        return self.conv2(x, edge_index, edge_type)                      # rgcn.py:128
+        p = self.dropout.p if self.training else 0.0
+        if p < 1.0:
+            # conv1 -> relu -> dropout -> conv2 (rgcn.py:123-128) as one fused autograd node; the
+            # mask comes from torch's dropout kernel and RNG stream, as in the reference
+            return rgcn_encoder2(x, edge_index, edge_type, self.conv1, self.conv2, dropout_p=p)
+        x = self.conv1(x, edge_index, edge_type, activation="relu")      # p == 1: everything dropped
+        x = self.dropout(x)
+        return self.conv2(x, edge_index, edge_type)
 
     def get_node_embeddings(self, node_indices: Tensor) -> Tensor:
         return self.node_embeddings(node_indices)

@@ -58,3 +58,37 @@ def test_ranks_and_auc_on_a_larger_graph():
     assert 0.0 <= out["classification"]["auc_roc"] <= 1.0 and out["num_test_edges"] == te["edge_index"].size(1)
     s, l = ev.compute_scores_and_labels(num_neg_samples=2)
     assert s.shape == l.shape == (3 * out["num_test_edges"],) and l.sum() == out["num_test_edges"]
+
+
+# ---------------------------------------------------------------- embedding consumers
+def test_cosine_consumers_match_the_numpy_restatement():
+    """pair scores (DistMult kernel on unit rows), score matrix and top-k drugs vs the oracle's
+    numpy restatement of compare_methods.py:368-397 / case_studies.py:236-284."""
+    dev = need_gpu()
+    from oracle import rgcn_oracle as O
+    from primekg_rgcn_linkprediction_amd import consumers as C
+    gen = torch.Generator().manual_seed(11)
+    emb = torch.randn(500, 128, generator=gen)
+    emb[40] = emb[17]                                     # two candidates tie exactly
+    drugs = torch.arange(10, 210).tolist()
+    diseases = torch.arange(300, 420).tolist()
+    want = O.cosine_scores_ref(emb.numpy(), drugs, diseases)
+    e = emb.to(dev)
+    got = C.cosine_score_matrix(e, drugs, diseases).cpu().numpy()
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
+    pi = torch.randint(0, len(drugs), (1000,), generator=gen)
+    pj = torch.randint(0, len(diseases), (1000,), generator=gen)
+    pair = C.cosine_pair_scores(e, torch.tensor(drugs)[pi], torch.tensor(diseases)[pj]).cpu().numpy()
+    assert np.abs(pair - want[pi.numpy(), pj.numpy()]).max() <= 2e-6
+    unit = C.normalize_rows(e)
+    for disease, k, thr in ((300, 10, 0.0), (333, 25, 0.5), (419, 5, 0.99)):
+        ref = O.top_drugs_ref(emb.numpy(), disease, drugs, k, thr)
+        top = C.predict_top_drugs(unit, disease, drugs, k, thr, normalized=True)
+        assert len(top) == len(ref)
+        for (gi, gs), (ri, rs) in zip(top, ref):
+            assert abs(gs - rs) <= 2e-6
+            assert gi == ri or abs(gs - rs) <= 1e-7       # order may swap only between fp-equal scores
+    with pytest.raises(ValueError):
+        C.cosine_pair_scores(e, [1, 2], [3])
+    with pytest.raises(RuntimeError):
+        C.cosine_pair_scores(emb, [1], [2])               # CPU tensor: no CPU fallback

@@ -208,3 +208,16 @@ def test_glorot_bounds_and_zero_bias():
     assert c.weight.shape == (3, 64, 128) and c.root.shape == (64, 128) and c.bias.shape == (128,)
     assert c.weight.abs().max() <= a and c.root.abs().max() <= a and c.weight.abs().max() > 0.9 * a
     assert torch.count_nonzero(c.bias) == 0
+
+
+def test_cosine_restatement_is_the_cosine():
+    """compare_methods.py:368-382 (per pair, python loop) == :384-397 (matrix) in the oracle's restatement."""
+    gen = torch.Generator().manual_seed(0)
+    emb = torch.randn(30, 16, generator=gen).numpy()
+    m = O.cosine_scores_ref(emb, [1, 2, 3], [4, 5])
+    for i, a in enumerate([1, 2, 3]):
+        for j, b in enumerate([4, 5]):
+            sim = np.dot(emb[a], emb[b]) / (np.linalg.norm(emb[a]) * np.linalg.norm(emb[b]))
+            assert abs(m[i, j] - (sim + 1) / 2) <= 1e-6
+    top = O.top_drugs_ref(emb, 4, [1, 2, 3], top_k=2)
+    assert len(top) == 2 and top[0][1] >= top[1][1] and {t[0] for t in top} <= {1, 2, 3}
