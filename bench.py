@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches, never a HIP graph replay")
     ap.add_argument("--graph", action="store_true", help="time the HIP graph replay even if eager calibrates faster")
+    ap.add_argument("--no-replica", action="store_true",
+                    help="N > 1: skip the batch-replica leg reported beside the node-partitioned number")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--fp16-gather", action="store_true",
                     help="BASELINE configs[4]: forward gathers read an fp16 copy of the feature table "
@@ -277,6 +279,23 @@ def main():
                               "kernel": dom["kernel"],
                               "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"]}
         result["gather_kernels"] = kernels
+
+    if world > 1 and not args.no_replica:
+        # Reported beside the node-partitioned number (never instead of it): batch-replica mode,
+        # every GPU the whole graph and its own mini-batch, one flat all-reduce of all parameter
+        # gradients per step.  Per-GPU work is fixed, so this one is weak scaling.
+        import copy
+        rep = rdist.ReplicatedEncoder(ei, et, n, r, emb_cpu, [copy.deepcopy(c) for c in convs], dev)
+        cot_full = cot_cpu.to(dev)
+        for _ in range(args.warmup):
+            rep.step(cot_full)
+        rep_s = timed(lambda: rep.step(cot_full), args.steps)
+        t = torch.tensor([rep_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        result["replica"] = {"value": world * LAYERS * num_edges / t.item(), "unit": "edges/s",
+                             "ms_per_step": t.item() * 1e3, "scaling": "weak",
+                             "parallelism": f"batch replicas x{world}: full graph and encoder per GPU, one "
+                                            f"{rep._flat.numel() * 4 / 1e6:.1f} MB gradient all-reduce per step"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(ei, et, n, r, args.cpu_seconds)

@@ -323,3 +323,51 @@ class PartitionedEncoder:
     def gather_output(self, own: Tensor) -> Tensor:
         """all ranks' rows -> [N, d] in node order (for checks)"""
         return self.part.unshard_rows(_all_gather_rows(own.detach(), self.world, self.group))
+
+
+class ReplicatedEncoder:
+    """Batch-replica mode ("alternative worth measuring"): every GPU holds
+    the whole bucketed graph and runs the whole encoder for ITS mini-batch - the reference
+    re-runs the full-graph encoder for each 1,024-edge batch anyway (``train.py:291-297``), so
+    N GPUs work on N batches at once - and the gradients of all parameters including the
+    embedding table (8.3 MB at C2) are averaged with ONE flat all-reduce per step.  No exchange
+    inside the layer: per-GPU work is fixed as N grows (weak scaling).
+
+    ``encoder_fn(emb, edge_index, edge_type, conv1, conv2) -> [N, d_out]`` is injectable for
+    the CPU (gloo) tests; the product path is ``rgcn_encoder2`` on the HIP library."""
+
+    def __init__(self, edge_index: Tensor, edge_type: Tensor, num_nodes: int, num_relations: int,
+                 emb_full: Tensor, convs: Sequence[torch.nn.Module], device, encoder_fn=None, group=None):
+        self.world = dist.get_world_size(group)
+        self.group = group
+        if encoder_fn is None:
+            from .conv import rgcn_encoder2
+            from . import ops
+            encoder_fn = rgcn_encoder2
+            self.edge_index, self.edge_type = edge_index.to(device), edge_type.to(device)
+            ops.bucket(self.edge_index, self.edge_type, num_nodes, num_relations)
+        else:
+            self.edge_index, self.edge_type = edge_index.to(device), edge_type.to(device)
+        self.encoder_fn = encoder_fn
+        self.emb = emb_full.to(device).clone().requires_grad_(True)
+        self.convs: List[torch.nn.Module] = [c.to(device) for c in convs]
+        self.params = [self.emb] + [p for c in self.convs for p in c.parameters()]
+        self._flat = torch.empty(sum(p.numel() for p in self.params), device=device, dtype=self.emb.dtype)
+        self._views, off = [], 0
+        for p in self.params:
+            self._views.append(self._flat[off: off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def step(self, cot: Tensor) -> Tensor:
+        """forward + backward for this rank's cotangent, then the cross-rank mean of every
+        parameter gradient (left in ``.grad``, identical on all ranks)."""
+        out = self.encoder_fn(self.emb, self.edge_index, self.edge_type, self.convs[0], self.convs[1])
+        for p in self.params:
+            p.grad = None
+        out.backward(cot)
+        torch._foreach_copy_(self._views, [p.grad for p in self.params])
+        dist.all_reduce(self._flat, group=self.group)
+        self._flat.div_(self.world)
+        for p, v in zip(self.params, self._views):
+            p.grad = v
+        return out

@@ -154,6 +154,54 @@ def test_partitioned_encoder_gloo(world, n, e):
     _check_partitioned(_run_partitioned(world, n, e, r, dims, seed, False), world, n, e, r, dims, seed)
 
 
+def _oracle_encoder(emb, ei, et, c1, c2):
+    return O.encoder_ref(emb, dict(c1.named_parameters()), dict(c2.named_parameters()), ei, et)
+
+
+def _replica_worker(rank, world, port, n, e, r, dims, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ei, et, emb, convs, _ = _make_problem(n, e, r, dims, seed)
+        enc = rdist.ReplicatedEncoder(ei, et, n, r, emb, convs, torch.device("cpu"), encoder_fn=_oracle_encoder)
+        cot = torch.randn(n, dims[2], generator=torch.Generator().manual_seed(100 + rank))   # this rank's batch
+        enc.step(cot)
+        q.put((rank, [p.grad.numpy().copy() for p in enc.params]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_replicated_encoder_gloo_averages_the_batches():
+    """batch-replica mode, world 2: every rank ends with the mean over ranks of the gradients a
+    single process computes for each rank's cotangent."""
+    world, n, e, r, dims, seed = 2, 80, 1200, 3, (16, 32, 32), 9
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(k, world, port, n, e, r, dims, seed, q)) for k in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ei, et, emb, convs, _ = _make_problem(n, e, r, dims, seed)
+    want = None
+    for rank in range(world):
+        cot = torch.randn(n, dims[2], generator=torch.Generator().manual_seed(100 + rank))
+        _, gemb, ps = _oracle_full(ei, et, emb, convs, cot)
+        grads = [gemb] + [ps[i][k].grad for i in range(2) for k, _ in convs[i].named_parameters()]
+        want = grads if want is None else [a + b for a, b in zip(want, grads)]
+    for rank in range(world):
+        for g, w in zip(got[rank], want):
+            torch.testing.assert_close(torch.from_numpy(g), w / world, rtol=1e-5, atol=1e-6)
+    for a, b in zip(got[0], got[1]):
+        assert (a == b).all()
+
+
 @pytest.mark.gpu
 def test_partitioned_encoder_hip_two_ranks():
     """two processes, both on the box's one GPU, the product HIP backend in each; collectives
