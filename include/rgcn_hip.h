@@ -200,6 +200,21 @@ int distmult_bwd(const float* grad_scores, const float* h, const int64_t* h_idx,
                  const int64_t* t_idx, const float* r, const int64_t* r_idx, int64_t batch,
                  int64_t d, float* grad_h, float* grad_t, float* grad_r, void* stream);
 
+/* The head fused with the training loss (SURVEY section 8f "next" row 1; reference
+ * `self.criterion = nn.BCEWithLogitsLoss()` src/train.py:139 applied to the scores at
+ * train.py:300): scores[b] as above and loss[b] = binary_cross_entropy_with_logits(scores[b],
+ * labels[b]) per sample (the caller takes the mean).  labels: float[batch] in {0, 1}. */
+int distmult_bce_fwd(const float* h, const int64_t* h_idx, const float* t, const int64_t* t_idx,
+                     const float* r, const int64_t* r_idx, const float* labels, int64_t batch,
+                     int64_t d, float* scores, float* loss, void* stream);
+/* Its backward in one launch: grad_scores[b] = grad_mean_loss[0] * (sigmoid(scores[b]) -
+ * labels[b]) / batch (autograd of mean(loss)), fed straight into the accumulation of
+ * distmult_bwd.  grad_mean_loss is a DEVICE pointer to one float (no host sync). */
+int distmult_bce_bwd(const float* grad_mean_loss, const float* scores, const float* labels,
+                     const float* h, const int64_t* h_idx, const float* t, const int64_t* t_idx,
+                     const float* r, const int64_t* r_idx, int64_t batch, int64_t d, float* grad_h,
+                     float* grad_t, float* grad_r, void* stream);
+
 /* Tail ranking for evaluation (LinkPredictor.score_all_tails rgcn.py:215-243 +
  * compute_ranking_metrics evaluate.py:260-276, without materialising the [B, N] score matrix
  * or sorting it): hr = head_emb * rel_emb rows [B, d]; scores[b, n] = <hr[b], emb[n]> on the

@@ -55,6 +55,8 @@ PROTOTYPES = {
     "distmult_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "distmult_rank_tails": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "distmult_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "distmult_bce_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
+    "distmult_bce_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
 }
 
 _lib = None

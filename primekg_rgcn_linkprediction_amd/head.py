@@ -81,6 +81,47 @@ class _RelationRows(torch.autograd.Function):
         return one_hot @ g, None
 
 
+class _DistMultBCEFunction(torch.autograd.Function):
+    """(mean binary_cross_entropy_with_logits(scores, labels), scores): the scoring kernel also
+    emits the per-sample loss, and ONE backward kernel turns the gradient of the mean loss into
+    the head / tail / relation gradients (sigmoid, subtraction, 1/B and the DistMult products
+    fused) - instead of the eight elementwise launches of BCEWithLogitsLoss around the head
+    (``src/train.py:300``).  ``scores`` is returned for the accuracy bookkeeping only."""
+
+    @staticmethod
+    def forward(ctx, h, h_idx, t, t_idx, r, r_idx, labels):
+        h, t, r = h.contiguous(), t.contiguous(), r.contiguous()
+        h_idx, t_idx, r_idx = (i.contiguous() if i is not None else None for i in (h_idx, t_idx, r_idx))
+        labels = labels.contiguous()
+        batch = (h_idx if h_idx is not None else h).size(0)
+        scores, per_sample = ops.distmult_bce_fwd(h, h_idx, t, t_idx, r, r_idx, labels, batch)
+        ctx.batch = batch
+        ctx.same_ht = h.data_ptr() == t.data_ptr() and h.shape == t.shape
+        ctx.save_for_backward(h, h_idx, t, t_idx, r, r_idx, labels, scores)
+        ctx.mark_non_differentiable(scores)
+        return per_sample.mean(), scores
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_scores):
+        h, h_idx, t, t_idx, r, r_idx, labels, scores = ctx.saved_tensors
+        need_h, _, need_t, _, need_r, _, _ = ctx.needs_input_grad
+
+        def buf(src, idx, need):
+            if not need:
+                return None
+            return torch.zeros_like(src) if idx is not None else torch.empty_like(src)
+
+        gh = buf(h, h_idx, need_h)
+        shared = ctx.same_ht and need_h and need_t and h_idx is not None and t_idx is not None
+        gt = gh if shared else buf(t, t_idx, need_t)
+        gr = buf(r, r_idx, need_r)
+        ops.distmult_bce_bwd(g_loss.reshape(1).contiguous(), scores, labels, h, h_idx, t, t_idx, r, r_idx,
+                             ctx.batch, gh, gt, gr)
+        if shared:
+            return gh, None, None, None, gr, None, None
+        return gh, None, gt, None, gr, None, None
+
+
 def distmult(h, h_idx, t, t_idx, r, r_idx) -> Tensor:
     return _DistMultFunction.apply(h, h_idx, t, t_idx, r, r_idx)
 
@@ -119,6 +160,13 @@ class LinkPredictor(nn.Module):
         materialising the two [B, d] gathers."""
         r, r_idx = self._relation_operand(relation_types)
         return distmult(node_embeddings, head_indices, node_embeddings, tail_indices, r, r_idx)
+
+    def bce_loss(self, node_embeddings: Tensor, head_indices: Tensor, tail_indices: Tensor,
+                 relation_types: Tensor, labels: Tensor):
+        """``(BCEWithLogitsLoss()(score_triples(...), labels), scores)`` as one fused node."""
+        r, r_idx = self._relation_operand(relation_types)
+        return _DistMultBCEFunction.apply(node_embeddings, head_indices, node_embeddings, tail_indices,
+                                          r, r_idx, labels)
 
     @torch.no_grad()
     def rank_tails(self, head_embeddings: Tensor, relation_types: Tensor, all_tail_embeddings: Tensor,

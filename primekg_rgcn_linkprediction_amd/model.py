@@ -86,6 +86,13 @@ class DrugDiseaseModel(nn.Module):
         # rgcn.py:325-329: two row gathers + decoder, fused into one scoring kernel
         return self.decoder.score_triples(node_embeddings, head_indices, tail_indices, relation_types)
 
+    def bce_loss(self, edge_index: Tensor, edge_type: Tensor, head_indices: Tensor, tail_indices: Tensor,
+                 relation_types: Tensor, labels: Tensor):
+        """``(nn.BCEWithLogitsLoss()(self(...), labels), scores)`` - what ``Trainer`` needs per
+        step (``train.py:291-300``) with the loss fused into the head kernels."""
+        node_embeddings = self.encoder(edge_index, edge_type)
+        return self.decoder.bce_loss(node_embeddings, head_indices, tail_indices, relation_types, labels)
+
     def predict(self, edge_index: Tensor, edge_type: Tensor, head_indices: Tensor,
                 tail_indices: Tensor, relation_types: Tensor) -> Tensor:
         self.eval()

@@ -476,6 +476,44 @@ def distmult_fwd(h, h_idx, t, t_idx, r, r_idx, batch: int) -> torch.Tensor:
     return scores
 
 
+def distmult_bce_fwd(h, h_idx, t, t_idx, r, r_idx, labels, batch: int):
+    """-> (scores [B], per-sample binary_cross_entropy_with_logits(scores, labels) [B]) in one launch."""
+    d = h.size(1)
+    for name, m, i in (("head", h, h_idx), ("tail", t, t_idx), ("rel", r, r_idx)):
+        _check_operand(name, m, i, batch)
+        if m.size(1) != d:
+            raise ValueError("head / tail / relation embedding dims differ")
+    if d % 4:
+        raise ValueError("embedding dim must be a multiple of 4")
+    _need_gpu("labels", labels, torch.float32)
+    if labels.shape != (batch,):
+        raise ValueError(f"labels must be [{batch}], got {tuple(labels.shape)}")
+    lib = _lib.load()
+    with torch.cuda.device(h.device):
+        scores = torch.empty(batch, dtype=torch.float32, device=h.device)
+        loss = torch.empty(batch, dtype=torch.float32, device=h.device)
+        rc = lib.distmult_bce_fwd(_ptr(h), _ptr(h_idx), _ptr(t), _ptr(t_idx), _ptr(r), _ptr(r_idx), _ptr(labels),
+                                  batch, d, _ptr(scores), _ptr(loss), _stream())
+    _lib.check(rc, "distmult_bce_fwd")
+    return scores, loss
+
+
+def distmult_bce_bwd(grad_mean_loss, scores, labels, h, h_idx, t, t_idx, r, r_idx, batch: int,
+                     grad_h, grad_t, grad_r) -> None:
+    """Backward of ``mean(bce_with_logits(distmult(...), labels))``; ``grad_mean_loss`` is a
+    one-element device tensor.  Accumulates like ``distmult_bwd``."""
+    _need_gpu("grad_mean_loss", grad_mean_loss, torch.float32)
+    if grad_mean_loss.numel() != 1:
+        raise ValueError("grad_mean_loss must hold one float")
+    d = h.size(1)
+    lib = _lib.load()
+    with torch.cuda.device(h.device):
+        rc = lib.distmult_bce_bwd(_ptr(grad_mean_loss), _ptr(scores), _ptr(labels), _ptr(h), _ptr(h_idx), _ptr(t),
+                                  _ptr(t_idx), _ptr(r), _ptr(r_idx), batch, d, _ptr(grad_h), _ptr(grad_t),
+                                  _ptr(grad_r), _stream())
+    _lib.check(rc, "distmult_bce_bwd")
+
+
 def distmult_bwd(gs, h, h_idx, t, t_idx, r, r_idx, batch: int, grad_h, grad_t, grad_r) -> None:
     """Accumulates into caller-provided (zeroed where indexed) gradient buffers."""
     _need_gpu("grad_scores", gs, torch.float32)

@@ -117,8 +117,12 @@ class Trainer:
         """One batch of positives: negatives, forward over the train graph, BCE, backward and
         (when ``update``) clip + optimizer step; running loss / hits stay on the device."""
         heads, tails, rels, labels = self._with_negatives(head, tail, rel)
-        scores = self.model(self.train_edge_index, self.train_edge_type, heads, tails, rels)
-        loss = self.criterion(scores, labels)
+        if isinstance(self.criterion, nn.BCEWithLogitsLoss) and hasattr(self.model, "bce_loss"):
+            loss, scores = self.model.bce_loss(self.train_edge_index, self.train_edge_type, heads, tails, rels,
+                                               labels)                  # the criterion fused into the head
+        else:
+            scores = self.model(self.train_edge_index, self.train_edge_type, heads, tails, rels)
+            loss = self.criterion(scores, labels)
         (loss / accum if accum > 1 else loss).backward()
         if update:
             if self.args.grad_clip > 0:

@@ -352,6 +352,41 @@ def test_training_step_matches_reference_run():
         assert_grad(p.grad, t["grad__" + name.replace(".", "__")])
 
 
+def test_fused_bce_head_matches_reference_run_and_torch():
+    """model.bce_loss (loss fused into the head kernels) vs the reference-run training step
+    (loss and every parameter gradient), and vs torch's BCEWithLogitsLoss on large logits."""
+    dev = need_gpu()
+    z, t = load_golden("ref_model_eval.npz"), load_golden("ref_model_train_step.npz")
+    m = _load_ref_model(z, dev, dropout=0.0, decoder_dropout=0.0).train()
+    loss, scores = m.bce_loss(z["edge_index"].to(dev), z["edge_type"].to(dev), z["head"].to(dev),
+                              z["tail"].to(dev), z["rel"].to(dev), t["labels"].to(dev))
+    assert_fwd(scores, t["scores"])
+    assert abs(loss.item() - t["loss"].item()) <= 1e-6
+    (loss * 0.5).backward()                                 # a non-unit upstream gradient must flow through
+    for name, p in m.named_parameters():
+        assert_grad(p.grad * 2, t["grad__" + name.replace(".", "__")])
+    # saturated logits, duplicate rows, relation-dropout rows ([B, d] operand) vs torch ops
+    gen = torch.Generator().manual_seed(6)
+    emb = (torch.randn(40, 64, generator=gen) * 3).to(dev)
+    hi, ti = torch.randint(0, 40, (1000,), generator=gen).to(dev), torch.randint(0, 6, (1000,), generator=gen).to(dev)
+    ri = torch.randint(0, 3, (1000,), generator=gen).to(dev)
+    y = (torch.rand(1000, generator=gen) < 0.5).float().to(dev)
+    for p_drop in (0.0, 0.3):
+        dec = LinkPredictor(3, 64, dropout=p_drop).to(dev).train()
+        e1, e2 = emb.clone().requires_grad_(True), emb.clone().requires_grad_(True)
+        torch.manual_seed(9)
+        loss1, sc1 = dec.bce_loss(e1, hi, ti, ri, y)
+        g1 = torch.autograd.grad(loss1, [e1, dec.relation_embeddings.weight])
+        torch.manual_seed(9)
+        sc2 = dec.score_triples(e2, hi, ti, ri)
+        loss2 = torch.nn.BCEWithLogitsLoss()(sc2, y)
+        g2 = torch.autograd.grad(loss2, [e2, dec.relation_embeddings.weight])
+        assert sc1.abs().max() > 30                          # the stable form is exercised
+        assert torch.equal(sc1, sc2) and abs(loss1.item() - loss2.item()) <= 1e-5 * max(1.0, abs(loss2.item()))
+        for a, b in zip(g1, g2):
+            assert_grad(a, b.cpu(), 1e-5)
+
+
 def test_link_predictor_matches_reference_run():
     dev = need_gpu()
     z = load_golden("ref_link_predictor.npz")
