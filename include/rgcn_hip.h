@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 4
+#define RGCN_ABI_VERSION 5
 
 enum {
   RGCN_OK = 0,
@@ -214,6 +214,21 @@ int distmult_bce_bwd(const float* grad_mean_loss, const float* scores, const flo
                      const float* h, const int64_t* h_idx, const float* t, const int64_t* t_idx,
                      const float* r, const int64_t* r_idx, int64_t batch, int64_t d, float* grad_h,
                      float* grad_t, float* grad_r, void* stream);
+
+/* Mini-batch assembly on the device (SURVEY section 8f "next" row 1): the batch slice of the
+ * shuffled train columns (src/train.py:223-245), NegativeSampler.sample (train.py:59-97) and the
+ * positives + negatives + labels concatenation (train.py:281-288) in one launch.
+ *   sample i <  batch : column order[cursor[0] + i] of (edge_index [2, E], edge_type [E]), label 1
+ *   sample batch + j  : positive j / num_neg with its head (fair coin) or else its tail replaced
+ *                       by a uniform node of [0, num_nodes), label 0
+ * order: int64[E] (NULL = identity); cursor: DEVICE int64[1] (NULL = 0), so the launch can be
+ * replayed from a HIP graph; rng: DEVICE int64[2] = {seed, epoch}: Philox4x32-10 keyed by the
+ * seed, counter = (cursor*num_neg + j, epoch).  Outputs hold batch*(1+num_neg) entries.
+ * Positions / columns outside [0, E) are clamped, never dereferenced. */
+int rgcn_sample_batch(const int64_t* edge_index, const int64_t* edge_type, int64_t num_edges,
+                      const int64_t* order, const int64_t* cursor, int64_t batch, int64_t num_neg,
+                      int64_t num_nodes, const int64_t* rng, int64_t* heads, int64_t* tails,
+                      int64_t* rels, float* labels, void* stream);
 
 /* Tail ranking for evaluation (LinkPredictor.score_all_tails rgcn.py:215-243 +
  * compute_ranking_metrics evaluate.py:260-276, without materialising the [B, N] score matrix

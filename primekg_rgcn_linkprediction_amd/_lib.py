@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_p
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -55,6 +55,7 @@ PROTOTYPES = {
     "distmult_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "distmult_rank_tails": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "distmult_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "rgcn_sample_batch": (c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "distmult_bce_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "distmult_bce_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
 }

@@ -476,6 +476,47 @@ def distmult_fwd(h, h_idx, t, t_idx, r, r_idx, batch: int) -> torch.Tensor:
     return scores
 
 
+def sample_batch(edge_index: torch.Tensor, edge_type: torch.Tensor, order: Optional[torch.Tensor],
+                 cursor: Optional[torch.Tensor], batch: int, num_neg: int, num_nodes: int,
+                 rng: Optional[torch.Tensor]):
+    """One training mini-batch assembled on the device (``rgcn_sample_batch``): positives =
+    columns ``order[cursor : cursor + batch]``, then ``num_neg`` corruptions of each (head or
+    tail, fair coin, uniform replacement), then labels.  ``cursor`` (int64[1]) and ``rng``
+    (int64[2] = seed, epoch) are DEVICE tensors.  -> (heads, tails, rels int64[B(1+k)], labels f32)."""
+    _need_gpu("edge_index", edge_index, torch.int64)
+    _need_gpu("edge_type", edge_type, torch.int64)
+    if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_type.shape != (edge_index.size(1),):
+        raise ValueError("edge_index must be [2, E] and edge_type [E]")
+    e = edge_index.size(1)
+    if order is not None:
+        _need_gpu("order", order, torch.int64)
+        if order.shape != (e,):
+            raise ValueError(f"order must be [{e}]")
+    if cursor is not None:
+        _need_gpu("cursor", cursor, torch.int64)
+        if cursor.numel() != 1:
+            raise ValueError("cursor must hold one int64")
+    if num_neg > 0:
+        if rng is None:
+            raise ValueError("rng (int64[2]: seed, epoch) is needed to draw negatives")
+        _need_gpu("rng", rng, torch.int64)
+        if rng.numel() != 2:
+            raise ValueError("rng must hold two int64 (seed, epoch)")
+    if batch < 0 or num_neg < 0 or (batch > 0 and e == 0):
+        raise ValueError("batch / num_neg must be >= 0 and the graph must have columns")
+    total = batch * (1 + num_neg)
+    lib = _lib.load()
+    with torch.cuda.device(edge_index.device):
+        heads = torch.empty(total, dtype=torch.int64, device=edge_index.device)
+        tails, rels = torch.empty_like(heads), torch.empty_like(heads)
+        labels = torch.empty(total, dtype=torch.float32, device=edge_index.device)
+        rc = lib.rgcn_sample_batch(_ptr(edge_index), _ptr(edge_type), e, _ptr(order), _ptr(cursor), batch, num_neg,
+                                   int(num_nodes), _ptr(rng), _ptr(heads), _ptr(tails), _ptr(rels), _ptr(labels),
+                                   _stream())
+    _lib.check(rc, "rgcn_sample_batch")
+    return heads, tails, rels, labels
+
+
 def distmult_bce_fwd(h, h_idx, t, t_idx, r, r_idx, labels, batch: int):
     """-> (scores [B], per-sample binary_cross_entropy_with_logits(scores, labels) [B]) in one launch."""
     d = h.size(1)

@@ -10,9 +10,13 @@ full graph (``train.py:389-395``), so a reference user can run
     python -m primekg_rgcn_linkprediction_amd.train --data_dir data/processed --epochs 100
 
 and get checkpoints with the reference's keys (``train.py:431-442``).  What differs, on
-purpose: the model is this package's ``DrugDiseaseModel`` (HIP kernels), and the running
-loss / accuracy are accumulated on the device and read back once per epoch instead of two
-``.item()`` host syncs per step (``train.py:322,325``).
+purpose: the model is this package's ``DrugDiseaseModel`` (HIP kernels); the running loss /
+accuracy are accumulated on the device and read back once per epoch instead of two ``.item()``
+host syncs per step (``train.py:322,325``); a mini-batch (slice of the shuffled columns,
+negatives, labels) is assembled by one kernel (``--torch_sampler`` restores the reference's
+``torch.rand`` / ``torch.randint`` sequence); BCE-with-logits is fused into the head kernels;
+the optimizer is torch's single-kernel (fused) Adam; and the whole step is one captured HIP
+graph replayed per batch (``--no_hip_graph`` launches it eagerly).  Same update rule throughout.
 
 ``--synthetic`` builds a PrimeKG-shaped random graph instead of loading ``--data_dir`` (the
 reference's ``train_data.pt`` / ``full_graph.pt`` blobs are not in its mount).
@@ -87,6 +91,9 @@ class Trainer:
         extra = {"fused": True, "capturable": self.use_hip_graph} if device.type == "cuda" else {}
         self.optimizer = opt(self.model.parameters(), lr=args.lr, weight_decay=args.weight_decay, **extra)
         self._graph = self._loss_sum = None
+        # mini-batch assembly (slice + negatives + labels) as one kernel; --torch_sampler keeps the
+        # reference's op-by-op sampler on torch's RNG stream
+        self.device_sampler = device.type == "cuda" and not getattr(args, "torch_sampler", False)
         self.criterion = nn.BCEWithLogitsLoss()
         self.neg_sampler = NegativeSampler(train_data["num_nodes"], args.num_neg_samples)
         self.best_val_loss, self.best_val_acc = float("inf"), 0.0
@@ -113,10 +120,24 @@ class Trainer:
         return torch.cat([head, nh]), torch.cat([tail, nt]), torch.cat([rel, nr]), labels
 
     # -- one epoch ----------------------------------------------------------------------
-    def _step(self, head, tail, rel, accum: int = 1, update: bool = True):
-        """One batch of positives: negatives, forward over the train graph, BCE, backward and
-        (when ``update``) clip + optimizer step; running loss / hits stay on the device."""
-        heads, tails, rels, labels = self._with_negatives(head, tail, rel)
+    def _make_batch(self, lo: int, size: int):
+        """(heads, tails, rels, labels) of train columns ``order[lo : lo + size]`` plus their
+        negatives.  Device sampler: one launch reading the position from ``self._cursor``;
+        ``--torch_sampler``: the reference's op sequence on torch's RNG stream."""
+        if self.device_sampler:
+            from . import ops
+            return ops.sample_batch(self.train_edge_index, self.train_edge_type, self._order, self._cursor, size,
+                                    self.neg_sampler.num_neg_samples, self.neg_sampler.num_nodes, self._rng)
+        idx = self._order.index_select(0, self._arange[:size] + self._cursor)
+        return self._with_negatives(self.train_edge_index[0].index_select(0, idx),
+                                    self.train_edge_index[1].index_select(0, idx),
+                                    self.train_edge_type.index_select(0, idx))
+
+    def _step(self, lo: int, size: int, accum: int = 1, update: bool = True):
+        """One batch: assembly, forward over the train graph, BCE, backward and (when
+        ``update``) clip + optimizer step; running loss / hits stay on the device.  ``lo`` is
+        only documentation here - the position is whatever ``self._cursor`` holds."""
+        heads, tails, rels, labels = self._make_batch(lo, size)
         if isinstance(self.criterion, nn.BCEWithLogitsLoss) and hasattr(self.model, "bce_loss"):
             loss, scores = self.model.bce_loss(self.train_edge_index, self.train_edge_type, heads, tails, rels,
                                                labels)                  # the criterion fused into the head
@@ -134,18 +155,14 @@ class Trainer:
         return heads, tails, rels, labels, loss.detach()
 
     def _capture_step(self, batch: int) -> None:
-        """Record ``_step`` on the batch ``order[cursor : cursor+batch]`` (``order``, ``cursor`` and
-        the running sums are device-resident and keep their addresses), so a full-size batch is
-        one graph replay with no host work besides setting the cursor.  Called after at least
-        one eager step (graph bucketed, optimizer state allocated)."""
-        self._arange = torch.arange(batch, device=self.device)
+        """Record ``_step`` on the batch at ``self._cursor`` (``order``, ``cursor``, the RNG
+        state and the running sums are device-resident and keep their addresses), so a
+        full-size batch is one graph replay with no host work besides setting the cursor.
+        Called after at least one eager step (graph bucketed, optimizer state allocated)."""
         graph = torch.cuda.CUDAGraph()
         self.optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(graph):
-            idx = self._order.index_select(0, self._arange + self._cursor)
-            self._static = self._step(self.train_edge_index[0].index_select(0, idx),
-                                      self.train_edge_index[1].index_select(0, idx),
-                                      self.train_edge_type.index_select(0, idx))
+            self._static = self._step(0, batch)
         self.optimizer.zero_grad(set_to_none=True)      # eager steps get fresh grads; replays use the graph's own
         self._graph, self._graph_batch = graph, batch
 
@@ -159,9 +176,13 @@ class Trainer:
             self._loss_sum = torch.zeros((), device=self.device, dtype=torch.float64)
             self._correct = torch.zeros((), device=self.device, dtype=torch.int64)
             self._order = torch.empty(e, device=self.device, dtype=torch.int64)
-            self._cursor = torch.zeros((), device=self.device, dtype=torch.int64)
+            self._cursor = torch.zeros(1, device=self.device, dtype=torch.int64)
+            self._arange = torch.arange(bsz, device=self.device)
+            # Philox key = the run's seed, stream = epoch (device sampler)
+            self._rng = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64).to(self.device)
         self._loss_sum.zero_()
         self._correct.zero_()
+        self._rng[1] += 1
         # the permutation is drawn on the host like the reference's torch.randperm(num_edges)
         self._order.copy_(torch.randperm(e))
         steps = -(-e // bsz)
@@ -171,18 +192,16 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         for step in range(steps):
             lo, hi = step * bsz, min((step + 1) * bsz, e)
+            self._cursor.fill_(lo)
             replayable = self.use_hip_graph and hi - lo == bsz
             if replayable and step >= 1 and (self._graph is None or self._graph_batch != bsz):
                 self._capture_step(bsz)
             if replayable and self._graph is not None and self._graph_batch == bsz:
-                self._cursor.fill_(lo)
                 self._graph.replay()
                 out = self._static
             else:
-                idx = self._order[lo:hi]
                 last = (step + 1) % accum == 0 or step + 1 == steps
-                out = self._step(self.train_edge_index[0, idx], self.train_edge_index[1, idx],
-                                 self.train_edge_type[idx], accum=accum, update=last)
+                out = self._step(lo, hi - lo, accum=accum, update=last)
                 if last:
                     self.optimizer.zero_grad(set_to_none=True)
             seen += (hi - lo) * (1 + self.neg_sampler.num_neg_samples)
@@ -335,6 +354,9 @@ def build_parser() -> argparse.ArgumentParser:
                    help="gather neighbour rows from an fp16 copy of the feature table (fp32 accumulate)")
     p.add_argument("--bucket_cache", action="store_true",
                    help="persist / reuse the bucketed graph structure next to the .pt files in --data_dir")
+    p.add_argument("--torch_sampler", action="store_true",
+                   help="draw negatives with the reference's torch.rand/randint sequence instead of the "
+                        "one-kernel device sampler")
     p.add_argument("--no_hip_graph", action="store_true",
                    help="launch every training step eagerly instead of replaying one captured HIP graph")
     p.add_argument("--synthetic", action="store_true",

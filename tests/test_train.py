@@ -56,8 +56,52 @@ def _args(**kw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hip_graph", [False, True])
-def test_trainer_steps_match_oracle_on_the_same_batches(tmp_path, hip_graph):
+def test_device_sampler_follows_the_reference_protocol():
+    """rgcn_sample_batch vs train.py:223-245 / 59-97 / 281-288: positives are the ordered slice,
+    each negative keeps exactly the other endpoint and the relation of ITS positive, labels are
+    1s then 0s, the coin is fair, replacements are uniform, and (seed, epoch, position) fixes the draw."""
+    dev = need_gpu()
+    from primekg_rgcn_linkprediction_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    n, e, b, k = 1000, 50000, 4096, 3
+    ei = torch.randint(0, n, (2, e), generator=gen).to(dev)
+    et = torch.randint(0, 3, (e,), generator=gen).to(dev)
+    order = torch.randperm(e, generator=gen).to(dev)
+    cursor = torch.tensor([8192], device=dev)
+    rng = torch.tensor([1234, 1], device=dev)
+    h, t, r, y = ops.sample_batch(ei, et, order, cursor, b, k, n, rng)
+    idx = order[8192: 8192 + b]
+    assert torch.equal(h[:b], ei[0, idx]) and torch.equal(t[:b], ei[1, idx]) and torch.equal(r[:b], et[idx])
+    assert torch.equal(y, torch.cat([torch.ones(b), torch.zeros(b * k)]).to(dev))
+    ph, pt, pr = (v[:b].repeat_interleave(k) for v in (h, t, r))
+    nh, nt, nr = h[b:], t[b:], r[b:]
+    assert torch.equal(nr, pr)
+    keeps_tail, keeps_head = nt == pt, nh == ph
+    assert bool((keeps_tail | keeps_head).all())
+    head_replaced = (keeps_tail & ~keeps_head).float().mean().item()       # ~0.5 (ties are ~1/n)
+    assert abs(head_replaced - 0.5) < 0.03
+    repl = torch.where(keeps_tail & ~keeps_head, nh, nt)
+    assert int(repl.min()) >= 0 and int(repl.max()) < n
+    counts = torch.bincount(repl, minlength=n).float()
+    assert counts.min() > 0 and abs(counts.mean().item() - b * k / n) < 1e-3 and counts.std() < 2.0 * (b * k / n) ** 0.5
+    again = ops.sample_batch(ei, et, order, cursor, b, k, n, rng)
+    assert all(torch.equal(a, c) for a, c in zip((h, t, r, y), again))
+    other = ops.sample_batch(ei, et, order, cursor, b, k, n, torch.tensor([1234, 2], device=dev))
+    assert not torch.equal(other[0][b:], nh) and torch.equal(other[0][:b], h[:b])
+    # identity order, no cursor, no negatives; a window hanging over the end is clamped, not read past
+    h0, t0, r0, y0 = ops.sample_batch(ei, et, None, None, 10, 0, n, None)
+    assert torch.equal(h0, ei[0, :10]) and torch.equal(r0, et[:10]) and bool((y0 == 1).all())
+    hz = ops.sample_batch(ei, et, None, torch.tensor([e - 2], device=dev), 4, 0, n, None)[0]
+    assert torch.equal(hz, ei[0, [e - 2, e - 1, e - 1, e - 1]])
+    with pytest.raises(ValueError):
+        ops.sample_batch(ei, et, order[:-1], cursor, b, k, n, rng)
+    with pytest.raises(RuntimeError):
+        ops.sample_batch(ei.cpu(), et.cpu(), None, None, 4, 0, n, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hip_graph,torch_sampler", [(False, True), (True, True), (False, False), (True, False)])
+def test_trainer_steps_match_oracle_on_the_same_batches(tmp_path, hip_graph, torch_sampler):
     """Five optimizer steps (Adam, clip 1.0, dropout 0) on the HIP model vs the oracle model
     fed the recorded batches: per-step loss and the parameters afterwards agree -- launched
     eagerly, and with steps 2-5 as replays of the captured whole-step HIP graph."""
@@ -69,7 +113,7 @@ def test_trainer_steps_match_oracle_on_the_same_batches(tmp_path, hip_graph):
     et = torch.randint(0, r, (6000,), generator=gen)
     data = {"edge_index": ei, "edge_type": et, "num_nodes": n, "num_relations": r}
     args = _args(dropout=0.0, decoder_dropout=0.0, batch_size=256, output_dir=str(tmp_path), device="cuda",
-                 no_hip_graph=not hip_graph)
+                 no_hip_graph=not hip_graph, torch_sampler=torch_sampler)
     model = T.create_model(n, r, args)
     ref_state = {k: v.clone() for k, v in model.state_dict().items()}
     trainer = T.Trainer(model, data, data, data, dev, args)
