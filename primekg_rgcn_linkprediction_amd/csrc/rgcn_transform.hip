@@ -456,8 +456,20 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restri
   __shared__ __attribute__((aligned(16))) float sA[32 * TKC];
   __shared__ __attribute__((aligned(16))) float sG[32 * 128];
   const int Kc = K1 + K2;
-  const int kc0 = (blockIdx.x / n_tiles) * TKC, n0 = (blockIdx.x % n_tiles) * 128;
-  const int split = blockIdx.y;
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id.  All tiles of one row split read
+  // the same rows of G, so a split's tiles are placed on ONE XCD (split = xcd mod 8): its L2 then
+  // serves G once per split instead of once per tile and XCD.  Pure placement: same work, same sums.
+  int bx = blockIdx.x, split = blockIdx.y;
+  {
+    const int gx = (int)gridDim.x, full = ((int)gridDim.y >> 3) << 3;      // splits placed 8 at a time
+    const int lin = blockIdx.y * gx + blockIdx.x;
+    if (lin < gx * full) {
+      const int q = lin >> 3;
+      bx = q % gx;
+      split = (q / gx) * 8 + (lin & 7);
+    }                                                                     // the last gridDim.y % 8 splits: as launched
+  }
+  const int kc0 = (bx / n_tiles) * TKC, n0 = (bx % n_tiles) * 128;
   const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -555,8 +567,20 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
   constexpr int A_PW = 2, G_PW = 4, P = A_PW + G_PW;            // LDS-DMA instructions per wave and m-tile
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF_FLOATS];   // the ONLY LDS object
   const int Kc = K1 + K2;
-  const int kc0 = (blockIdx.x / n_tiles) * TKC, n0 = (blockIdx.x % n_tiles) * 128;
-  const int split = blockIdx.y;
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id.  All tiles of one row split read
+  // the same rows of G, so a split's tiles are placed on ONE XCD (split = xcd mod 8): its L2 then
+  // serves G once per split instead of once per tile and XCD.  Pure placement: same work, same sums.
+  int bx = blockIdx.x, split = blockIdx.y;
+  {
+    const int gx = (int)gridDim.x, full = ((int)gridDim.y >> 3) << 3;      // splits placed 8 at a time
+    const int lin = blockIdx.y * gx + blockIdx.x;
+    if (lin < gx * full) {
+      const int q = lin >> 3;
+      bx = q % gx;
+      split = (q / gx) * 8 + (lin & 7);
+    }                                                                     // the last gridDim.y % 8 splits: as launched
+  }
+  const int kc0 = (bx / n_tiles) * TKC, n0 = (bx % n_tiles) * 128;
   const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
   const int tid = threadIdx.x, lane = tid & 63;
