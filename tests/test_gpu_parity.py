@@ -676,3 +676,54 @@ def test_config_c5_fp16_features_vs_fp32_oracle():
         a.load_state_dict(b.state_dict())
     out32 = rgcn_encoder2(emb.to(dev), ei.to(dev), et.to(dev), convs32[0], convs32[1])
     assert not torch.equal(out32, out.detach())
+
+
+# ------------------------------------------------------------------ C ABI called directly, device-side error paths
+def test_c_abi_error_codes_with_real_handles():
+    """what only shows with a live handle: short workspace, a direction a shard does not have,
+    widths the kernels do not take, levels out of range - each a return code, never a fault."""
+    import ctypes
+    from primekg_rgcn_linkprediction_amd import _lib
+    dev = need_gpu()
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    ei = torch.zeros(2, 500, dtype=torch.int64)
+    ei[0] = torch.arange(500) % 50                        # node 0 receives 500 edges of one relation: partial rows
+    g = ops.BucketedGraph(ei.to(dev), torch.zeros(500, dtype=torch.int64, device=dev), 50, 2)
+    d = 64
+    need = lib.rgcn_aggregate_workspace_bytes(g.handle, 0, d)
+    assert need == 8 * d * 4                              # ceil(500 / 64) partial rows
+    x = torch.randn(50, d, device=dev)
+    agg = torch.empty(100, d, device=dev)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    P = lambda t: t.data_ptr()                            # noqa: E731
+    assert lib.rgcn_aggregate(g.handle, 0, P(x), d, P(agg), P(ws), need - 1, stream) == _lib.RGCN_ERR_WORKSPACE
+    assert lib.rgcn_aggregate(g.handle, 0, P(x), d, P(agg), None, 0, stream) == _lib.RGCN_ERR_WORKSPACE
+    assert lib.rgcn_aggregate(g.handle, 0, P(x), 6, P(agg), P(ws), need, stream) == _lib.RGCN_ERR_ARG
+    assert lib.rgcn_aggregate(g.handle, 0, None, d, P(agg), P(ws), need, stream) == _lib.RGCN_ERR_ARG
+    assert lib.rgcn_aggregate_f16(g.handle, 0, P(x), 68, P(agg), P(ws), need * 2, stream) == _lib.RGCN_ERR_ARG   # d % 8
+    assert lib.rgcn_aggregate_level(g.handle, 0, 7, P(x), d, P(agg), P(ws), need, stream) == _lib.RGCN_ERR_ARG
+    assert lib.rgcn_aggregate(g.handle, 0, P(x), d, P(agg), P(ws), need, stream) == _lib.RGCN_OK
+    torch.cuda.synchronize()
+    assert_fwd(agg.view(50, -1), O.mean_aggregate_ref(x.cpu(), ei, torch.zeros(500, dtype=torch.int64), 2).view(50, -1))
+    # a shard handle has one direction
+    sh = ops.BucketedGraph.from_shard(ei[1].to(dev), ei[0].to(dev), torch.zeros(500, dtype=torch.int64, device=dev),
+                                      50, 50, 2)
+    assert lib.rgcn_aggregate(sh.handle, 1, P(x), d, P(agg), P(ws), need, stream) == _lib.RGCN_ERR_ARG
+    assert lib.rgcn_graph_export(sh.handle, 1, None, None, None, None, stream) == _lib.RGCN_ERR_ARG
+    # parameter-gradient workspace
+    nb = lib.rgcn_transform_bwd_params_workspace_bytes(50, 2, d, d)
+    gw, gr_, gb = torch.empty(2, d, d, device=dev), torch.empty(d, d, device=dev), torch.empty(d, device=dev)
+    gout = torch.randn(50, d, device=dev)
+    assert lib.rgcn_transform_bwd_params(P(agg), P(x), P(gout), None, 50, 2, d, d, P(gw), P(gr_), P(gb), None, 0,
+                                         stream) == _lib.RGCN_ERR_WORKSPACE
+    wsp = torch.empty(nb, dtype=torch.uint8, device=dev)
+    assert lib.rgcn_transform_bwd_params(P(agg), P(x), P(gout), None, 50, 2, d, d, P(gw), P(gr_), P(gb), P(wsp), nb,
+                                         stream) == _lib.RGCN_OK
+    torch.cuda.synchronize()
+    assert_grad(gb, gout.sum(0).cpu())
+    out = ctypes.c_void_p()
+    bad = torch.tensor([[0, 7], [1, 0]], device=dev)
+    assert lib.rgcn_graph_create(P(bad), P(torch.zeros(2, dtype=torch.int64, device=dev)), 2, 5, 1, stream,
+                                 ctypes.byref(out)) == _lib.RGCN_ERR_RANGE
+    assert out.value is None

@@ -48,6 +48,31 @@ def test_null_handle_and_bad_args_return_codes_without_a_gpu():
     assert lib.distmult_fwd(None, None, None, None, None, None, 4, 6, None, None) == _lib.RGCN_ERR_ARG
     assert lib.distmult_fwd(None, None, None, None, None, None, 0, 8, None, None) == _lib.RGCN_OK
     assert lib.rgcn_transform_bwd_params_workspace_bytes(30926, 3, 128, 128) > 0
+    # every entry point rejects bad sizes / null pointers before it touches the device
+    import ctypes
+    out = ctypes.c_void_p()
+    E, A, U = _lib.RGCN_ERR_ARG, _lib.RGCN_ERR_ARG, _lib.RGCN_ERR_UNSUPPORTED
+    assert lib.rgcn_graph_create(None, None, -1, 5, 3, None, ctypes.byref(out)) == E
+    assert lib.rgcn_graph_create(None, None, 4, 5, 3, None, ctypes.byref(out)) == E         # edges but no arrays
+    assert lib.rgcn_graph_create(None, None, 0, 5, 0, None, ctypes.byref(out)) == E         # R = 0
+    assert lib.rgcn_graph_create(None, None, 0, 5, 3, None, None) == E                      # no place for the handle
+    assert lib.rgcn_graph_create(None, None, 0, 1 << 31, 3, None, ctypes.byref(out)) == U   # N*R over int32
+    assert lib.rgcn_graph_create_bipartite(None, None, None, 2, 3, 3, 1, None, None, ctypes.byref(out)) == E
+    assert lib.rgcn_graph_import(0, 3, 2, None, None, None, None, None, None, None, None, None, ctypes.byref(out)) == E
+    assert lib.rgcn_graph_export(None, 0, None, None, None, None, None) == E
+    assert out.value is None
+    assert lib.rgcn_transform_fwd(None, None, None, None, None, 0, None, 10, 3, 6, 8, None, None) == A   # d_in % 4
+    assert lib.rgcn_transform_fwd(None, None, None, None, None, 0, None, 10, 3, 8, 8, None, None) == A   # null operands
+    assert lib.rgcn_transform_bwd_input(None, None, None, None, None, None, 10, 0, 8, 8, None, None) == A
+    assert lib.rgcn_transform_bwd_params(None, None, None, None, 10, 3, 8, 8, None, None, None, None, 0, None) == A
+    assert lib.distmult_bwd(None, None, None, None, None, None, None, 4, 8, None, None, None, None) == E
+    assert lib.distmult_bce_fwd(None, None, None, None, None, None, None, 4, 8, None, None, None) == E
+    assert lib.distmult_bce_bwd(None, None, None, None, None, None, None, None, None, 4, 8, None, None, None, None) == E
+    assert lib.distmult_bce_fwd(None, None, None, None, None, None, None, 0, 8, None, None, None) == _lib.RGCN_OK
+    assert lib.distmult_rank_tails(None, None, None, None, 4, 100, 48, None, None) != _lib.RGCN_OK       # d % 32
+    assert lib.rgcn_sample_batch(None, None, 10, None, None, 4, 1, 0, None, None, None, None, None, None) == E
+    assert lib.rgcn_sample_batch(None, None, 10, None, None, 4, 1, 100, None, None, None, None, None, None) == E
+    assert lib.rgcn_sample_batch(None, None, 10, None, None, 0, 1, 100, None, None, None, None, None, None) == _lib.RGCN_OK
 
 
 def test_missing_library_fails_loudly(monkeypatch):
