@@ -786,13 +786,22 @@ struct SplitPlan { int kc_tiles, n_tiles, splits, rows_per_split; };
 
 constexpr int TN_TKC = 64;          // kc columns per workgroup of k_gemm_tn_slab<1>
 
-int tn_target_blocks() {            // workgroups per launch; slab bytes scale with it
+int tn_blocks_override() {          // RGCN_TN_BLOCKS: workgroups per launch (A/B runs); 0 = automatic
   static const int v = [] {
     const char* e = getenv("RGCN_TN_BLOCKS");
     const int x = e ? atoi(e) : 0;
-    return x > 0 ? x : 256;
+    return x > 0 ? x : 0;
   }();
   return v;
+}
+
+// Workgroups per launch.  Slab bytes (and the reduce that follows) scale with the count, so a
+// graph of C2's size gets one workgroup per CU (measured best); once every workgroup still has
+// >= 2,048 rows to stream, two per CU are worth their slabs: the second wave per SIMD covers
+// the per-tile barrier (C4 on one GPU: 2.5 -> 2.0 ms per launch).
+int tn_target_blocks(int64_t M, int tiles) {
+  if (tn_blocks_override()) return tn_blocks_override();
+  return M / std::max(1, 512 / tiles) >= 2048 ? 512 : 256;
 }
 
 SplitPlan plan_splits(int64_t M, int64_t Kc, int64_t N) {
@@ -800,7 +809,7 @@ SplitPlan plan_splits(int64_t M, int64_t Kc, int64_t N) {
   p.kc_tiles = (int)ceil_div64(Kc, TN_TKC);
   p.n_tiles = (int)ceil_div64(N, 128);
   const int tiles = p.kc_tiles * p.n_tiles;
-  int64_t s = std::max<int64_t>(1, tn_target_blocks() / tiles);
+  int64_t s = std::max<int64_t>(1, tn_target_blocks(M, tiles) / tiles);
   s = std::min<int64_t>(s, std::max<int64_t>(1, ceil_div64(M, 128)));
   int64_t rps = ceil_div64(ceil_div64(M, s), 32) * 32;
   if (rps < 32) rps = 32;
