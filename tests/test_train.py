@@ -178,3 +178,23 @@ def test_fp16_gather_training_reaches_the_same_auc(tmp_path):
         scores, labels = ev.compute_scores_and_labels()
         aucs.append(ev.compute_classification_metrics(scores, labels)["auc_roc"])
     assert aucs[0] > 0.6 and abs(aucs[0] - aucs[1]) <= 0.005, aucs
+
+
+@pytest.mark.gpu
+def test_gradient_accumulation_takes_one_update_per_group(tmp_path):
+    """--gradient_accumulation_steps 2 (eager path): 5 batches -> updates after batches 2, 4 and the
+    last one, each on the sum of (loss / 2) gradients of its group."""
+    dev = need_gpu()
+    torch.manual_seed(0)
+    tr, va, full, _ = T.synthetic_data(num_edges=6000, seed=2)
+    args = _args(batch_size=1024, output_dir=str(tmp_path), device="cuda", dropout=0.0, decoder_dropout=0.0,
+                 gradient_accumulation_steps=2)
+    trainer = T.Trainer(T.create_model(tr["num_nodes"], 3, args), tr, va, full, dev, args)
+    assert not trainer.use_hip_graph
+    steps = []
+    orig = trainer.optimizer.step
+    trainer.optimizer.step = lambda *a, **k: (steps.append(1), orig(*a, **k))[1]
+    before = {k: v.clone() for k, v in trainer.model.state_dict().items()}
+    loss, acc = trainer.train_epoch(max_steps=5)
+    assert len(steps) == 3 and 0.0 < loss < 1.0 and 0.0 <= acc <= 1.0
+    assert any(not torch.equal(v, before[k]) for k, v in trainer.model.state_dict().items())
