@@ -1,7 +1,10 @@
 """Evaluation protocol on the HIP path (SURVEY.md section 8f "next" row 2).
 
-Counterpart of the metric core of the reference's ``src/evaluate.py`` (plots, reports and the
-CLI stay out of scope): same protocol, same metric names and return shapes, with the two
+Counterpart of the reference's ``src/evaluate.py`` minus its plots: same command line
+(``--model_path --data_dir --output_dir --batch_size --num_neg_samples --k_values --device``,
+``evaluate.py:766-827``), same checkpoint reading (N and R recovered from the state dict,
+``evaluate.py:655-730``), same protocol, metric names and return shapes, same ``results.json`` /
+``metrics_summary.txt`` (``evaluate.py:594-652``; cf. ``results_final/results.json``), with the two
 hot spots removed -
 
 * ``compute_scores_and_labels`` (``evaluate.py:147-217``): positives + random corruptions of the
@@ -13,13 +16,19 @@ hot spots removed -
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence, Tuple
+import argparse
+import json
+import logging
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
 from .model import DrugDiseaseModel
-from .train import NegativeSampler
+from .train import NegativeSampler, filter_edges
+
+logger = logging.getLogger("primekg_rgcn_linkprediction_amd.evaluate")
 
 
 class ModelEvaluator:
@@ -85,6 +94,93 @@ class ModelEvaluator:
 
     def evaluate(self, num_neg_samples: int = 1, k_values: List[int] = (10, 50)) -> Dict:
         scores, labels = self.compute_scores_and_labels(num_neg_samples)
+        self.scores, self.labels = scores, labels          # kept for plotting code, as the reference does
         return {"classification": self.compute_classification_metrics(scores, labels),
                 "ranking": self.compute_ranking_metrics(k_values),
-                "num_test_edges": self.num_test_edges, "num_nodes": self.num_nodes}
+                "test_edges": self.num_test_edges, "num_nodes": self.num_nodes}
+
+
+# ------------------------------------------------------------------------------------------
+# checkpoint / data / results files / CLI
+# ------------------------------------------------------------------------------------------
+def load_model(model_path: str, device: torch.device) -> Tuple[DrugDiseaseModel, Dict]:
+    """-> (model in eval mode on ``device``, model_info).  A training checkpoint pickles its
+    argparse ``Namespace`` (``train.py:431-442``), so - like the reference - this needs
+    ``weights_only=False``: load only checkpoints you wrote yourself."""
+    checkpoint = torch.load(model_path, map_location="cpu", weights_only=False)
+    args = checkpoint.get("args")
+    if args is None:
+        raise ValueError("Checkpoint does not contain 'args'. Cannot reconstruct model architecture.")
+    state = checkpoint["model_state_dict"]
+    num_nodes = state["encoder.node_embeddings.weight"].size(0)
+    num_relations = state["decoder.relation_embeddings.weight"].size(0)
+    model = DrugDiseaseModel(num_nodes=num_nodes, num_relations=num_relations, embedding_dim=args.embedding_dim,
+                             hidden_dim=args.hidden_dim, dropout=args.dropout,
+                             decoder_dropout=getattr(args, "decoder_dropout", 0.0),
+                             num_bases=getattr(args, "num_bases", None))
+    model.load_state_dict(state)
+    model = model.to(device).eval()
+    info = {"checkpoint_path": str(model_path), "epoch": checkpoint.get("epoch", "unknown"), "num_nodes": num_nodes,
+            "num_relations": num_relations, "embedding_dim": args.embedding_dim, "hidden_dim": args.hidden_dim,
+            "num_parameters": sum(p.numel() for p in model.parameters())}
+    for key in ("best_val_loss", "best_val_acc"):
+        if key in checkpoint:
+            info[key] = checkpoint[key]
+    return model, info
+
+
+def load_test_data(data_dir: str) -> Tuple[Dict, Dict]:
+    """``test_data.pt`` and ``full_graph.pt`` (tensor-only dicts: ``weights_only=True``) with the
+    reference's out-of-range filter applied."""
+    root = Path(data_dir)
+    test = torch.load(root / "test_data.pt", weights_only=True)
+    full = torch.load(root / "full_graph.pt", weights_only=True)
+    n = test["num_nodes"]
+    return filter_edges(test, n, "Test"), filter_edges(full, n, "Full graph")
+
+
+def save_results(metrics: Dict, output_dir: Path, model_info: Optional[Dict] = None) -> None:
+    """``results.json`` ({"metrics", "model_info"}) and ``metrics_summary.txt`` in the reference's layout."""
+    output_dir = Path(output_dir)
+    output_dir.mkdir(parents=True, exist_ok=True)
+    with open(output_dir / "results.json", "w") as fh:
+        json.dump({"metrics": metrics, "model_info": model_info or {}}, fh, indent=2)
+    rule = "=" * 60
+    lines = [rule, "EVALUATION RESULTS SUMMARY", rule, ""]
+    if model_info:
+        lines += ["Model Information:", "-" * 60] + [f"{k}: {v}" for k, v in model_info.items()] + [""]
+    lines += ["Dataset Statistics:", "-" * 60, f"Test edges: {metrics['test_edges']:,}",
+              f"Number of nodes: {metrics['num_nodes']:,}", ""]
+    for title, key in (("Classification Metrics:", "classification"), ("Ranking Metrics:", "ranking")):
+        lines += [title, "-" * 60] + [f"{k}: {v:.4f}" for k, v in metrics[key].items()] + [""]
+    lines.append(rule)
+    (output_dir / "metrics_summary.txt").write_text("\n".join(lines) + "\n")
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Evaluate a trained R-GCN link predictor on MI355X")
+    p.add_argument("--model_path", type=str, required=True)
+    p.add_argument("--data_dir", type=str, default="data/processed")
+    p.add_argument("--output_dir", type=str, default="results")
+    p.add_argument("--batch_size", type=int, default=1024)
+    p.add_argument("--num_neg_samples", type=int, default=1)
+    p.add_argument("--k_values", type=int, nargs="+", default=[10, 50])
+    p.add_argument("--device", type=str, default="cuda")
+    return p
+
+
+def main(argv=None) -> Dict:
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
+    args = build_parser().parse_args(argv)
+    device = torch.device(args.device)
+    model, info = load_model(args.model_path, device)
+    test_data, full_graph = load_test_data(args.data_dir)
+    evaluator = ModelEvaluator(model, test_data, full_graph, device, batch_size=args.batch_size)
+    metrics = evaluator.evaluate(num_neg_samples=args.num_neg_samples, k_values=args.k_values)
+    save_results(metrics, Path(args.output_dir), info)
+    logger.info("Results saved to: %s", args.output_dir)
+    return metrics
+
+
+if __name__ == "__main__":
+    main()

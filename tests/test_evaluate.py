@@ -55,9 +55,9 @@ def test_ranks_and_auc_on_a_larger_graph():
     assert bool(((ranks[:200] >= lo) & (ranks[:200] <= hi.clamp(min=1))).all())
     assert ranks.min() >= 1 and ranks.max() <= full["num_nodes"]
     out = ev.evaluate()
-    assert 0.0 <= out["classification"]["auc_roc"] <= 1.0 and out["num_test_edges"] == te["edge_index"].size(1)
+    assert 0.0 <= out["classification"]["auc_roc"] <= 1.0 and out["test_edges"] == te["edge_index"].size(1)
     s, l = ev.compute_scores_and_labels(num_neg_samples=2)
-    assert s.shape == l.shape == (3 * out["num_test_edges"],) and l.sum() == out["num_test_edges"]
+    assert s.shape == l.shape == (3 * out["test_edges"],) and l.sum() == out["test_edges"]
 
 
 # ---------------------------------------------------------------- embedding consumers
@@ -92,3 +92,32 @@ def test_cosine_consumers_match_the_numpy_restatement():
         C.cosine_pair_scores(e, [1, 2], [3])
     with pytest.raises(RuntimeError):
         C.cosine_pair_scores(emb, [1], [2])               # CPU tensor: no CPU fallback
+
+
+
+def test_evaluate_cli_round_trip(tmp_path):
+    """train 1 short epoch -> final_model.pt -> `evaluate.main` on files in the reference's on-disk
+    format -> results.json / metrics_summary.txt with the reference's keys (results_final/results.json)."""
+    need_gpu()
+    import json
+    from primekg_rgcn_linkprediction_amd import evaluate as E, train as T
+    tr, va, full, te = T.synthetic_data(num_edges=20000, seed=4)
+    data_dir = tmp_path / "processed"
+    data_dir.mkdir()
+    for name, d in (("train_data.pt", tr), ("val_data.pt", va), ("test_data.pt", te), ("full_graph.pt", full)):
+        torch.save(d, data_dir / name)
+    T.main(["--data_dir", str(data_dir), "--output_dir", str(tmp_path / "out"), "--epochs", "1", "--lr", "0.01",
+            "--bucket_cache"])
+    assert (data_dir / "train_data.bucketed.pt").exists() and (data_dir / "full_graph.bucketed.pt").exists()
+    metrics = E.main(["--model_path", str(tmp_path / "out" / "models" / "final_model.pt"), "--data_dir", str(data_dir),
+                      "--output_dir", str(tmp_path / "results"), "--k_values", "10", "50", "100"])
+    saved = json.loads((tmp_path / "results" / "results.json").read_text())
+    assert saved["metrics"] == metrics
+    assert set(saved["metrics"]) == {"classification", "ranking", "test_edges", "num_nodes"}
+    assert set(saved["metrics"]["classification"]) == {"auc_roc", "auc_pr", "precision", "recall", "f1_score", "threshold"}
+    assert set(saved["metrics"]["ranking"]) == {"mrr", "mean_rank", "median_rank", "hits@10", "hits@50", "hits@100"}
+    assert set(saved["model_info"]) >= {"checkpoint_path", "epoch", "num_nodes", "num_relations", "embedding_dim",
+                                        "hidden_dim", "num_parameters", "best_val_loss", "best_val_acc"}
+    assert saved["model_info"]["num_parameters"] == 2078208 and saved["metrics"]["test_edges"] == te["edge_index"].size(1)
+    text = (tmp_path / "results" / "metrics_summary.txt").read_text()
+    assert "EVALUATION RESULTS SUMMARY" in text and "Ranking Metrics:" in text and "hits@100" in text
