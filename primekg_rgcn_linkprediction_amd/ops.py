@@ -2,8 +2,9 @@
 
 These do the checks PyG/torch would do on the host (dtype, device, contiguity,
 shape), hand raw device pointers + the current HIP stream to the library and
-return torch-allocated outputs.  No arithmetic happens in Python, and there is
-no CPU path: a CPU tensor raises.
+return torch-allocated outputs.  No layer arithmetic happens in Python (the only
+torch ops here verify a persisted bucketing against the columns it claims to
+describe), and there is no CPU path: a CPU tensor raises.
 
 Reference call sites replaced: ``RGCNConv.forward`` as used at
 ``src/models/rgcn.py:123,128`` and ``LinkPredictor.forward`` (``rgcn.py:189-213``).
