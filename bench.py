@@ -236,6 +236,18 @@ def main():
         step()
     sync()
     events, ops.GATHER_EVENTS = ops.GATHER_EVENTS, None
+    # what an empty bracket costs on this stream (two event records, nothing between): reported, not
+    # subtracted - the profiler's kernel-only durations in profiles/ are shorter by about this much
+    if world == 1:
+        torch.cuda._sleep(2_000_000)
+    pairs = []
+    for _ in range(20):
+        b, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b.record()
+        e.record()
+        pairs.append((b, e))
+    torch.cuda.synchronize()
+    event_overhead_us = sum(b.elapsed_time(e) for b, e in pairs) / len(pairs) * 1e3
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -277,7 +289,8 @@ def main():
                               "frac": dom["gbs"] / HBM_PEAK_GBS,
                               "traffic": pmc_traffic(dom["kernel"]) if world == 1 else None,
                               "kernel": dom["kernel"],
-                              "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"]}
+                              "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"],
+                              "event_bracket_overhead_us": event_overhead_us}
         result["gather_kernels"] = kernels
 
     if world > 1 and not args.no_replica:
