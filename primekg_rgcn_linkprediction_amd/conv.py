@@ -39,6 +39,27 @@ def _table(x: Tensor, gather_dtype) -> Tensor:
     return x if gather_dtype in (None, torch.float32) else x.to(gather_dtype)
 
 
+class _BasisCompose(torch.autograd.Function):
+    """``W[r] = sum_b comp[r, b] * basis[b]`` (PyG: ``(comp @ weight.view(B, -1)).view(R, in, out)``).
+    Plain torch ops, but the backward is spelled out: autograd's ``grad_comp = gW @ basis^T`` is a
+    [R, in*out] x [in*out, B] product with 12 outputs and K = 65,536, for which the GEMM library
+    picks a one-tile kernel (63 us per layer measured at hidden 256); a broadcast multiply and a
+    row sum do it in a few microseconds."""
+
+    @staticmethod
+    def forward(ctx, comp: Tensor, basis: Tensor) -> Tensor:
+        ctx.save_for_backward(comp, basis)
+        return (comp @ basis.view(basis.size(0), -1)).view(comp.size(0), basis.size(1), basis.size(2))
+
+    @staticmethod
+    def backward(ctx, gw: Tensor):
+        comp, basis = ctx.saved_tensors
+        gw2, b2 = gw.reshape(comp.size(0), -1), basis.view(basis.size(0), -1)
+        g_comp = (gw2.unsqueeze(1) * b2.unsqueeze(0)).sum(-1) if ctx.needs_input_grad[0] else None
+        g_basis = (comp.t() @ gw2).view_as(basis) if ctx.needs_input_grad[1] else None
+        return g_comp, g_basis
+
+
 class _RGCNConvFunction(torch.autograd.Function):
     """x, weight[R, d_in, d_out], root, bias -> out (optionally relu(out)), on a bucketed graph."""
 
@@ -224,12 +245,10 @@ class RGCNConv(nn.Module):
             self.bias.data.zero_()
 
     def effective_weight(self) -> Tensor:
-        """``weight`` or the basis composition (row A5; left to torch/autograd: it is a
-        [R, B] x [B, d_in*d_out] product, negligible next to the layer)."""
+        """``weight`` or the basis composition ``comp[R, B] @ weight[B, d_in*d_out]`` (row A5)."""
         if self.num_bases is None:
             return self.weight
-        return (self.comp @ self.weight.view(self.num_bases, -1)).view(
-            self.num_relations, self.in_channels_l, self.out_channels)
+        return _BasisCompose.apply(self.comp, self.weight)
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_type: Optional[Tensor] = None,
                 activation: Optional[str] = None) -> Tensor:
