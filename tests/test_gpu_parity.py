@@ -535,6 +535,29 @@ def test_functional_entry_and_r16():
     assert_fwd(out, O.rgcn_conv_ref(x, ei, et, w, root, bias))
 
 
+def test_more_than_32_relations_and_odd_widths():
+    """R = 40 (no relation-occupancy words: dense path), widths that are multiples of 4 but not of 32
+    (register-staged GEMM fallbacks), forward and every gradient vs the oracle."""
+    dev = need_gpu()
+    ei, et, n, r = synth.uniform_graph(300, 9000, 40, seed=6)
+    gen = torch.Generator().manual_seed(6)
+    for d_in, d_out in ((32, 64), (20, 12)):
+        x = torch.randn(n, d_in, generator=gen)
+        w = torch.randn(r, d_in, d_out, generator=gen) * 0.1
+        root = torch.randn(d_in, d_out, generator=gen) * 0.1
+        bias = torch.randn(d_out, generator=gen)
+        cot = torch.randn(n, d_out, generator=gen)
+        ref_in = [t.clone().requires_grad_(True) for t in (x, w, root, bias)]
+        O.rgcn_conv_ref(ref_in[0], ei, et, ref_in[1], ref_in[2], ref_in[3]).backward(cot)
+        got_in = [t.to(dev).requires_grad_(True) for t in (x, w, root, bias)]
+        out = rgcn_conv(got_in[0], ei.to(dev), et.to(dev), got_in[1], got_in[2], got_in[3], r)
+        assert_fwd(out, O.rgcn_conv_ref(x, ei, et, w, root, bias))
+        out.backward(cot.to(dev))
+        for a, b in zip(got_in, ref_in):
+            assert_grad(a.grad, b.grad)
+    assert ops.bucket(ei.to(dev), et.to(dev), n, r).tile_mask_ptr(False) is None
+
+
 def test_config_c4_scale_on_one_gpu():
     """BASELINE configs[3] shape (500k nodes / 20M edges / 16 relations, 64 -> 128) on ONE GPU:
     size-independent properties over the whole graph + the oracle on a sample of rows."""
