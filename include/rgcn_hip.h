@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 5
+#define RGCN_ABI_VERSION 6
 
 enum {
   RGCN_OK = 0,
@@ -156,6 +156,18 @@ int rgcn_aggregate_level(const rgcn_graph* g, int transposed, int level, const f
 int rgcn_transform_fwd(const float* agg, const float* x, const float* weight, const float* root,
                        const float* bias, int relu, const uint32_t* tile_mask, int64_t num_nodes,
                        int64_t num_relations, int64_t d_in, int64_t d_out, float* out, void* stream);
+
+/* The forward transform on the fp16 matrix cores (BASELINE.json configs[4], "fp16 features + fp32
+ * accumulate"): the same contraction with [agg | x] and [W ; root] rounded to IEEE fp16 (nearest
+ * even) and fp32 accumulation (v_mfma_f32_32x32x16_f16); bias / ReLU / out in fp32.  agg and x are
+ * still passed as fp32 (the backward, which stays fp32, needs them); `workspace` receives the
+ * packed fp16 weight operand (rgcn_transform_fwd_f16_workspace_bytes).  d_in must be a multiple
+ * of 32 (RGCN_ERR_UNSUPPORTED otherwise: use rgcn_transform_fwd). */
+size_t rgcn_transform_fwd_f16_workspace_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
+int rgcn_transform_fwd_f16(const float* agg, const float* x, const float* weight, const float* root,
+                           const float* bias, int relu, const uint32_t* tile_mask, int64_t num_nodes,
+                           int64_t num_relations, int64_t d_in, int64_t d_out, float* out,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* Autograd of A6 with respect to the layer input (row A7):
  *   grad_x[N, d_in] = sum_r gagg[:, r, :] @ weight[r]^T + g @ root^T

@@ -13,7 +13,7 @@ from ctypes import POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_p
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -48,6 +48,8 @@ PROTOTYPES = {
     "rgcn_aggregate_level": (c_int, [c_void_p, c_int, c_int, _P, _I64, _P, _P, c_size_t, _P]),
     "rgcn_graph_tile_mask": (c_void_p, [c_void_p, c_int, POINTER(c_int64)]),
     "rgcn_transform_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _I64, _I64, _I64, _I64, _P, _P]),
+    "rgcn_transform_fwd_f16_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),
+    "rgcn_transform_fwd_f16": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _I64, _I64, _I64, _I64, _P, _P, c_size_t, _P]),
     "rgcn_transform_bwd_input": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P]),
     "rgcn_transform_bwd_params_workspace_bytes": (c_size_t, [_I64, _I64, _I64, _I64]),
     "rgcn_transform_bwd_params": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P,

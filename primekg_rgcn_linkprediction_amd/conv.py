@@ -72,7 +72,8 @@ class _RGCNConvFunction(torch.autograd.Function):
         bias_c = bias.contiguous() if bias is not None else None
         ctx.gather_dtype = gather_dtype
         agg = ops.aggregate(graph, _table(x, gather_dtype), transposed=False)   # rows A3 + A4
-        out = ops.transform_fwd(agg, x, weight, root_c, bias_c, relu=relu, graph=graph)  # row A6 (+ fused ReLU)
+        out = ops.transform_fwd(agg, x, weight, root_c, bias_c, relu=relu, graph=graph,
+                                half=gather_dtype == torch.float16)                    # row A6 (+ fused ReLU)
         ctx.graph, ctx.relu = graph, relu
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
         ctx.save_for_backward(x, agg, weight, root_c, out if relu else None)
@@ -113,11 +114,12 @@ class _Encoder2Function(torch.autograd.Function):
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
         ctx.gather_dtype = gather_dtype
         agg1 = ops.aggregate(graph, _table(x, gather_dtype))
-        h = ops.transform_fwd(agg1, x, w1, root1, b1, relu=True, graph=graph)
+        half = gather_dtype == torch.float16          # configs[4]: fp16 operands on the fp16 matrix cores too
+        h = ops.transform_fwd(agg1, x, w1, root1, b1, relu=True, graph=graph, half=half)
         if p > 0:
             h = torch.native_dropout(h, p, True)[0]
         agg2 = ops.aggregate(graph, _table(h, gather_dtype))
-        out = ops.transform_fwd(agg2, h, w2, root2, b2, graph=graph)
+        out = ops.transform_fwd(agg2, h, w2, root2, b2, graph=graph, half=half)
         ctx.graph, ctx.p = graph, p
         ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
         ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2)

@@ -418,6 +418,39 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_dma(const float* __restric
     }
     return;
   }
+  if (m0 + BM <= M && n0 + BN <= N) {
+    // Interior tile (all but the last row of tiles): no per-element bounds branches, so the
+    // epilogue loads (bias, mask) are waited for ONCE and the 16 x TN stores of a lane go out
+    // back to back.  With a branch around every store hipcc re-inserts `s_waitcnt vmcnt(0)` in
+    // each block, and on gfx9 that also waits for the previous STORE's write acknowledgement.
+    float bv[TN];
+    float mk[TN][16];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + (wn * TN + b) * 32 + li;
+      bv[b] = bias ? bias[n] : 0.f;
+      if (EPI == EPI_MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          mk[b][r] = mask[(size_t)m * N + n];
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + (wn * TN + b) * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float v = acc[b][r] + bv[b];
+        if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+        if (EPI == EPI_MASK) v = mk[b][r] > 0.f ? v : 0.f;
+        C[(size_t)m * N + n] = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int n = n0 + (wn * TN + b) * 32 + li;

@@ -378,13 +378,27 @@ def _mask_for(graph: Optional[BucketedGraph], transposed: bool, n: int, r: int) 
 
 
 def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
-                  graph: Optional[BucketedGraph] = None) -> torch.Tensor:
+                  graph: Optional[BucketedGraph] = None, half: bool = False) -> torch.Tensor:
     """``sum_r agg[:, r] @ weight[r] + x @ root + bias`` as one fp32-MFMA GEMM; ``relu``
     fuses the activation that follows conv1 (``rgcn.py:124``) into the epilogue.  ``graph``
     (the structure ``agg`` was aggregated over) lets the kernel skip the k-tiles of relations
-    that a whole 64-row tile does not have - exact zeros in ``agg``."""
+    that a whole 64-row tile does not have - exact zeros in ``agg``.
+
+    ``half=True`` (BASELINE configs[4]): operands rounded to fp16, fp32 accumulate, on the fp16
+    matrix cores (``rgcn_transform_fwd_f16``); widths the kernel does not take (d_in % 32) run the
+    fp32 GEMM instead - more precise, never less."""
     n, r, d_in, d_out = _check_layer(agg, x, weight, root, bias)
     lib = _lib.load()
+    if half and d_in % 32 == 0:
+        with torch.cuda.device(x.device):
+            out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
+            nbytes = lib.rgcn_transform_fwd_f16_workspace_bytes(r, d_in, d_out)
+            ws = _workspace(nbytes, x.device)
+            rc = lib.rgcn_transform_fwd_f16(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu),
+                                            _mask_for(graph, False, n, r), n, r, d_in, d_out, _ptr(out), _ptr(ws),
+                                            nbytes, _stream())
+        _lib.check(rc, "rgcn_transform_fwd_f16")
+        return out
     with torch.cuda.device(x.device):
         out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
         rc = lib.rgcn_transform_fwd(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu),

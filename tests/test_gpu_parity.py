@@ -661,6 +661,52 @@ def test_fp16_gather_equals_fp32_gather_of_the_rounded_table(d):
         ops.aggregate(g, torch.zeros(n, 12, device=dev, dtype=torch.float16))     # d % 8
 
 
+@pytest.mark.parametrize("n,r,d_in,d_out,relu", [(30926, 3, 64, 128, True), (30926, 3, 128, 128, False),
+                                                  (1000, 16, 32, 64, False), (77, 1, 96, 200, True)])
+def test_fp16_matrix_core_transform(n, r, d_in, d_out, relu):
+    """rgcn_transform_fwd_f16 (configs[4]) against its exact meaning - both operands rounded to fp16
+    (nearest even), products and sums in fp32/fp64 - tightly, and against the fp32 transform within
+    the 2e-3 gate; the packed-operand path with and without root / bias."""
+    dev = need_gpu()
+    gen = torch.Generator().manual_seed(n + d_in)
+    agg = torch.randn(n, r * d_in, generator=gen)
+    agg[:, : d_in] *= (torch.rand(n, 1, generator=gen) < 0.7)            # rows without relation 0
+    x = torch.randn(n, d_in, generator=gen)
+    w = torch.randn(r, d_in, d_out, generator=gen) * 0.1
+    root = torch.randn(d_in, d_out, generator=gen) * 0.1
+    bias = torch.randn(d_out, generator=gen)
+    a16 = torch.cat([agg, x], 1).half().double()
+    b16 = torch.cat([w.view(-1, d_out), root]).half().double()
+    want = a16 @ b16 + bias.double()
+    want = want.clamp(min=0) if relu else want
+    got = ops.transform_fwd(agg.to(dev), x.to(dev), w.to(dev), root.to(dev), bias.to(dev), relu=relu, half=True)
+    scale = want.abs().max().item()
+    assert (got.double().cpu() - want).abs().max().item() <= 2e-6 * scale + 1e-5      # fp32 accumulation of exact products
+    full = ops.transform_fwd(agg.to(dev), x.to(dev), w.to(dev), root.to(dev), bias.to(dev), relu=relu)
+    assert rel_err(got, full.cpu()) <= 2e-3 and not torch.equal(got, full)
+    # no root, no bias
+    got2 = ops.transform_fwd(agg.to(dev), x.to(dev), w.to(dev), None, None, half=True)
+    want2 = agg.half().double() @ w.view(-1, d_out).half().double()
+    assert (got2.double().cpu() - want2).abs().max().item() <= 2e-6 * want2.abs().max().item() + 1e-5
+    # a width the fp16 kernel does not take falls back to the fp32 GEMM (never less precise)
+    if d_in == 32:
+        x20, w20, agg20 = x[:, :20].contiguous(), w[:, :20].contiguous(), torch.randn(n, r * 20, generator=gen)
+        fb = ops.transform_fwd(agg20.to(dev), x20.to(dev), w20.to(dev), None, None, half=True)
+        assert torch.equal(fb, ops.transform_fwd(agg20.to(dev), x20.to(dev), w20.to(dev), None, None))
+
+
+def test_fp16_matrix_core_transform_respects_relation_masks():
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=60000, seed=1)
+    g = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn(n, 64, generator=gen).to(dev)
+    w, root = (torch.randn(r, 64, 128, generator=gen) * 0.1).to(dev), (torch.randn(64, 128, generator=gen) * 0.1).to(dev)
+    agg = ops.aggregate(g, x.half())
+    assert torch.equal(ops.transform_fwd(agg, x, w, root, None, half=True, graph=g),
+                       ops.transform_fwd(agg, x, w, root, None, half=True))       # skipped tiles were exact zeros
+
+
 def test_config_c5_fp16_features_vs_fp32_oracle():
     """configs[4]: PrimeKG shape, fp16 feature table + fp32 accumulate vs the fp32 oracle:
     <= 2e-3 relative (SURVEY 8d parity gate)."""
