@@ -370,12 +370,14 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_dma(const float* __restric
     if (kt_b < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // first fragments of this k-tile go out before the DMA issue below, whose ~40 instructions then
+    // cover their LDS latency
+    const unsigned buf_bytes = (unsigned)((t % NBUF) * BUF_FLOATS) * 4u;
+    read_frags(0, 0, buf_bytes);
     kt_c = kt_b < K ? next_kt(kt_b) : K;
     if (kt_c < K) stage(kt_c, (t + 2) % NBUF);
     kt_a = kt_b;
     kt_b = kt_c;
-    const unsigned buf_bytes = (unsigned)((t % NBUF) * BUF_FLOATS) * 4u;
-    read_frags(0, 0, buf_bytes);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const int cur = s4 & 1;
@@ -710,6 +712,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+    const unsigned buf_bytes = (unsigned)((t % NBUF) * BUF_FLOATS) * 4u;
+    read_frags(0, 0, buf_bytes);               // ahead of the DMA issue, which covers their LDS latency
     mt_c = mt_b < mend ? next_mt(mt_b) : mend;
     if (mt_c < mend) stage(mt_c, (t + 2) % NBUF);
     mt_a = mt_b;
@@ -723,8 +727,6 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
 #pragma unroll
       for (int mm = 0; mm < 32; ++mm) bsum += v[mm];
     }
-    const unsigned buf_bytes = (unsigned)((t % NBUF) * BUF_FLOATS) * 4u;
-    read_frags(0, 0, buf_bytes);
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const int cur = q4 & 1;

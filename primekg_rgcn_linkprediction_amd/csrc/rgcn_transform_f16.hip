@@ -137,10 +137,6 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f16(const float* __restric
     if (kt_b < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    kt_c = kt_b < K ? next_kt(kt_b) : K;
-    if (kt_c < K) stage(kt_c, (t + 2) % NBUF);
-    kt_a = kt_b;
-    kt_b = kt_c;
     const unsigned buf = (unsigned)((t % NBUF) * BUF_BYTES);
     f32x4 fa[2][2], fb[2][TN];
 #pragma unroll
@@ -150,6 +146,10 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_f16(const float* __restric
 #pragma unroll
       for (int b = 0; b < TN; ++b) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[s][b]) : "v"(b_addr[b][s] + buf));
     }
+    kt_c = kt_b < K ? next_kt(kt_b) : K;         // the DMA issue covers the LDS latency of the reads above
+    if (kt_c < K) stage(kt_c, (t + 2) % NBUF);
+    kt_a = kt_b;
+    kt_b = kt_c;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       // step 0 may start once its own 2 + TN reads are back (the last 2 + TN issued are step 1's)
