@@ -24,7 +24,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kUnroll = 8;
+constexpr int kUnroll = RGCN_HEAD;   // rows in flight per lane group = ids that travel with an item
 #ifndef RGCN_REDUCE_UNROLL
 #define RGCN_REDUCE_UNROLL 16
 #endif
@@ -40,7 +40,8 @@ template <int G, bool WEIGHTED>
 __global__ __launch_bounds__(kThreads) void k_aggregate(
     const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
-    float* __restrict__ agg, float* __restrict__ partial, int d) {
+    float* __restrict__ agg, float* __restrict__ partial, int d, const int32_t* __restrict__ head_col,
+    const float* __restrict__ head_w) {
   const int64_t item_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   const int c4 = ((int)threadIdx.x % G + (int)blockIdx.y * G) * 4;
   if (item_id >= nitems || c4 >= d) return;
@@ -49,11 +50,11 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
   float4 acc = f4zero();
   int idx_n[kUnroll];
   float wt_n[kUnroll];
+  // ids / weights of the first kUnroll edges come with the item (padded -1 / 0): no wait on it.begin
 #pragma unroll
   for (int u = 0; u < kUnroll; ++u) {
-    const bool ok = it.begin + u < it.end;
-    idx_n[u] = ok ? col[it.begin + u] : -1;
-    wt_n[u] = (WEIGHTED && ok) ? w[it.begin + u] : 0.f;
+    idx_n[u] = head_col[item_id * kUnroll + u];
+    wt_n[u] = WEIGHTED ? head_w[item_id * kUnroll + u] : 0.f;
   }
   for (int e = it.begin; e < it.end; e += kUnroll) {
     int idx[kUnroll];
@@ -100,7 +101,8 @@ template <int G, bool WEIGHTED>
 __global__ __launch_bounds__(kThreads) void k_aggregate_h(
     const __half* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
-    float* __restrict__ agg, float* __restrict__ partial, int d) {
+    float* __restrict__ agg, float* __restrict__ partial, int d, const int32_t* __restrict__ head_col,
+    const float* __restrict__ head_w) {
   const int64_t item_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   const int c8 = ((int)threadIdx.x % G + (int)blockIdx.y * G) * 8;
   if (item_id >= nitems || c8 >= d) return;
@@ -112,10 +114,9 @@ __global__ __launch_bounds__(kThreads) void k_aggregate_h(
   int idx_n[kUnroll];
   float wt_n[kUnroll];
 #pragma unroll
-  for (int u = 0; u < kUnroll; ++u) {
-    const bool ok = it.begin + u < it.end;
-    idx_n[u] = ok ? col[it.begin + u] : -1;
-    wt_n[u] = ok ? (WEIGHTED ? w[it.begin + u] : 1.f) : 0.f;
+  for (int u = 0; u < kUnroll; ++u) {          // heads travel with the item (see k_aggregate)
+    idx_n[u] = head_col[item_id * kUnroll + u];
+    wt_n[u] = WEIGHTED ? head_w[item_id * kUnroll + u] : (idx_n[u] >= 0 ? 1.f : 0.f);
   }
   for (int e = it.begin; e < it.end; e += kUnroll) {
     int idx[kUnroll];
@@ -220,9 +221,11 @@ void launch_level(const rgcn_csr* c, int level, bool weighted, const float* x, c
   if (level == 0) {
     dim3 grid((unsigned)ceil_div64(nitems, kThreads / G), gy);
     if (weighted)
-      k_aggregate<G, true><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, c->val, cnt, agg, partial, d);
+      k_aggregate<G, true><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, c->val, cnt, agg, partial, d,
+                                                          c->head_col, c->head_w);
     else
-      k_aggregate<G, false><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, nullptr, cnt, agg, partial, d);
+      k_aggregate<G, false><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, nullptr, cnt, agg, partial, d,
+                                                           c->head_col, nullptr);
   } else {
     dim3 grid((unsigned)nitems, gy);
     k_reduce_partials<G><<<grid, kThreads, 0, stream>>>(c->items[level], cnt, agg, partial, d);
@@ -236,9 +239,11 @@ void launch_level0_h(const rgcn_csr* c, bool weighted, const __half* x, const fl
   if (nitems == 0) return;
   dim3 grid((unsigned)ceil_div64(nitems, kThreads / G), (unsigned)ceil_div64(d, 8 * G));
   if (weighted)
-    k_aggregate_h<G, true><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, c->val, cnt, agg, partial, d);
+    k_aggregate_h<G, true><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, c->val, cnt, agg, partial, d,
+                                                            c->head_col, c->head_w);
   else
-    k_aggregate_h<G, false><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, nullptr, cnt, agg, partial, d);
+    k_aggregate_h<G, false><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, nullptr, cnt, agg, partial, d,
+                                                             c->head_col, nullptr);
 }
 
 int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, const float* x, int64_t d,

@@ -17,6 +17,8 @@ constexpr int RGCN_CHUNK = 64;
 // Fan-in of the levels above: partial rows are contiguous and a whole workgroup sums one run.
 constexpr int RGCN_CHUNK_UP = 512;
 constexpr int RGCN_MAX_LEVELS = 8;
+// Edges of an item whose ids travel with the item (= rows a lane group keeps in flight).
+constexpr int RGCN_HEAD = 8;
 
 // One unit of aggregate work: sum source rows [begin, end) into row `dst`.
 //   level 0 : source rows are x[col[e]] for e in [begin, end)
@@ -39,6 +41,11 @@ struct rgcn_csr {
   rgcn_item* items[RGCN_MAX_LEVELS] = {};
   int64_t num_items[RGCN_MAX_LEVELS] = {};
   int64_t num_partials = 0;   // rows of partial-sum workspace (all levels)
+  // Per level-0 item, the column ids (and, in weighted mode, the weights) of its first RGCN_HEAD
+  // edges, padded with -1 / 0: fetched together with the item record, so the first row loads of an
+  // item are one dependent round trip away instead of two (item -> col -> row).
+  int32_t* head_col = nullptr;   // [num_items[0] * RGCN_HEAD]
+  float* head_w = nullptr;       // [num_items[0] * RGCN_HEAD], weighted structures only
   // bit r of tile_mask[t]: some row of rows [32t, 32t+32) has a non-empty (row, r) segment.
   // Typed relations leave whole row ranges without a relation (drug-gene edges never reach a
   // disease row): the transforms skip the all-zero k/m-tiles these bits expose.  NULL if R > 32.

@@ -141,6 +141,8 @@ void free_csr(rgcn_csr* c) {
   (void)hipFree(c->perm);
   (void)hipFree(c->val);
   (void)hipFree(c->tile_mask);
+  (void)hipFree(c->head_col);
+  (void)hipFree(c->head_w);
   for (int l = 0; l < RGCN_MAX_LEVELS; ++l) (void)hipFree(c->items[l]);
   *c = rgcn_csr();
 }
@@ -211,6 +213,20 @@ int build_structure(const int64_t* key_node, const int64_t* other_node, const in
   return RGCN_OK;
 }
 
+#define TRY_PLAN(expr) do { int rc__ = (expr); if (rc__ != RGCN_OK) return rc__; } while (0)
+
+__global__ void k_item_heads(const rgcn_item* __restrict__ items, int64_t nitems, const int32_t* __restrict__ col,
+                             const float* __restrict__ w, int32_t* __restrict__ head_col,
+                             float* __restrict__ head_w) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nitems * RGCN_HEAD) return;
+  const rgcn_item it = items[i / RGCN_HEAD];
+  const int e = it.begin + (int)(i % RGCN_HEAD);
+  const bool ok = e < it.end;
+  head_col[i] = ok ? col[e] : -1;
+  if (head_w) head_w[i] = ok ? w[e] : 0.f;
+}
+
 int plan_structure(rgcn_csr* c, int64_t R, hipStream_t stream) {
   const int64_t NR = c->n_key * R;
   std::vector<int32_t> rp((size_t)NR + 1);
@@ -225,7 +241,17 @@ int plan_structure(rgcn_csr* c, int64_t R, hipStream_t stream) {
     RGCN_HIP_TRY(hipMalloc((void**)&c->tile_mask, mask.size() * sizeof(uint32_t)));
     RGCN_HIP_TRY(hipMemcpy(c->tile_mask, mask.data(), mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
-  return build_plan(rp, NR, c);
+  TRY_PLAN(build_plan(rp, NR, c));
+  const int64_t n0 = c->num_items[0];
+  if (n0 > 0) {                                  // heads of the level-0 items (col / val are final by now)
+    RGCN_HIP_TRY(hipMalloc((void**)&c->head_col, (size_t)n0 * RGCN_HEAD * sizeof(int32_t)));
+    if (c->weighted) RGCN_HIP_TRY(hipMalloc((void**)&c->head_w, (size_t)n0 * RGCN_HEAD * sizeof(float)));
+    k_item_heads<<<grid_for(n0 * RGCN_HEAD), kThreads, 0, stream>>>(c->items[0], n0, c->col,
+                                                                   c->weighted ? c->val : nullptr, c->head_col,
+                                                                   c->head_w);
+    RGCN_HIP_TRY(hipGetLastError());
+  }
+  return RGCN_OK;
 }
 
 int mean_counts(rgcn_csr* c, int64_t R, hipStream_t stream) {
