@@ -36,6 +36,56 @@ __device__ inline void f4fma(float4& a, const float4& b, float s) {   // explici
   a.x = fmaf(b.x, s, a.x); a.y = fmaf(b.y, s, a.y); a.z = fmaf(b.z, s, a.z); a.w = fmaf(b.w, s, a.w);
 }
 
+
+// Column ids (and weights) of a work item, fetched by the lane group as a team.  A vector-memory
+// instruction occupies the CU's address unit for the same 16 cycles whether it returns 1 KB of
+// rows or one broadcast dword, and the per-lane form (every lane loading the same 8 ids, then the
+// same 8 weights) made the id traffic HALF of the kernel's memory instructions - the gather ran
+// with that unit 71 % busy (PMC: TA_TA_BUSY).  Here lane j of the group loads edge base + j of a
+// window of G edges with ONE instruction, and the ids are handed round with ds_bpermute (__shfl,
+// LDS crossbar, no memory).  The first RGCN_HEAD ids come with the item (head_col / head_w).
+template <int G, bool WEIGHTED>
+struct IdWindow {
+  int cur, nxt, pos, len, nbase, end;
+  float curw, nxtw;
+  __device__ inline void fetch_next(int gl, const int32_t* __restrict__ col, const float* __restrict__ w) {
+    const int e = nbase + gl;
+    const bool ok = e < end;
+    nxt = ok ? col[e] : -1;
+    nxtw = (WEIGHTED && ok) ? w[e] : 0.f;
+  }
+  __device__ inline void init(int64_t item_id, int gl, const rgcn_item& it, const int32_t* __restrict__ col,
+                              const float* __restrict__ w, const int32_t* __restrict__ head_col,
+                              const float* __restrict__ head_w) {
+    const bool h = gl < RGCN_HEAD;
+    cur = h ? head_col[item_id * RGCN_HEAD + gl] : -1;
+    curw = (WEIGHTED && h) ? head_w[item_id * RGCN_HEAD + gl] : 0.f;
+    pos = 0;
+    len = RGCN_HEAD;
+    nbase = it.begin + RGCN_HEAD;
+    end = it.end;
+    fetch_next(gl, col, w);
+  }
+  __device__ inline void get(int (&idx)[RGCN_HEAD], float (&wt)[RGCN_HEAD]) const {
+#pragma unroll
+    for (int u = 0; u < RGCN_HEAD; ++u) {
+      idx[u] = __shfl(cur, pos + u, G);
+      wt[u] = WEIGHTED ? __shfl(curw, pos + u, G) : 0.f;
+    }
+  }
+  __device__ inline void advance(int gl, const int32_t* __restrict__ col, const float* __restrict__ w) {
+    pos += RGCN_HEAD;
+    if (pos == len) {                     // the same iteration for every group of the wave
+      cur = nxt;
+      curw = nxtw;
+      pos = 0;
+      len = G;
+      nbase += G;
+      fetch_next(gl, col, w);             // in flight behind the rows of this round
+    }
+  }
+};
+
 template <int G, bool WEIGHTED>
 __global__ __launch_bounds__(kThreads) void k_aggregate(
     const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
@@ -44,45 +94,70 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
     const float* __restrict__ head_w) {
   const int64_t item_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   const int c4 = ((int)threadIdx.x % G + (int)blockIdx.y * G) * 4;
-  if (item_id >= nitems || c4 >= d) return;
+  if (item_id >= nitems) return;                 // whole lane groups only
+  const bool live = c4 < d;                      // lanes past the row end still carry ids for their group
   const rgcn_item it = items[item_id];
 
   float4 acc = f4zero();
-  int idx_n[kUnroll];
-  float wt_n[kUnroll];
-  // ids / weights of the first kUnroll edges come with the item (padded -1 / 0): no wait on it.begin
+  if constexpr (G >= RGCN_HEAD) {
+    const int gl = (int)threadIdx.x % G;
+    IdWindow<G, WEIGHTED> win;
+    win.init(item_id, gl, it, col, w, head_col, head_w);
+    for (int e = it.begin; e < it.end; e += kUnroll) {
+      int idx[kUnroll];
+      float wt[kUnroll];
+      float4 v[kUnroll];
+      win.get(idx, wt);
 #pragma unroll
-  for (int u = 0; u < kUnroll; ++u) {
-    idx_n[u] = head_col[item_id * kUnroll + u];
-    wt_n[u] = WEIGHTED ? head_w[item_id * kUnroll + u] : 0.f;
+      for (int u = 0; u < kUnroll; ++u) {
+        v[u] = f4zero();
+        if (live && idx[u] >= 0) v[u] = *reinterpret_cast<const float4*>(src + (size_t)idx[u] * d + c4);
+      }
+      win.advance(gl, col, w);
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if (WEIGHTED) f4fma(acc, v[u], wt[u]);
+        else f4add(acc, v[u]);
+      }
+    }
+  } else {
+    if (!live) return;                                  // fewer than 8 lanes per row (d < 32): every lane loads the ids
+    int idx_n[kUnroll];
+    float wt_n[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      idx_n[u] = head_col[item_id * kUnroll + u];
+      wt_n[u] = WEIGHTED ? head_w[item_id * kUnroll + u] : 0.f;
+    }
+    for (int e = it.begin; e < it.end; e += kUnroll) {
+      int idx[kUnroll];
+      float wt[kUnroll];
+      float4 v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        idx[u] = idx_n[u];
+        wt[u] = wt_n[u];
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        v[u] = f4zero();
+        if (idx[u] >= 0) v[u] = *reinterpret_cast<const float4*>(src + (size_t)idx[u] * d + c4);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {   // ids of the next round, in flight behind the rows
+        const int en = e + kUnroll + u;
+        const bool ok = en < it.end;
+        idx_n[u] = ok ? col[en] : -1;
+        wt_n[u] = (WEIGHTED && ok) ? w[en] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if (WEIGHTED) f4fma(acc, v[u], wt[u]);
+        else f4add(acc, v[u]);
+      }
+    }
   }
-  for (int e = it.begin; e < it.end; e += kUnroll) {
-    int idx[kUnroll];
-    float wt[kUnroll];
-    float4 v[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      idx[u] = idx_n[u];
-      wt[u] = wt_n[u];
-    }
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      v[u] = f4zero();
-      if (idx[u] >= 0) v[u] = *reinterpret_cast<const float4*>(src + (size_t)idx[u] * d + c4);
-    }
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {   // ids of the next round, in flight behind the rows
-      const int en = e + kUnroll + u;
-      const bool ok = en < it.end;
-      idx_n[u] = ok ? col[en] : -1;
-      wt_n[u] = (WEIGHTED && ok) ? w[en] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      if (WEIGHTED) f4fma(acc, v[u], wt[u]);
-      else f4add(acc, v[u]);
-    }
-  }
+  if (!live) return;
   if (it.flags & 1) {
     if (cnt) {  // mean: true division by max(1, segment size), as `sum / count` does
       const float c = cnt[it.dst];
@@ -105,40 +180,14 @@ __global__ __launch_bounds__(kThreads) void k_aggregate_h(
     const float* __restrict__ head_w) {
   const int64_t item_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   const int c8 = ((int)threadIdx.x % G + (int)blockIdx.y * G) * 8;
-  if (item_id >= nitems || c8 >= d) return;
+  if (item_id >= nitems) return;
+  const bool live = c8 < d;
   const rgcn_item it = items[item_id];
 
   float acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  int idx_n[kUnroll];
-  float wt_n[kUnroll];
-#pragma unroll
-  for (int u = 0; u < kUnroll; ++u) {          // heads travel with the item (see k_aggregate)
-    idx_n[u] = head_col[item_id * kUnroll + u];
-    wt_n[u] = WEIGHTED ? head_w[item_id * kUnroll + u] : (idx_n[u] >= 0 ? 1.f : 0.f);
-  }
-  for (int e = it.begin; e < it.end; e += kUnroll) {
-    int idx[kUnroll];
-    float wt[kUnroll];
-    uint4 v[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      idx[u] = idx_n[u];
-      wt[u] = wt_n[u];
-    }
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      v[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (idx[u] >= 0) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)idx[u] * d + c8);
-    }
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const int en = e + kUnroll + u;
-      const bool ok = en < it.end;
-      idx_n[u] = ok ? col[en] : -1;
-      wt_n[u] = ok ? (WEIGHTED ? w[en] : 1.f) : 0.f;
-    }
+  auto accumulate = [&](const uint4 (&v)[kUnroll], const float (&wt)[kUnroll]) {
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const __half2* h2 = reinterpret_cast<const __half2*>(&v[u]);
@@ -148,13 +197,64 @@ __global__ __launch_bounds__(kThreads) void k_aggregate_h(
         if (WEIGHTED) {
           acc[2 * k] = fmaf(f.x, wt[u], acc[2 * k]);
           acc[2 * k + 1] = fmaf(f.y, wt[u], acc[2 * k + 1]);
-        } else {
+        } else {                                  // rows of absent edges were loaded as zeros
           acc[2 * k] += f.x;
           acc[2 * k + 1] += f.y;
         }
       }
     }
+  };
+  if constexpr (G >= RGCN_HEAD) {                 // ids fetched by the group as a team (see IdWindow)
+    const int gl = (int)threadIdx.x % G;
+    IdWindow<G, WEIGHTED> win;
+    win.init(item_id, gl, it, col, w, head_col, head_w);
+    for (int e = it.begin; e < it.end; e += kUnroll) {
+      int idx[kUnroll];
+      float wt[kUnroll];
+      uint4 v[kUnroll];
+      win.get(idx, wt);
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (live && idx[u] >= 0) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)idx[u] * d + c8);
+      }
+      win.advance(gl, col, w);
+      accumulate(v, wt);
+    }
+  } else {
+    if (!live) return;
+    int idx_n[kUnroll];
+    float wt_n[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      idx_n[u] = head_col[item_id * kUnroll + u];
+      wt_n[u] = WEIGHTED ? head_w[item_id * kUnroll + u] : 0.f;
+    }
+    for (int e = it.begin; e < it.end; e += kUnroll) {
+      int idx[kUnroll];
+      float wt[kUnroll];
+      uint4 v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        idx[u] = idx_n[u];
+        wt[u] = wt_n[u];
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (idx[u] >= 0) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)idx[u] * d + c8);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int en = e + kUnroll + u;
+        const bool ok = en < it.end;
+        idx_n[u] = ok ? col[en] : -1;
+        wt_n[u] = (WEIGHTED && ok) ? w[en] : 0.f;
+      }
+      accumulate(v, wt);
+    }
   }
+  if (!live) return;
   float* out = (it.flags & 1) ? agg : partial;
   if ((it.flags & 1) && cnt) {
     const float c = cnt[it.dst];
