@@ -590,8 +590,14 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restri
 // [32 m][64 kc] and [32 m][128 n] tiles go global -> LDS directly through a ring of three
 // buffers, one raw barrier per m-tile, counted vmcnt (see k_gemm_nt_dma).  Both tiles are read
 // with lanes along the contiguous dimension (ds_read_b32, conflict free), so no swizzle.
-// Same m order per output element => bit-identical to the register-staged kernel.
-__global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restrict__ A1, int K1,
+// WG = 1: same m order per output element => bit-identical to the register-staged kernel.
+// WG = 2 (default): the launch has one workgroup per CU (slab bytes scale with the count), which with
+// four waves leaves each SIMD a single wave and nothing to cover the per-tile barrier and LDS
+// latency.  Eight waves in two groups share every m-tile - group 0 takes its rows 0-15, group 1 its
+// rows 16-31 - so each SIMD has two waves to alternate between; group 1 hands its accumulators
+// over through LDS at the end and group 0 writes the slab (fixed order: deterministic).
+template <int WG>
+__global__ __launch_bounds__(kThreads * WG) void k_gemm_tn_dma(const float* __restrict__ A1, int K1,
                                                           const float* __restrict__ A2, int K2,
                                                           const float* __restrict__ G, int M, int N,
                                                           int n_tiles, int rows_per_split,
@@ -599,7 +605,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
                                                           float* __restrict__ bias_part,
                                                           const uint32_t* __restrict__ tile_mask, int kseg) {
   constexpr int TKC = 64, NBUF = 3, A_FLOATS = 32 * TKC, G_FLOATS = 32 * 128, BUF_FLOATS = A_FLOATS + G_FLOATS;
-  constexpr int A_PW = 2, G_PW = 4, P = A_PW + G_PW;            // LDS-DMA instructions per wave and m-tile
+  constexpr int NT = kThreads * WG;                             // WG groups of 4 waves (see below)
+  constexpr int A_PW = 2 / WG, G_PW = 4 / WG, P = A_PW + G_PW;  // LDS-DMA instructions per wave and m-tile
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF_FLOATS];   // the ONLY LDS object
   const int Kc = K1 + K2;
   // Workgroups are dealt to the 8 XCDs round-robin by linear id.  All tiles of one row split read
@@ -620,7 +627,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
   const int mend = min(M, mbeg + rows_per_split);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wk = wave >> 1, wn = wave & 1;
+  const int grp = wave >> 2, w4 = wave & 3;   // wave group (splits the rows of an m-tile), wave in group
+  const int wk = w4 >> 1, wn = w4 & 1;
   const int li = lane & 31, lh = lane >> 5;
   // column sums of G ride with the first kc tile of the always-dense A2 (root) part, or with
   // kc tile 0 when there is no A2; that workgroup must see every row
@@ -705,33 +713,45 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
     float* sA = lds + (t % NBUF) * BUF_FLOATS;
     float* sG = sA + A_FLOATS;
     if (mt + 32 > mend) {                      // ragged last tile: rows >= mend must contribute 0
-      for (int i = tid; i < 32 * TKC; i += kThreads)
+      for (int i = tid; i < 32 * TKC; i += NT)
         if (mt + i / TKC >= mend) sA[i] = 0.f;
-      for (int i = tid; i < 32 * 128; i += kThreads)
+      for (int i = tid; i < 32 * 128; i += NT)
         if (mt + i / 128 >= mend) sG[i] = 0.f;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
     const unsigned buf_bytes = (unsigned)((t % NBUF) * BUF_FLOATS) * 4u;
-    read_frags(0, 0, buf_bytes);               // ahead of the DMA issue, which covers their LDS latency
+    constexpr int QN = 4 / WG;                  // 8-row steps of an m-tile this wave group works on
+    const int q_first = grp * QN;
+    read_frags(0, q_first, buf_bytes);         // ahead of the DMA issue, which covers their LDS latency
     mt_c = mt_b < mend ? next_mt(mt_b) : mend;
     if (mt_c < mend) stage(mt_c, (t + 2) % NBUF);
     mt_a = mt_b;
     mt_b = mt_c;
     if (do_bias) {
-      float v[32];
+      // column sums of G; the wait is TIED to the registers it guards (an untied `s_waitcnt` lets
+      // the scheduler hoist the adds above it), 16 at a time (asm operand limit)
+      const unsigned baddr = (unsigned)((sG - lds) + tid) * 4u;
 #pragma unroll
-      for (int mm = 0; mm < 32; ++mm)
-        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[mm]) : "v"((unsigned)((sG - lds) + tid) * 4u), "n"(mm * 128 * 4));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int half = 0; half < 2; ++half) {
+        float v[16];
 #pragma unroll
-      for (int mm = 0; mm < 32; ++mm) bsum += v[mm];
+        for (int mm = 0; mm < 16; ++mm)
+          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[mm]) : "v"(baddr + (unsigned)(half * 16 * 128 * 4)), "n"(mm * 128 * 4));
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                       "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]),
+                       "+v"(v[15]));
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm) bsum += v[mm];
+        asm volatile("" ::: "memory");
+      }
     }
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const int cur = q4 & 1;
+    for (int qq = 0; qq < QN; ++qq) {
+      const int cur = qq & 1;
       wait_frags(cur);
-      if (q4 + 1 < 4) read_frags(cur ^ 1, q4 + 1, buf_bytes);
+      if (qq + 1 < QN) read_frags(cur ^ 1, q_first + qq + 1, buf_bytes);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -742,6 +762,24 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_dma(const float* __restric
     }
   }
 
+  if (WG == 2) {
+    // the second wave group hands its accumulators over through LDS (the ring is idle now); the
+    // first adds them to its own - one fixed order - and writes the slab
+    __builtin_amdgcn_s_barrier();
+    float* xch = lds;
+    if (grp == 1) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[((w4 * 2 + b) * 16 + r) * 64 + lane] = acc[b][r];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] += xch[((w4 * 2 + b) * 16 + r) * 64 + lane];
+  }
   float* out = slab + (size_t)split * Kc * N;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
@@ -851,6 +889,14 @@ SplitPlan plan_splits(int64_t M, int64_t Kc, int64_t N) {
   p.rows_per_split = (int)rps;
   p.splits = (int)std::max<int64_t>(1, ceil_div64(M, rps));
   return p;
+}
+
+int tn_wave_groups() {                // wave groups per workgroup of the parameter-gradient GEMM; RGCN_TN_WG=1 for A/B runs
+  static const int v = [] {
+    const char* e = getenv("RGCN_TN_WG");
+    return (e && e[0] == '1') ? 1 : 2;
+  }();
+  return v;
 }
 
 bool force_plain_gemm() {             // RGCN_GEMM=plain: register-staged kernel for every shape (A/B runs)
@@ -990,10 +1036,17 @@ int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, 
   }
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
   if (K1 % 64 == 0 && K2 % 64 == 0 && !force_plain_gemm())
-    k_gemm_tn_dma<<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                 p.rows_per_split, slab, grad_bias ? bias_part : nullptr,
-                                                 (use_tile_masks() && d_in % 64 == 0) ? tile_mask : nullptr,
-                                                 (int)d_in);
+  {
+    const uint32_t* tmask = (use_tile_masks() && d_in % 64 == 0) ? tile_mask : nullptr;
+    if (tn_wave_groups() == 2)
+      k_gemm_tn_dma<2><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
+                                                          p.rows_per_split, slab, grad_bias ? bias_part : nullptr,
+                                                          tmask, (int)d_in);
+    else
+      k_gemm_tn_dma<1><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
+                                                      p.rows_per_split, slab, grad_bias ? bias_part : nullptr,
+                                                      tmask, (int)d_in);
+  }
   else
     k_gemm_tn_slab<1><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
                                                      p.rows_per_split, slab, grad_bias ? bias_part : nullptr);

@@ -260,7 +260,8 @@ def test_transform_kernels(n, r, d_in, d_out):
     assert rel_err(gbias, g.double().sum(0)) <= 5e-6
     gw2, groot2, gbias2 = ops.transform_bwd_params(agg.to(dev), x.to(dev), g.to(dev), r, want_root=False,
                                                    want_bias=False)
-    assert groot2 is None and gbias2 is None and torch.equal(gw2, gw)
+    # (without a root the operand widths can select the other slab kernel, whose row order differs)
+    assert groot2 is None and gbias2 is None and rel_err(gw2, gw.cpu()) <= 1e-6
 
 
 # ------------------------------------------------------------------ the layer against the goldens
