@@ -126,9 +126,10 @@ int rgcn_graph_import(int64_t num_edges, int64_t num_nodes, int64_t num_relation
  *
  * x: float[N, d] (ld = d), agg: float[N*R, d].  d % 4 == 0.  Segments with no edge are
  * written as exact zeros.  Summation inside a segment runs in the bucketed (= original
- * column) order for segments of <= 64 edges; longer ones are summed as a fixed tree of
- * 64-edge chunks, so the result is run-to-run deterministic.
- * `workspace` holds the chunk partial sums: rgcn_aggregate_workspace_bytes(g, t, d).
+ * column) order for segments of <= 64 edges; longer ones are summed as a fixed tree (runs of
+ * 64 edges, four runs to a pack, packs reduced in order), so the result is run-to-run
+ * deterministic.  `workspace` holds one partial row per pack of the segments longer than 256
+ * edges: rgcn_aggregate_workspace_bytes(g, t, d).
  * ---------------------------------------------------------------------------------- */
 size_t rgcn_aggregate_workspace_bytes(const rgcn_graph* g, int transposed, int64_t d);
 int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,

@@ -92,11 +92,14 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
     float* __restrict__ agg, float* __restrict__ partial, int d, const int32_t* __restrict__ head_col,
     const float* __restrict__ head_w) {
+  __shared__ float4 red[kThreads];               // pack combine (see rgcn_common.h)
   const int64_t item_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   const int c4 = ((int)threadIdx.x % G + (int)blockIdx.y * G) * 4;
   if (item_id >= nitems) return;                 // whole lane groups only
   const bool live = c4 < d;                      // lanes past the row end still carry ids for their group
   const rgcn_item it = items[item_id];
+  // packs come first in the item order: the workgroup's first slot says whether any is in here
+  const bool has_packs = (items[(int64_t)blockIdx.x * (kThreads / G)].flags & RGCN_ITEM_PACK) != 0;
 
   float4 acc = f4zero();
   if constexpr (G >= RGCN_HEAD) {
@@ -120,8 +123,7 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
         else f4add(acc, v[u]);
       }
     }
-  } else {
-    if (!live) return;                                  // fewer than 8 lanes per row (d < 32): every lane loads the ids
+  } else if (live) {                            // fewer than 8 lanes per row (d < 32): every lane loads the ids
     int idx_n[kUnroll];
     float wt_n[kUnroll];
 #pragma unroll
@@ -157,8 +159,15 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
       }
     }
   }
+  if (has_packs) {                               // the runs of a pack meet in LDS; its leader adds them in slot order
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (it.flags & (RGCN_ITEM_MEMBER | RGCN_ITEM_SKIP)) return;
+    const int followers = (it.flags >> RGCN_ITEM_FOLLOW_SHIFT) & (RGCN_PACK - 1);
+    for (int f = 1; f <= followers; ++f) f4add(acc, red[threadIdx.x + f * G]);
+  }
   if (!live) return;
-  if (it.flags & 1) {
+  if (it.flags & RGCN_ITEM_FINAL) {
     if (cnt) {  // mean: true division by max(1, segment size), as `sum / count` does
       const float c = cnt[it.dst];
       acc.x /= c; acc.y /= c; acc.z /= c; acc.w /= c;
@@ -179,10 +188,12 @@ __global__ __launch_bounds__(kThreads) void k_aggregate_h(
     float* __restrict__ agg, float* __restrict__ partial, int d, const int32_t* __restrict__ head_col,
     const float* __restrict__ head_w) {
   const int64_t item_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
+  __shared__ float4 red[2 * kThreads];           // pack combine: two float4 per lane
   const int c8 = ((int)threadIdx.x % G + (int)blockIdx.y * G) * 8;
   if (item_id >= nitems) return;
   const bool live = c8 < d;
   const rgcn_item it = items[item_id];
+  const bool has_packs = (items[(int64_t)blockIdx.x * (kThreads / G)].flags & RGCN_ITEM_PACK) != 0;
 
   float acc[8];
 #pragma unroll
@@ -221,8 +232,7 @@ __global__ __launch_bounds__(kThreads) void k_aggregate_h(
       win.advance(gl, col, w);
       accumulate(v, wt);
     }
-  } else {
-    if (!live) return;
+  } else if (live) {
     int idx_n[kUnroll];
     float wt_n[kUnroll];
 #pragma unroll
@@ -254,9 +264,21 @@ __global__ __launch_bounds__(kThreads) void k_aggregate_h(
       accumulate(v, wt);
     }
   }
+  if (has_packs) {
+    red[2 * threadIdx.x] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    red[2 * threadIdx.x + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    __syncthreads();
+    if (it.flags & (RGCN_ITEM_MEMBER | RGCN_ITEM_SKIP)) return;
+    const int followers = (it.flags >> RGCN_ITEM_FOLLOW_SHIFT) & (RGCN_PACK - 1);
+    for (int f = 1; f <= followers; ++f) {
+      const float4 a = red[2 * (threadIdx.x + f * G)], b = red[2 * (threadIdx.x + f * G) + 1];
+      acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+      acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    }
+  }
   if (!live) return;
-  float* out = (it.flags & 1) ? agg : partial;
-  if ((it.flags & 1) && cnt) {
+  float* out = (it.flags & RGCN_ITEM_FINAL) ? agg : partial;
+  if ((it.flags & RGCN_ITEM_FINAL) && cnt) {
     const float c = cnt[it.dst];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] /= c;
@@ -300,7 +322,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* _
     float4 s = red[gl];
 #pragma unroll
     for (int k = 1; k < SLOTS; ++k) f4add(s, red[k * G + gl]);
-    if (it.flags & 1) {
+    if (it.flags & RGCN_ITEM_FINAL) {
       if (cnt) {
         const float c = cnt[it.dst];
         s.x /= c; s.y /= c; s.z /= c; s.w /= c;

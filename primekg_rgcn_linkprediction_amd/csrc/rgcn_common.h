@@ -23,11 +23,23 @@ constexpr int RGCN_HEAD = 8;
 // One unit of aggregate work: sum source rows [begin, end) into row `dst`.
 //   level 0 : source rows are x[col[e]] for e in [begin, end)
 //   level>0 : source rows are partial[begin .. end) (contiguous)
-//   flags&1 : `dst` is a final segment row of agg (apply the mean divide), otherwise a row
-//             of the partial-sum workspace.
+//   flags & RGCN_ITEM_FINAL : `dst` is a final segment row of agg (apply the mean divide), otherwise
+//             a row of the partial-sum workspace.
+// Level 0 only - packs: a segment longer than RGCN_CHUNK edges is cut into runs of RGCN_CHUNK, and
+// up to RGCN_PACK consecutive runs form a pack that sits in RGCN_PACK consecutive, RGCN_PACK-aligned
+// item slots - hence inside one gather workgroup for every row width - whose lane groups combine
+// their sums through LDS: the pack's first item (the leader) adds the `followers` after it in slot
+// order and writes ONE row (final if the whole segment is this pack, a partial row otherwise).
+//   RGCN_ITEM_PACK   : slot belongs to a pack (leader, member or padding)
+//   RGCN_ITEM_MEMBER : not the leader: contributes through LDS, writes nothing
+//   RGCN_ITEM_SKIP   : padding slot of a short pack: nothing to do
+//   bits 8..9        : leader only - number of members that follow (0..RGCN_PACK-1)
 struct rgcn_item {
   int32_t begin, end, dst, flags;
 };
+constexpr int RGCN_PACK = 4;
+enum : int32_t { RGCN_ITEM_FINAL = 1, RGCN_ITEM_PACK = 2, RGCN_ITEM_MEMBER = 4, RGCN_ITEM_SKIP = 8 };
+constexpr int RGCN_ITEM_FOLLOW_SHIFT = 8;
 
 struct rgcn_csr {
   int32_t* rowptr = nullptr;  // [N*R+1]

@@ -81,41 +81,86 @@ __global__ void k_permute_weights(const float* __restrict__ w_in, const int64_t*
 
 inline unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, ceil_div64(n, kThreads)); }
 
-// Host-side plan: split every segment into runs of <= RGCN_CHUNK source rows; runs of a
-// multi-run segment write partial sums that the next level reduces in runs of <= RGCN_CHUNK_UP
-// partial rows (a workgroup per run), until one run is left.  Inside a level the items are ordered by descending length so that the lane
-// groups of one wavefront finish together (no divergence tail) and long items start first.
+// Host-side plan.  Level 0: a segment of <= RGCN_CHUNK edges is one item; a longer one is cut into
+// runs of RGCN_CHUNK edges grouped into packs of RGCN_PACK runs (see rgcn_common.h): a pack is summed
+// inside one gather workgroup and leaves ONE row - the segment's final row if it is the only pack
+// (<= 256 edges), a partial row otherwise.  Levels >= 1 reduce the partial rows of a segment in runs
+// of <= RGCN_CHUNK_UP (a workgroup per run) until one row is left.  Order inside level 0: packs first
+// (by descending edge count), then the single items by descending length, so the lane groups of a
+// wavefront finish together and long items start first; packs occupy RGCN_PACK-aligned slots.
 int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, rgcn_csr* csr) {
   struct Pending { int32_t seg, begin, end; };
+  struct Pack { int32_t begin, end, dst, final_row; };
   std::vector<std::vector<rgcn_item>> levels;
   std::vector<Pending> pending, next;
+  std::vector<rgcn_item> singles;
+  std::vector<Pack> packs;
   int64_t partial_rows = 0;
 
-  auto emit = [&](std::vector<rgcn_item>& out, std::vector<Pending>& nxt, int32_t seg,
-                  int32_t begin, int32_t end, int32_t chunk) {
-    int32_t len = end - begin;
-    if (len <= chunk) {
-      out.push_back({begin, end, seg, 1});
+  for (int64_t s = 0; s < NR; ++s) {
+    const int32_t begin = rowptr[s], end = rowptr[s + 1], len = end - begin;
+    if (len <= RGCN_CHUNK) {
+      singles.push_back({begin, end, (int32_t)s, RGCN_ITEM_FINAL});
+      continue;
+    }
+    const int32_t span = RGCN_CHUNK * RGCN_PACK;
+    const int32_t npacks = (int32_t)ceil_div64(len, span);
+    if (npacks == 1) {
+      packs.push_back({begin, end, (int32_t)s, 1});
+    } else {
+      const int32_t pbase = (int32_t)partial_rows;
+      for (int32_t p = 0; p < npacks; ++p)
+        packs.push_back({begin + p * span, std::min(begin + (p + 1) * span, end), pbase + p, 0});
+      partial_rows += npacks;
+      pending.push_back({(int32_t)s, pbase, pbase + npacks});
+    }
+  }
+  std::stable_sort(packs.begin(), packs.end(),
+                   [](const Pack& a, const Pack& b) { return (a.end - a.begin) > (b.end - b.begin); });
+  std::stable_sort(singles.begin(), singles.end(), [](const rgcn_item& a, const rgcn_item& b) {
+    return (a.end - a.begin) > (b.end - b.begin);
+  });
+  levels.emplace_back();
+  levels[0].reserve(packs.size() * RGCN_PACK + singles.size());
+  for (const Pack& pk : packs) {
+    const int32_t runs = (int32_t)ceil_div64(pk.end - pk.begin, RGCN_CHUNK);
+    for (int32_t c = 0; c < RGCN_PACK; ++c) {
+      if (c >= runs) {
+        levels[0].push_back({0, 0, 0, RGCN_ITEM_PACK | RGCN_ITEM_SKIP});
+        continue;
+      }
+      const int32_t b = pk.begin + c * RGCN_CHUNK, e = std::min(b + RGCN_CHUNK, pk.end);
+      int32_t flags = RGCN_ITEM_PACK;
+      if (c == 0) flags |= (pk.final_row ? RGCN_ITEM_FINAL : 0) | ((runs - 1) << RGCN_ITEM_FOLLOW_SHIFT);
+      else flags |= RGCN_ITEM_MEMBER;
+      levels[0].push_back({b, e, pk.dst, flags});
+    }
+  }
+  levels[0].insert(levels[0].end(), singles.begin(), singles.end());
+
+  auto emit_up = [&](std::vector<rgcn_item>& out, std::vector<Pending>& nxt, const Pending& p) {
+    const int32_t len = p.end - p.begin;
+    if (len <= RGCN_CHUNK_UP) {
+      out.push_back({p.begin, p.end, p.seg, RGCN_ITEM_FINAL});
       return;
     }
-    int32_t nch = (int32_t)ceil_div64(len, chunk);
-    int32_t pbase = (int32_t)partial_rows;
+    const int32_t nch = (int32_t)ceil_div64(len, RGCN_CHUNK_UP);
+    const int32_t pbase = (int32_t)partial_rows;
     for (int32_t c = 0; c < nch; ++c) {
-      int32_t b = begin + c * chunk;
-      out.push_back({b, std::min(b + chunk, end), pbase + c, 0});
+      const int32_t b = p.begin + c * RGCN_CHUNK_UP;
+      out.push_back({b, std::min(b + RGCN_CHUNK_UP, p.end), pbase + c, 0});
     }
     partial_rows += nch;
-    nxt.push_back({seg, pbase, pbase + nch});
+    nxt.push_back({p.seg, pbase, pbase + nch});
   };
-
-  levels.emplace_back();
-  levels[0].reserve((size_t)NR + 16);
-  for (int64_t s = 0; s < NR; ++s) emit(levels[0], pending, (int32_t)s, rowptr[s], rowptr[s + 1], RGCN_CHUNK);
   while (!pending.empty()) {
     if ((int)levels.size() >= RGCN_MAX_LEVELS) return RGCN_ERR_UNSUPPORTED;
     levels.emplace_back();
     next.clear();
-    for (const Pending& p : pending) emit(levels.back(), next, p.seg, p.begin, p.end, RGCN_CHUNK_UP);
+    for (const Pending& p : pending) emit_up(levels.back(), next, p);
+    std::stable_sort(levels.back().begin(), levels.back().end(), [](const rgcn_item& a, const rgcn_item& b) {
+      return (a.end - a.begin) > (b.end - b.begin);
+    });
     pending.swap(next);
   }
   if (partial_rows > INT32_MAX) return RGCN_ERR_UNSUPPORTED;
@@ -124,9 +169,6 @@ int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, rgcn_csr* csr) {
   csr->num_partials = partial_rows;
   for (int l = 0; l < csr->num_levels; ++l) {
     auto& v = levels[l];
-    std::stable_sort(v.begin(), v.end(), [](const rgcn_item& a, const rgcn_item& b) {
-      return (a.end - a.begin) > (b.end - b.begin);
-    });
     csr->num_items[l] = (int64_t)v.size();
     if (v.empty()) continue;
     RGCN_HIP_TRY(hipMalloc((void**)&csr->items[l], v.size() * sizeof(rgcn_item)));

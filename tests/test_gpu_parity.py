@@ -762,7 +762,7 @@ def test_c_abi_error_codes_with_real_handles():
     g = ops.BucketedGraph(ei.to(dev), torch.zeros(500, dtype=torch.int64, device=dev), 50, 2)
     d = 64
     need = lib.rgcn_aggregate_workspace_bytes(g.handle, 0, d)
-    assert need == 8 * d * 4                              # ceil(500 / 64) partial rows
+    assert need == 2 * d * 4                              # 8 runs of 64 edges = 2 packs of 4 = 2 partial rows
     x = torch.randn(50, d, device=dev)
     agg = torch.empty(100, d, device=dev)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
