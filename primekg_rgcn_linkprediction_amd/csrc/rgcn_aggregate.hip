@@ -13,10 +13,12 @@
 // behind them, and the adds retire in edge order, which keeps the sum of an unsplit segment
 // identical to a sequential scatter.
 //
-// Segments longer than 64 edges leave one partial row per run; k_reduce_partials sums the
-// (contiguous) partial rows of a segment with a whole workgroup per item (up to 512 rows:
-// 256/G row slots in parallel, LDS combine in slot order), so even a 30k-edge hub costs one
-// extra short launch and the result is run-to-run deterministic.
+// A segment longer than 64 edges is walked as runs of 64; four consecutive runs (a pack) sit in one
+// workgroup and are combined through LDS, so a segment of up to 256 edges is finished here and a
+// longer one leaves one partial row per pack; k_reduce_partials sums the (contiguous) partial rows
+// of a segment with a whole workgroup per item (up to 512 rows: 256/G row slots in parallel, LDS
+// combine in slot order), so even a 100k-edge hub costs one extra short launch and the result is
+// run-to-run deterministic.
 #include <hip/hip_fp16.h>
 
 #include "rgcn_common.h"
