@@ -207,7 +207,35 @@ class BucketedGraph:
         _lib.check(rc, "rgcn_graph_export")
         return rowptr, col, perm, val
 
+    def merged_transposed(self) -> Optional["BucketedGraph"]:
+        """The out-edges of every node across ALL relations as one weighted gather structure over
+        a table of ``N * (R + 1)`` rows: edge (j -> i, r) reads row ``i * (R + 1) + r`` with weight
+        ``1 / cnt[i, r]``, and every node j additionally reads its own row ``j * (R + 1) + R`` with
+        weight 1.  With ``T = g @ [W_0^T | ... | W_{R-1}^T | root^T]`` viewed ``[N * (R + 1), d_in]``
+        the layer's input gradient is ``aggregate(merged, T)`` - transform first, then gather
+        ``d_in``-wide rows instead of ``d_out``-wide ones.  Built lazily from the transposed
+        structure (already in (source, relation) order), once; None if it would not fit int32."""
+        if self.bipartite:
+            raise ValueError("a shard structure has no merged form")
+        if getattr(self, "_merged", None) is None:
+            n, r, e = self.num_nodes, self.num_relations, self.num_edges
+            if n * (r + 1) >= 2 ** 31 - 1 or e + n >= 2 ** 31 - 1:
+                return None
+            rowptr_t, col_t, _, w_t = self.arrays(True)
+            counts = (rowptr_t[1:] - rowptr_t[:-1]).long()
+            seg = torch.repeat_interleave(torch.arange(n * r, device=self.device), counts)   # = src * R + rel
+            nodes = torch.arange(n, device=self.device)
+            key = torch.cat([seg // r, nodes])
+            other = torch.cat([col_t.long() * (r + 1) + seg % r, nodes * (r + 1) + r])
+            weight = torch.cat([w_t, torch.ones(n, device=self.device)])
+            self._merged = BucketedGraph.from_shard(key, other, torch.zeros_like(key), n, n * (r + 1), 1, weight)
+        return self._merged
+
     def destroy(self) -> None:
+        merged = getattr(self, "_merged", None)
+        if merged is not None:
+            merged.destroy()
+            self._merged = None
         if self._handle is not None:
             try:
                 _lib.load().rgcn_graph_destroy(self._handle)
