@@ -825,3 +825,28 @@ def test_transform_first_input_gradient_equals_gather_first():
     g = torch.randn(n, 64, generator=gen).to(dev)
     assert torch.equal(_input_grad(graph, g, w, root),
                        ops.transform_bwd_input(ops.aggregate(graph, g, transposed=True), g, w, root, graph=graph))
+
+
+def test_integration_md_ctypes_stub_runs_as_written():
+    """The binding INTEGRATION.md section 2 shows a maintainer is executed verbatim and checked
+    against the oracle - the document cannot drift from the ABI."""
+    import os
+    import re
+    dev = need_gpu()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"## 2\..*?```python\n(.*?)```", text, re.S).group(1)
+    cwd = os.getcwd()
+    os.chdir(root)                                          # the stub opens the library by relative path
+    try:
+        scope = {}
+        exec(compile(block, "INTEGRATION.md", "exec"), scope)
+    finally:
+        os.chdir(cwd)
+    ei, et, n, r = synth.uniform_graph(500, 6000, 3, seed=12)
+    gen = torch.Generator().manual_seed(12)
+    x, w = torch.randn(n, 64, generator=gen), torch.randn(r, 64, 128, generator=gen) * 0.1
+    rt, b = torch.randn(64, 128, generator=gen) * 0.1, torch.randn(128, generator=gen)
+    out = scope["rgcn_forward"](x.to(dev), ei.to(dev), et.to(dev), w.to(dev), rt.to(dev), b.to(dev))
+    torch.cuda.synchronize()
+    assert_fwd(out, O.rgcn_conv_ref(x, ei, et, w, rt, b))
