@@ -795,8 +795,9 @@ __global__ __launch_bounds__(kThreads * WG) void k_gemm_tn_dma(const float* __re
 }
 
 // Fixed-order sum of the slabs (deterministic), split between grad_weight and grad_root.
-// 64 outputs (float4 each) x 4 slab groups per workgroup: group g sums slabs
-// [g*S/4, (g+1)*S/4) in order, then the four partials are added in group order.
+// OUTS outputs (float4 each) x GROUPS slab groups per workgroup: group g sums slabs
+// [g*S/GROUPS, (g+1)*S/GROUPS) in order, then the partials are added in group order.
+template <int OUTS, int GROUPS>
 __global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restrict__ slab,
                                                            const float* __restrict__ bias_part, int S, int K1,
                                                            int Kc, int N, float* __restrict__ grad_weight,
@@ -804,9 +805,10 @@ __global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restri
                                                            float* __restrict__ grad_bias) {
   __shared__ float4 red[kThreads];
   const int64_t nq = (int64_t)Kc * N / 4;                       // float4 outputs of the weight grads
-  const int64_t q = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int grp = threadIdx.x >> 6;
-  const int s0 = (int)((int64_t)S * grp / 4), s1 = (int)((int64_t)S * (grp + 1) / 4);
+  static_assert(OUTS * GROUPS == kThreads, "one thread per (output, slab group)");
+  const int64_t q = (int64_t)blockIdx.x * OUTS + ((int)threadIdx.x % OUTS);
+  const int grp = (int)threadIdx.x / OUTS;
+  const int s0 = (int)((int64_t)S * grp / GROUPS), s1 = (int)((int64_t)S * (grp + 1) / GROUPS);
   float4 acc = f4zero();
   if (q < nq) {
     const float* p = slab + (size_t)q * 4;
@@ -838,8 +840,8 @@ __global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restri
   if (grp != 0) return;
   float4 s = red[threadIdx.x];
 #pragma unroll
-  for (int g = 1; g < 4; ++g) {
-    const float4 v = red[g * 64 + threadIdx.x];
+  for (int g = 1; g < GROUPS; ++g) {
+    const float4 v = red[g * OUTS + threadIdx.x];
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   if (q < nq) {
@@ -1051,9 +1053,17 @@ int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, 
     k_gemm_tn_slab<1><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
                                                      p.rows_per_split, slab, grad_bias ? bias_part : nullptr);
   const int64_t nq = (int64_t)Kc * d_out / 4 + (d_out + 3) / 4;
-  k_reduce_slabs<<<(unsigned)ceil_div64(nq, 64), kThreads, 0, stream>>>(slab, bias_part, p.splits, K1, Kc,
-                                                                        (int)d_out, grad_weight, grad_root,
-                                                                        grad_bias);
+  {
+    // 16 outputs x 16 slab groups per workgroup: short load chains and >= 4 workgroups per CU for a
+    // reduction that is all latency (RGCN_SLAB_GROUPS=4: 64 x 4, for A/B runs)
+    static const int groups = [] { const char* e = getenv("RGCN_SLAB_GROUPS"); return e ? atoi(e) : 16; }();
+    if (groups == 4)
+      k_reduce_slabs<64, 4><<<(unsigned)ceil_div64(nq, 64), kThreads, 0, stream>>>(
+          slab, bias_part, p.splits, K1, Kc, (int)d_out, grad_weight, grad_root, grad_bias);
+    else
+      k_reduce_slabs<16, 16><<<(unsigned)ceil_div64(nq, 16), kThreads, 0, stream>>>(
+          slab, bias_part, p.splits, K1, Kc, (int)d_out, grad_weight, grad_root, grad_bias);
+  }
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
