@@ -203,3 +203,30 @@ def test_bucket_input_validation_on_host():
         ops.BucketedGraph(torch.zeros(2, 4, dtype=torch.long), torch.zeros(3, dtype=torch.long), 5, 2)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.BucketedGraph(torch.zeros(2, 4, dtype=torch.long), torch.zeros(4, dtype=torch.long), 5, 2)
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/rgcn_hip.h compiles as C99 and as C++ (-pedantic), and a C program linked against
+    librgcn_hip.so sees the ABI version the header declares - the boundary is a real C ABI."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include "include/rgcn_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%d %d %s\\n", rgcn_abi_version(), RGCN_ABI_VERSION, rgcn_strerror(-2));\n'
+                   '  return rgcn_graph_num_edges(0) == -1 ? 0 : 1; }\n')
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++17")):
+        subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-fsyntax-only", "-x", "c" if cc == "gcc" else "c++",
+                        "-I", root, str(src)], check=True)
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "abi"
+    subprocess.run(["gcc", "-std=c99", "-I", root, str(src), "-o", str(exe), "-L", lib_dir, "-l:librgcn_hip.so",
+                    f"-Wl,-rpath,{lib_dir}", "-Wl,--allow-shlib-undefined"], check=True)
+    import torch as _torch                                     # its bundled HIP runtime satisfies the .so at run time
+    hip_dir = os.path.join(os.path.dirname(_torch.__file__), "lib")
+    env = dict(os.environ, LD_LIBRARY_PATH=hip_dir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=env).stdout.split(maxsplit=2)
+    assert out[0] == out[1] == str(_lib.ABI_VERSION) and "outside" in out[2]
