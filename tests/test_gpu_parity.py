@@ -850,3 +850,45 @@ def test_integration_md_ctypes_stub_runs_as_written():
     out = scope["rgcn_forward"](x.to(dev), ei.to(dev), et.to(dev), w.to(dev), rt.to(dev), b.to(dev))
     torch.cuda.synchronize()
     assert_fwd(out, O.rgcn_conv_ref(x, ei, et, w, rt, b))
+
+
+@pytest.mark.parametrize("d", [4, 8, 32, 64, 128, 256, 320])
+def test_segment_lengths_around_run_and_pack_boundaries(d):
+    """One destination per in-degree in {0, 1, 7, 8, 9, 63..65, 127..129, 191..193, 255..257, 300,
+    511..513, 1023..1025, 2049, 16385+}: single items, packs of 2..4 runs, short last packs, multi-level
+    reduction - forward (mean) and transposed (weighted) gathers vs the oracle, fp32 and fp16 tables."""
+    dev = need_gpu()
+    lengths = [0, 1, 7, 8, 9, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 300, 511, 512, 513,
+               1023, 1024, 1025, 2049, 16385 + 3 * 256 + 70]
+    n, r = 40, 2
+    gen = torch.Generator().manual_seed(d)
+    dst = torch.cat([torch.full((L,), i, dtype=torch.int64) for i, L in enumerate(lengths)])
+    src = torch.randint(0, n, (dst.numel(),), generator=gen)
+    rel = torch.zeros_like(dst)
+    rel[dst % 2 == 1] = 1                                   # odd destinations use relation 1
+    order = torch.randperm(dst.numel(), generator=gen)      # original column order is arbitrary
+    ei, et = torch.stack([src, dst])[:, order].contiguous(), rel[order].contiguous()
+    g = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
+    x = torch.randn(n, d, generator=gen)
+    tol = 3e-6                                              # relative to the largest entry, vs float64 sums
+
+    def mean_ref(table):
+        return O.mean_aggregate_ref(table.double(), ei, et, r).view(n, -1)
+
+    assert rel_err(ops.aggregate(g, x.to(dev)), mean_ref(x)) <= tol
+    if d % 8 == 0:
+        assert rel_err(ops.aggregate(g, x.to(dev).half()), mean_ref(x.half())) <= tol
+
+    def weighted_ref(edges):
+        cnt = torch.bincount(edges[1] * r + et, minlength=n * r).clamp(min=1).float()
+        w = (1.0 / cnt[edges[1] * r + et]).double()          # the fp32 weights the structure stores, summed in float64
+        return torch.zeros(n * r, d, dtype=torch.float64).index_add_(
+            0, edges[0] * r + et, x.double()[edges[1]] * w.view(-1, 1)).view(n, -1)
+
+    # transposed: sources are random, so source segments are moderate, weights 1/cnt of every size
+    assert rel_err(ops.aggregate(g, x.to(dev), transposed=True), weighted_ref(ei)) <= tol
+    # the same lengths on the SOURCE side: long weighted segments (packs + reduction in weighted mode)
+    ei2 = ei.flip(0).contiguous()
+    g2 = ops.BucketedGraph(ei2.to(dev), et.to(dev), n, r)
+    assert rel_err(ops.aggregate(g2, x.to(dev), transposed=True), weighted_ref(ei2)) <= tol
+    assert g.num_levels(False) == 2 and g2.num_levels(True) == 2
