@@ -117,9 +117,14 @@ int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, rgcn_csr* csr) {
   }
   std::stable_sort(packs.begin(), packs.end(),
                    [](const Pack& a, const Pack& b) { return (a.end - a.begin) > (b.end - b.begin); });
-  std::stable_sort(singles.begin(), singles.end(), [](const rgcn_item& a, const rgcn_item& b) {
-    return (a.end - a.begin) > (b.end - b.begin);
-  });
+  {  // singles by descending length, stable: lengths are 0..RGCN_CHUNK, so a counting sort does it
+    std::vector<int64_t> start(RGCN_CHUNK + 2, 0);
+    for (const rgcn_item& it : singles) ++start[RGCN_CHUNK - (it.end - it.begin) + 1];
+    for (int l = 0; l <= RGCN_CHUNK; ++l) start[l + 1] += start[l];
+    std::vector<rgcn_item> sorted(singles.size());
+    for (const rgcn_item& it : singles) sorted[(size_t)start[RGCN_CHUNK - (it.end - it.begin)]++] = it;
+    singles.swap(sorted);
+  }
   levels.emplace_back();
   levels[0].reserve(packs.size() * RGCN_PACK + singles.size());
   for (const Pack& pk : packs) {
