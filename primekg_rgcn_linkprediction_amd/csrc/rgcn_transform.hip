@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_tn_slab(const float* __restri
 // latency.  Eight waves in two groups share every m-tile - group 0 takes its rows 0-15, group 1 its
 // rows 16-31 - so each SIMD has two waves to alternate between; group 1 hands its accumulators
 // over through LDS at the end and group 0 writes the slab (fixed order: deterministic).
-template <int WG>
+template <int WG, int NBUF>
 __global__ __launch_bounds__(kThreads * WG) void k_gemm_tn_dma(const float* __restrict__ A1, int K1,
                                                           const float* __restrict__ A2, int K2,
                                                           const float* __restrict__ G, int M, int N,
@@ -604,7 +604,10 @@ __global__ __launch_bounds__(kThreads * WG) void k_gemm_tn_dma(const float* __re
                                                           float* __restrict__ slab,
                                                           float* __restrict__ bias_part,
                                                           const uint32_t* __restrict__ tile_mask, int kseg) {
-  constexpr int TKC = 64, NBUF = 3, A_FLOATS = 32 * TKC, G_FLOATS = 32 * 128, BUF_FLOATS = A_FLOATS + G_FLOATS;
+  // ring of NBUF LDS buffers: the m-tile being multiplied + NBUF-1 in flight.  A streams from HBM here
+  // (agg was written a whole forward pass ago), so the ring is one deeper than in k_gemm_nt_dma.
+  // NBUF = 4 (96 KB) when the launch has one workgroup per CU, 3 (72 KB) when two must fit.
+  constexpr int TKC = 64, A_FLOATS = 32 * TKC, G_FLOATS = 32 * 128, BUF_FLOATS = A_FLOATS + G_FLOATS;
   constexpr int NT = kThreads * WG;                             // WG groups of 4 waves (see below)
   constexpr int A_PW = 2 / WG, G_PW = 4 / WG, P = A_PW + G_PW;  // LDS-DMA instructions per wave and m-tile
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF_FLOATS];   // the ONLY LDS object
@@ -676,9 +679,12 @@ __global__ __launch_bounds__(kThreads * WG) void k_gemm_tn_dma(const float* __re
     }
   };
 
-  int mt_a = next_mt(mbeg - 32), mt_b = mt_a < mend ? next_mt(mt_a) : mend, mt_c = mend;
+  // mt_a: the tile being multiplied; mt_b, mt_c: staged behind it (mt_c only with four buffers)
+  int mt_a = next_mt(mbeg - 32), mt_b = mt_a < mend ? next_mt(mt_a) : mend,
+      mt_c = (NBUF == 4 && mt_b < mend) ? next_mt(mt_b) : mend, mt_d = mend;
   if (mt_a < mend) stage(mt_a, 0);
   if (mt_b < mend) stage(mt_b, 1);
+  if (NBUF == 4 && mt_c < mend) stage(mt_c, 2);
   const unsigned a_addr = (unsigned)(lh * TKC + wk * 32 + li) * 4u;
   const unsigned g_addr = (unsigned)(A_FLOATS + lh * 128 + wn * 64 + li) * 4u;
   float fa[2][4], fg[2][4][2];
@@ -707,7 +713,9 @@ __global__ __launch_bounds__(kThreads * WG) void k_gemm_tn_dma(const float* __re
 
   for (int t = 0; mt_a < mend; ++t) {
     const int mt = mt_a;
-    if (mt_b < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+    // tile mt landed for this wave: everything but the DMAs of the (up to two) tiles staged after it
+    if (NBUF == 4 && mt_c < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    else if (mt_b < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     float* sA = lds + (t % NBUF) * BUF_FLOATS;
@@ -724,10 +732,18 @@ __global__ __launch_bounds__(kThreads * WG) void k_gemm_tn_dma(const float* __re
     constexpr int QN = 4 / WG;                  // 8-row steps of an m-tile this wave group works on
     const int q_first = grp * QN;
     read_frags(0, q_first, buf_bytes);         // ahead of the DMA issue, which covers their LDS latency
-    mt_c = mt_b < mend ? next_mt(mt_b) : mend;
-    if (mt_c < mend) stage(mt_c, (t + 2) % NBUF);
-    mt_a = mt_b;
-    mt_b = mt_c;
+    if (NBUF == 4) {
+      mt_d = mt_c < mend ? next_mt(mt_c) : mend;
+      if (mt_d < mend) stage(mt_d, (t + 3) % NBUF);
+      mt_a = mt_b;
+      mt_b = mt_c;
+      mt_c = mt_d;
+    } else {
+      mt_d = mt_b < mend ? next_mt(mt_b) : mend;
+      if (mt_d < mend) stage(mt_d, (t + 2) % NBUF);
+      mt_a = mt_b;
+      mt_b = mt_d;
+    }
     if (do_bias) {
       // column sums of G; the wait is TIED to the registers it guards (an untied `s_waitcnt` lets
       // the scheduler hoist the adds above it), 16 at a time (asm operand limit)
@@ -1040,14 +1056,17 @@ int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, 
   if (K1 % 64 == 0 && K2 % 64 == 0 && !force_plain_gemm())
   {
     const uint32_t* tmask = (use_tile_masks() && d_in % 64 == 0) ? tile_mask : nullptr;
-    if (tn_wave_groups() == 2)
-      k_gemm_tn_dma<2><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                          p.rows_per_split, slab, grad_bias ? bias_part : nullptr,
-                                                          tmask, (int)d_in);
+    const bool one_per_cu = (int64_t)grid.x * grid.y <= 320;    // deeper ring when LDS need not hold two workgroups
+    float* bp = grad_bias ? bias_part : nullptr;
+    if (tn_wave_groups() == 2 && one_per_cu)
+      k_gemm_tn_dma<2, 4><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
+                                                             p.rows_per_split, slab, bp, tmask, (int)d_in);
+    else if (tn_wave_groups() == 2)
+      k_gemm_tn_dma<2, 3><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
+                                                             p.rows_per_split, slab, bp, tmask, (int)d_in);
     else
-      k_gemm_tn_dma<1><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                      p.rows_per_split, slab, grad_bias ? bias_part : nullptr,
-                                                      tmask, (int)d_in);
+      k_gemm_tn_dma<1, 3><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
+                                                         p.rows_per_split, slab, bp, tmask, (int)d_in);
   }
   else
     k_gemm_tn_slab<1><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
