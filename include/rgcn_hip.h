@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 6
+#define RGCN_ABI_VERSION 7
 
 enum {
   RGCN_OK = 0,
@@ -242,6 +242,23 @@ int rgcn_sample_batch(const int64_t* edge_index, const int64_t* edge_type, int64
                       const int64_t* order, const int64_t* cursor, int64_t batch, int64_t num_neg,
                       int64_t num_nodes, const int64_t* rng, int64_t* heads, int64_t* tails,
                       int64_t* rels, float* labels, void* stream);
+
+/* Gradient clipping + Adam / AdamW update of the training step (SURVEY section 8f "next" row 1;
+ * reference `clip_grad_norm_(model.parameters(), grad_clip)` + `optimizer.step()`,
+ * src/train.py:311-317) in two launches over a list of up to 32 fp32 parameter tensors:
+ *   total = ||all grads||_2;  every gradient is scaled by min(1, max_norm / (total + 1e-6)) when
+ *   max_norm > 0 (the scaled value is used, not written back); then torch.optim.Adam's update - or
+ *   AdamW's decoupled decay when `adamw` != 0 - with bias correction from the step count.
+ * params / grads / exp_avg / exp_avg_sq / steps: HOST arrays of `num_tensors` DEVICE pointers (the
+ * pointers travel in the launch arguments, so a captured HIP graph keeps working on them); steps[t]:
+ * DEVICE float[1], torch's per-tensor step count, bumped by one per call on the device.
+ * total_norm: DEVICE float[1] or NULL.  workspace: rgcn_adam_workspace_bytes(num_tensors, numels). */
+size_t rgcn_adam_workspace_bytes(int num_tensors, const int64_t* numels);
+int rgcn_adam_clip_step(int num_tensors, float* const* params, const float* const* grads,
+                        float* const* exp_avg, float* const* exp_avg_sq, float* const* steps,
+                        const int64_t* numels, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int adamw, float max_norm, float* total_norm,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Tail ranking for evaluation (LinkPredictor.score_all_tails rgcn.py:215-243 +
  * compute_ranking_metrics evaluate.py:260-276, without materialising the [B, N] score matrix

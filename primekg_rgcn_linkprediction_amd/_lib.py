@@ -9,11 +9,11 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_float, POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_p
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -57,6 +57,9 @@ PROTOTYPES = {
     "distmult_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "distmult_rank_tails": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "distmult_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "rgcn_adam_workspace_bytes": (c_size_t, [c_int, _P]),
+    "rgcn_adam_clip_step": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int,
+                                    c_float, _P, _P, c_size_t, _P]),
     "rgcn_sample_batch": (c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "distmult_bce_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "distmult_bce_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),

@@ -519,6 +519,45 @@ def distmult_fwd(h, h_idx, t, t_idx, r, r_idx, batch: int) -> torch.Tensor:
     return scores
 
 
+def adam_clip_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr: float, beta1: float, beta2: float, eps: float,
+                   weight_decay: float = 0.0, adamw: bool = False, max_norm: float = 0.0,
+                   total_norm: Optional[torch.Tensor] = None) -> None:
+    """``clip_grad_norm_(params, max_norm)`` (``max_norm <= 0``: no clipping) followed by one
+    ``torch.optim.Adam`` / ``AdamW`` step, in two launches (``rgcn_adam_clip_step``).  All lists
+    are parallel, fp32, contiguous CUDA tensors; ``steps[t]`` is the one-element device step count of
+    tensor t (bumped here).  Parameters and moments are updated in place; gradients are left as
+    they are (the clipped values are used, not stored)."""
+    n = len(params)
+    if not (len(grads) == len(exp_avgs) == len(exp_avg_sqs) == len(steps) == n):
+        raise ValueError("params, grads, exp_avgs, exp_avg_sqs and steps must be equally long")
+    if n == 0:
+        return
+    if n > 32:
+        raise ValueError("at most 32 parameter tensors per call")
+    for i in range(n):
+        for name, t in (("param", params[i]), ("grad", grads[i]), ("exp_avg", exp_avgs[i]),
+                        ("exp_avg_sq", exp_avg_sqs[i]), ("step", steps[i])):
+            _need_gpu(f"{name}[{i}]", t, torch.float32)
+        if not (grads[i].shape == exp_avgs[i].shape == exp_avg_sqs[i].shape == params[i].shape) or steps[i].numel() != 1:
+            raise ValueError(f"tensor {i}: param / grad / moments must have one shape, step one element")
+    lib = _lib.load()
+    dev = params[0].device
+    arr = ctypes.c_void_p * n
+    numels = (ctypes.c_int64 * n)(*[p.numel() for p in params])
+    with torch.cuda.device(dev):
+        nbytes = lib.rgcn_adam_workspace_bytes(n, ctypes.cast(numels, ctypes.c_void_p))
+        ws = _workspace(nbytes, dev)
+        rc = lib.rgcn_adam_clip_step(
+            n, ctypes.cast(arr(*[_ptr(t) for t in params]), ctypes.c_void_p),
+            ctypes.cast(arr(*[_ptr(t) for t in grads]), ctypes.c_void_p),
+            ctypes.cast(arr(*[_ptr(t) for t in exp_avgs]), ctypes.c_void_p),
+            ctypes.cast(arr(*[_ptr(t) for t in exp_avg_sqs]), ctypes.c_void_p),
+            ctypes.cast(arr(*[_ptr(t) for t in steps]), ctypes.c_void_p), ctypes.cast(numels, ctypes.c_void_p),
+            float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(adamw), float(max_norm),
+            _ptr(total_norm), _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "rgcn_adam_clip_step")
+
+
 def sample_batch(edge_index: torch.Tensor, edge_type: torch.Tensor, order: Optional[torch.Tensor],
                  cursor: Optional[torch.Tensor], batch: int, num_neg: int, num_nodes: int,
                  rng: Optional[torch.Tensor]):

@@ -15,8 +15,9 @@ accuracy are accumulated on the device and read back once per epoch instead of t
 host syncs per step (``train.py:322,325``); a mini-batch (slice of the shuffled columns,
 negatives, labels) is assembled by one kernel (``--torch_sampler`` restores the reference's
 ``torch.rand`` / ``torch.randint`` sequence); BCE-with-logits is fused into the head kernels;
-the optimizer is torch's single-kernel (fused) Adam; and the whole step is one captured HIP
-graph replayed per batch (``--no_hip_graph`` launches it eagerly).  Same update rule throughout.
+gradient clipping + the Adam/AdamW update are two launches on the optimizer's own state
+(``--torch_optimizer`` keeps torch's kernels); and the whole step is one captured HIP graph
+replayed per batch (``--no_hip_graph`` launches it eagerly).  Same update rule throughout.
 
 ``--synthetic`` builds a PrimeKG-shaped random graph instead of loading ``--data_dir`` (the
 reference's ``train_data.pt`` / ``full_graph.pt`` blobs are not in its mount).
@@ -58,6 +59,12 @@ class NegativeSampler:
         return torch.where(flip_head, entity, head), torch.where(flip_head, tail, entity), rel
 
 
+def group_has_extras(optimizer: torch.optim.Optimizer) -> bool:
+    """options of torch's Adam the two-launch update does not implement"""
+    g = optimizer.param_groups
+    return len(g) != 1 or bool(g[0].get("amsgrad")) or bool(g[0].get("maximize")) or len(g[0]["params"]) > 32
+
+
 class Trainer:
     """Epoch loop, validation and checkpoints; attribute names follow the reference's
     ``Trainer`` so that scripts poking at ``trainer.train_losses`` etc. keep working."""
@@ -91,6 +98,9 @@ class Trainer:
         extra = {"fused": True, "capturable": self.use_hip_graph} if device.type == "cuda" else {}
         self.optimizer = opt(self.model.parameters(), lr=args.lr, weight_decay=args.weight_decay, **extra)
         self._graph = self._loss_sum = None
+        # clip + Adam(W) as two launches of this package instead of ~14 of torch's
+        self.fused_update = (device.type == "cuda" and not getattr(args, "torch_optimizer", False)
+                             and not group_has_extras(self.optimizer))
         # mini-batch assembly (slice + negatives + labels) as one kernel; --torch_sampler keeps the
         # reference's op-by-op sampler on torch's RNG stream
         self.device_sampler = device.type == "cuda" and not getattr(args, "torch_sampler", False)
@@ -146,13 +156,35 @@ class Trainer:
             loss = self.criterion(scores, labels)
         (loss / accum if accum > 1 else loss).backward()
         if update:
-            if self.args.grad_clip > 0:
-                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.args.grad_clip)
-            self.optimizer.step()
+            self._clip_and_update()
         with torch.no_grad():                       # device-side bookkeeping, no host sync
             self._loss_sum += loss.detach().double() * labels.numel()
             self._correct += ((scores.detach() > 0) == (labels > 0.5)).sum()
         return heads, tails, rels, labels, loss.detach()
+
+    def _clip_and_update(self) -> None:
+        """``clip_grad_norm_`` + ``optimizer.step()`` (train.py:311-317).  On the GPU: two launches
+        (``rgcn_adam_clip_step``) on the optimizer's own state tensors, so checkpoints and a later
+        ``optimizer.step()`` see the same state; ``--torch_optimizer`` keeps torch's kernels."""
+        if not self.fused_update:
+            if self.args.grad_clip > 0:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.args.grad_clip)
+            self.optimizer.step()
+            return
+        from . import ops
+        group = self.optimizer.param_groups[0]
+        params = [p for p in group["params"] if p.grad is not None]
+        state = self.optimizer.state
+        for p in params:
+            if len(state[p]) == 0:                     # what torch's Adam would create lazily
+                state[p]["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                state[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        beta1, beta2 = group["betas"]
+        ops.adam_clip_step([p.data for p in params], [p.grad for p in params], [state[p]["exp_avg"] for p in params],
+                           [state[p]["exp_avg_sq"] for p in params], [state[p]["step"] for p in params],
+                           group["lr"], beta1, beta2, group["eps"], group["weight_decay"],
+                           adamw=isinstance(self.optimizer, torch.optim.AdamW), max_norm=self.args.grad_clip)
 
     def _capture_step(self, batch: int) -> None:
         """Record ``_step`` on the batch at ``self._cursor`` (``order``, ``cursor``, the RNG
@@ -354,6 +386,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="gather neighbour rows from an fp16 copy of the feature table (fp32 accumulate)")
     p.add_argument("--bucket_cache", action="store_true",
                    help="persist / reuse the bucketed graph structure next to the .pt files in --data_dir")
+    p.add_argument("--torch_optimizer", action="store_true",
+                   help="clip and update with torch's own kernels instead of the two-launch fused update")
     p.add_argument("--torch_sampler", action="store_true",
                    help="draw negatives with the reference's torch.rand/randint sequence instead of the "
                         "one-kernel device sampler")

@@ -192,9 +192,47 @@ def test_gradient_accumulation_takes_one_update_per_group(tmp_path):
     trainer = T.Trainer(T.create_model(tr["num_nodes"], 3, args), tr, va, full, dev, args)
     assert not trainer.use_hip_graph
     steps = []
-    orig = trainer.optimizer.step
-    trainer.optimizer.step = lambda *a, **k: (steps.append(1), orig(*a, **k))[1]
+    orig = trainer._clip_and_update
+    trainer._clip_and_update = lambda: (steps.append(1), orig())[1]
     before = {k: v.clone() for k, v in trainer.model.state_dict().items()}
     loss, acc = trainer.train_epoch(max_steps=5)
     assert len(steps) == 3 and 0.0 < loss < 1.0 and 0.0 <= acc <= 1.0
     assert any(not torch.equal(v, before[k]) for k, v in trainer.model.state_dict().items())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adamw,wd,clip", [(False, 0.0, 1.0), (False, 0.01, 0.0), (True, 0.05, 0.5), (False, 0.0, 1e6)])
+def test_fused_clip_adam_equals_torch(adamw, wd, clip):
+    """rgcn_adam_clip_step vs clip_grad_norm_ + torch.optim.Adam / AdamW over six steps: tensors of odd
+    sizes (a scalar, a non-multiple of 4, one longer than a slice), clipping active / inactive / off."""
+    dev = need_gpu()
+    from primekg_rgcn_linkprediction_amd import ops
+    gen = torch.Generator().manual_seed(7)
+    shapes = [(30926, 64), (3, 64, 128), (128,), (1,), (7, 3), (8193,)]
+    ref = [torch.randn(s, generator=gen).to(dev).requires_grad_(True) for s in shapes]
+    got = [p.detach().clone() for p in ref]
+    opt = (torch.optim.AdamW if adamw else torch.optim.Adam)(ref, lr=1e-2, weight_decay=wd)
+    m = [torch.zeros_like(p) for p in got]
+    v = [torch.zeros_like(p) for p in got]
+    steps = [torch.zeros((), device=dev) for _ in got]
+    norm = torch.zeros(1, device=dev)
+    for it in range(6):
+        grads = [torch.randn(s, generator=gen).to(dev) * (10.0 if it % 2 else 0.01) for s in shapes]
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_(ref, clip) if clip > 0 else None
+        opt.step()
+        ops.adam_clip_step(got, grads, m, v, steps, 1e-2, 0.9, 0.999, 1e-8, wd, adamw=adamw, max_norm=clip,
+                           total_norm=norm)
+        if want_norm is not None:
+            assert abs(norm.item() - want_norm.item()) <= 1e-5 * want_norm.item()
+        for a, b in zip(got, ref):
+            assert (a - b.detach()).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), it
+    assert all(s.item() == 6.0 for s in steps)
+    for a, b in zip(m, ref):
+        st = opt.state[b]
+        assert (a - st["exp_avg"]).abs().max().item() <= 1e-6 * max(1.0, st["exp_avg"].abs().max().item())
+    with pytest.raises(ValueError):
+        ops.adam_clip_step(got, grads[:-1], m, v, steps, 1e-2, 0.9, 0.999, 1e-8)
+    with pytest.raises(ValueError):
+        ops.adam_clip_step(got, grads, m, v, steps, 1e-2, 1.0, 0.999, 1e-8)          # beta1 = 1 is rejected by the library
