@@ -29,6 +29,26 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on(device):
+    """Device guard for a launch: a real ``torch.cuda.device`` switch only when ``device`` is not
+    already current (the usual case - one process per GPU - costs a comparison instead of a
+    Python-level guard push/pop around each of the ~14 launches of a step)."""
+    if device.index is None or torch.cuda.current_device() == device.index:
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -78,7 +98,7 @@ class BucketedGraph:
         self.weighted_shard = False
         self.num_edges = int(edge_index.size(1))
         handle = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             rc = lib.rgcn_graph_create(_ptr(edge_index), _ptr(edge_type), self.num_edges,
                                        self.num_nodes, self.num_relations, _stream(),
                                        ctypes.byref(handle))
@@ -111,7 +131,7 @@ class BucketedGraph:
         self.weighted_shard = edge_weight is not None
         self.num_edges = int(key_node.size(0))
         handle = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             rc = lib.rgcn_graph_create_bipartite(_ptr(key_node), _ptr(other_node), _ptr(edge_type),
                                                  self.num_edges, self.num_nodes, self.num_other_nodes,
                                                  self.num_relations, _ptr(edge_weight), _stream(),
@@ -162,7 +182,7 @@ class BucketedGraph:
         self.num_nodes, self.num_relations, self.num_other_nodes, self.num_edges = n, r, n, e
         self.bipartite = self.weighted_shard = False
         handle = ctypes.c_void_p()
-        with torch.cuda.device(device):
+        with _on(device):
             rc = _lib.load().rgcn_graph_import(e, n, r, *(_ptr(dev[k]) for k in want), _stream(),
                                                ctypes.byref(handle))
         _lib.check(rc, "rgcn_graph_import")
@@ -197,7 +217,7 @@ class BucketedGraph:
         device: val = cnt[N*R] (forward) or w_t[E] (transposed).  For parity tests."""
         lib = _lib.load()
         nr, e = self.num_nodes * self.num_relations, self.num_edges
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             rowptr = torch.empty(nr + 1, dtype=torch.int32, device=self.device)
             col = torch.empty(e, dtype=torch.int32, device=self.device)
             perm = torch.empty(e, dtype=torch.int64, device=self.device)
@@ -340,7 +360,7 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False) -
     if d % (8 if half_in else 4):
         raise ValueError(f"feature dim {d} must be a multiple of {8 if half_in else 4}")
     lib = _lib.load()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         out = torch.empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
         nbytes = lib.rgcn_aggregate_workspace_bytes(graph.handle, int(transposed), d)
         ws = _workspace(nbytes, x.device)
@@ -418,7 +438,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
     n, r, d_in, d_out = _check_layer(agg, x, weight, root, bias)
     lib = _lib.load()
     if half and d_in % 32 == 0:
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
             nbytes = lib.rgcn_transform_fwd_f16_workspace_bytes(r, d_in, d_out)
             ws = _workspace(nbytes, x.device)
@@ -427,7 +447,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
                                             nbytes, _stream())
         _lib.check(rc, "rgcn_transform_fwd_f16")
         return out
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
         rc = lib.rgcn_transform_fwd(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu),
                                     _mask_for(graph, False, n, r), n, r, d_in, d_out, _ptr(out), _stream())
@@ -454,7 +474,7 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
         if tuple(relu_mask.shape) != (n, d_in):
             raise ValueError(f"relu_mask must be [{n}, {d_in}]")
     lib = _lib.load()
-    with torch.cuda.device(g.device):
+    with _on(g.device):
         gx = torch.empty(n, d_in, dtype=torch.float32, device=g.device)
         rc = lib.rgcn_transform_bwd_input(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root), _ptr(relu_mask),
                                           _mask_for(graph, True, n, r), n, r, d_in, d_out, _ptr(gx), _stream())
@@ -474,7 +494,7 @@ def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, 
     if tuple(agg.shape) != (n, r * d_in) or g.size(0) != n:
         raise ValueError("agg must be [N, R*d_in] and g [N, d_out]")
     lib = _lib.load()
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         gw = torch.empty(r, d_in, d_out, dtype=torch.float32, device=x.device)
         groot = torch.empty(d_in, d_out, dtype=torch.float32, device=x.device) if want_root else None
         gbias = torch.empty(d_out, dtype=torch.float32, device=x.device) if want_bias else None
@@ -511,7 +531,7 @@ def distmult_fwd(h, h_idx, t, t_idx, r, r_idx, batch: int) -> torch.Tensor:
     if d % 4:
         raise ValueError("embedding dim must be a multiple of 4")
     lib = _lib.load()
-    with torch.cuda.device(h.device):
+    with _on(h.device):
         scores = torch.empty(batch, dtype=torch.float32, device=h.device)
         rc = lib.distmult_fwd(_ptr(h), _ptr(h_idx), _ptr(t), _ptr(t_idx), _ptr(r), _ptr(r_idx), batch, d,
                               _ptr(scores), _stream())
@@ -544,7 +564,7 @@ def adam_clip_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr: float, beta1
     dev = params[0].device
     arr = ctypes.c_void_p * n
     numels = (ctypes.c_int64 * n)(*[p.numel() for p in params])
-    with torch.cuda.device(dev):
+    with _on(dev):
         nbytes = lib.rgcn_adam_workspace_bytes(n, ctypes.cast(numels, ctypes.c_void_p))
         ws = _workspace(nbytes, dev)
         rc = lib.rgcn_adam_clip_step(
@@ -588,7 +608,7 @@ def sample_batch(edge_index: torch.Tensor, edge_type: torch.Tensor, order: Optio
         raise ValueError("batch / num_neg must be >= 0 and the graph must have columns")
     total = batch * (1 + num_neg)
     lib = _lib.load()
-    with torch.cuda.device(edge_index.device):
+    with _on(edge_index.device):
         heads = torch.empty(total, dtype=torch.int64, device=edge_index.device)
         tails, rels = torch.empty_like(heads), torch.empty_like(heads)
         labels = torch.empty(total, dtype=torch.float32, device=edge_index.device)
@@ -612,7 +632,7 @@ def distmult_bce_fwd(h, h_idx, t, t_idx, r, r_idx, labels, batch: int):
     if labels.shape != (batch,):
         raise ValueError(f"labels must be [{batch}], got {tuple(labels.shape)}")
     lib = _lib.load()
-    with torch.cuda.device(h.device):
+    with _on(h.device):
         scores = torch.empty(batch, dtype=torch.float32, device=h.device)
         loss = torch.empty(batch, dtype=torch.float32, device=h.device)
         rc = lib.distmult_bce_fwd(_ptr(h), _ptr(h_idx), _ptr(t), _ptr(t_idx), _ptr(r), _ptr(r_idx), _ptr(labels),
@@ -630,7 +650,7 @@ def distmult_bce_bwd(grad_mean_loss, scores, labels, h, h_idx, t, t_idx, r, r_id
         raise ValueError("grad_mean_loss must hold one float")
     d = h.size(1)
     lib = _lib.load()
-    with torch.cuda.device(h.device):
+    with _on(h.device):
         rc = lib.distmult_bce_bwd(_ptr(grad_mean_loss), _ptr(scores), _ptr(labels), _ptr(h), _ptr(h_idx), _ptr(t),
                                   _ptr(t_idx), _ptr(r), _ptr(r_idx), batch, d, _ptr(grad_h), _ptr(grad_t),
                                   _ptr(grad_r), _stream())
@@ -642,7 +662,7 @@ def distmult_bwd(gs, h, h_idx, t, t_idx, r, r_idx, batch: int, grad_h, grad_t, g
     _need_gpu("grad_scores", gs, torch.float32)
     d = h.size(1)
     lib = _lib.load()
-    with torch.cuda.device(h.device):
+    with _on(h.device):
         rc = lib.distmult_bwd(_ptr(gs), _ptr(h), _ptr(h_idx), _ptr(t), _ptr(t_idx), _ptr(r), _ptr(r_idx),
                               batch, d, _ptr(grad_h), _ptr(grad_t), _ptr(grad_r), _stream())
     _lib.check(rc, "distmult_bwd")
@@ -663,7 +683,7 @@ def distmult_rank_tails(hr: torch.Tensor, emb: torch.Tensor, true_score: torch.T
     if d % 32:
         raise ValueError("embedding dim must be a multiple of 32 for the fused ranking kernel")
     lib = _lib.load()
-    with torch.cuda.device(hr.device):
+    with _on(hr.device):
         beaten = torch.zeros(b, dtype=torch.int32, device=hr.device)
         rc = lib.distmult_rank_tails(_ptr(hr), _ptr(emb), _ptr(true_score), _ptr(tail), b, emb.size(0), d,
                                      _ptr(beaten), _stream())
