@@ -206,8 +206,20 @@ class BucketedGraph:
         """device pointer (as int) of the relation-occupancy mask of 32-row tiles, or None"""
         if self.bipartite and transposed:
             raise ValueError("a shard structure has one direction only (transposed=False)")
-        ptr = _lib.load().rgcn_graph_tile_mask(self.handle, int(transposed), None)
-        return ptr or None
+        handle = self.handle                                         # raises once the graph is destroyed
+        cache = self.__dict__.setdefault("_mask_ptrs", {})          # fixed for the life of the handle
+        if transposed not in cache:
+            cache[transposed] = _lib.load().rgcn_graph_tile_mask(handle, int(transposed), None) or None
+        return cache[transposed]
+
+    def workspace_bytes(self, transposed: bool, d: int) -> int:
+        """bytes of partial-sum workspace ``aggregate`` needs for rows of width d (memoised)"""
+        handle = self.handle
+        cache = self.__dict__.setdefault("_ws_bytes", {})
+        key = (bool(transposed), int(d))
+        if key not in cache:
+            cache[key] = _lib.load().rgcn_aggregate_workspace_bytes(handle, int(transposed), int(d))
+        return cache[key]
 
     def num_levels(self, transposed: bool) -> int:
         return _lib.load().rgcn_graph_num_levels(self.handle, int(transposed))
@@ -362,7 +374,7 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False) -
     lib = _lib.load()
     with _on(x.device):
         out = torch.empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
-        nbytes = lib.rgcn_aggregate_workspace_bytes(graph.handle, int(transposed), d)
+        nbytes = graph.workspace_bytes(transposed, d)
         ws = _workspace(nbytes, x.device)
         if half_in:
             rc = lib.rgcn_aggregate_f16(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
