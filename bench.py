@@ -124,6 +124,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the measured path")
 
     from primekg_rgcn_linkprediction_amd import RGCNConv, _lib, ops, rgcn_encoder2, synth
+    if not os.path.exists(_lib.LIB_PATH):                 # a fresh checkout: the library is a build product
+        if local_rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        for _ in range(600):                              # the other ranks of the node wait for rank 0's build
+            if os.path.exists(_lib.LIB_PATH):
+                break
+            time.sleep(0.5)
     _lib.load()                                           # fail loudly if the HIP library is missing
     # one process per GPU.  (Rehearsal on a 1-GPU box: RGCN_BENCH_BACKEND=gloo lets several ranks
     # share cuda:0 with host-staged exchanges - RCCL refuses two ranks on one device.)
