@@ -373,6 +373,12 @@ def main():
                                                  launch=r_mode)
         except Exception as exc:                                           # pragma: no cover
             print(f"bench: graph launch mode not measured ({exc!r}); reporting eager launches", file=sys.stderr)
+            watchdog.cancel()
+            # HIP is unusable in this process now: report the eager line and leave without teardown
+            if rank == 0:
+                print(safe_line, flush=True)
+            sys.stderr.flush()
+            os._exit(0)
         finally:
             watchdog.cancel()
 
