@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 7
+#define RGCN_ABI_VERSION 8
 
 enum {
   RGCN_OK = 0,
@@ -117,6 +117,17 @@ int rgcn_graph_import(int64_t num_edges, int64_t num_nodes, int64_t num_relation
                       const int32_t* rowptr_t, const int32_t* col_t, const int64_t* perm_t,
                       const float* w_t, void* stream, rgcn_graph** out);
 
+/* A pending fixed-order reduction of parameter-gradient slabs (filled by
+ * rgcn_transform_bwd_params_begin, consumed by rgcn_slab_reduce or rgcn_aggregate_and_reduce). */
+typedef struct rgcn_slab_job {
+  const float* slab;
+  const float* bias_part;
+  int32_t splits, K1, Kc, N;
+  float* grad_weight;
+  float* grad_root;
+  float* grad_bias;
+} rgcn_slab_job;
+
 /* ------------------------------------------------------------------------------------
  * Gather + per-(node, relation) aggregation (rows A3 + A4, and their autograd, row A7).
  *
@@ -134,6 +145,12 @@ int rgcn_graph_import(int64_t num_edges, int64_t num_nodes, int64_t num_relation
 size_t rgcn_aggregate_workspace_bytes(const rgcn_graph* g, int transposed, int64_t d);
 int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* rgcn_aggregate whose level-0 launch also performs a pending slab reduction (see
+ * rgcn_transform_bwd_params_begin) as extra workgroups; `job` may be NULL.  For row widths the
+ * gather splits over a second grid dimension (d > 256) the reduction is launched by itself first. */
+int rgcn_aggregate_and_reduce(const rgcn_graph* g, int transposed, const float* x, int64_t d,
+                              float* agg, void* workspace, size_t workspace_bytes,
+                              const rgcn_slab_job* job, void* stream);
 /* The same with the gathered table stored as IEEE fp16 (x_f16: half[N, d], d % 8 == 0) and fp32
  * accumulation / output: half the bytes per gathered row (BASELINE.json configs[4], "fp16
  * features + fp32 accumulate").  agg and the workspace stay fp32. */
@@ -191,6 +208,19 @@ int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g,
                               const uint32_t* tile_mask, int64_t num_nodes, int64_t num_relations,
                               int64_t d_in, int64_t d_out, float* grad_weight, float* grad_root,
                               float* grad_bias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same in two halves, so that the short fixed-order slab reduction need not sit between two
+ * launch boundaries: `_begin` launches the slab GEMM and describes the pending reduction in `*job`
+ * (plain pointers into `workspace` and the three outputs; nothing is owned); the reduction then
+ * either runs by itself (rgcn_slab_reduce) or rides as extra workgroups of the transposed gather
+ * that follows in a layer's backward and does not depend on it (rgcn_aggregate_and_reduce).
+ * `workspace` and the outputs must stay alive until that launch. */
+int rgcn_transform_bwd_params_begin(const float* agg, const float* x, const float* g,
+                                    const uint32_t* tile_mask, int64_t num_nodes, int64_t num_relations,
+                                    int64_t d_in, int64_t d_out, float* grad_weight, float* grad_root,
+                                    float* grad_bias, void* workspace, size_t workspace_bytes, void* stream,
+                                    rgcn_slab_job* job);
+int rgcn_slab_reduce(const rgcn_slab_job* job, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DistMult head (rows C1 + C2; rgcn.py:325-326 row gathers + rgcn.py:207-211):

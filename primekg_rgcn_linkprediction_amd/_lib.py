@@ -13,7 +13,7 @@ from ctypes import c_float, POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -26,6 +26,13 @@ RGCN_ERR_WORKSPACE = -5
 
 _P = c_void_p      # device pointers travel as integers (tensor.data_ptr())
 _I64 = c_int64
+
+class SlabJob(ctypes.Structure):
+    """``rgcn_slab_job``: a pending parameter-gradient slab reduction (plain device pointers)."""
+    _fields_ = [("slab", c_void_p), ("bias_part", c_void_p), ("splits", ctypes.c_int32), ("K1", ctypes.c_int32),
+                ("Kc", ctypes.c_int32), ("N", ctypes.c_int32), ("grad_weight", c_void_p), ("grad_root", c_void_p),
+                ("grad_bias", c_void_p)]
+
 
 # name -> (restype, argtypes); mirrors include/rgcn_hip.h one to one
 PROTOTYPES = {
@@ -54,6 +61,10 @@ PROTOTYPES = {
     "rgcn_transform_bwd_params_workspace_bytes": (c_size_t, [_I64, _I64, _I64, _I64]),
     "rgcn_transform_bwd_params": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P,
                                           c_size_t, _P]),
+    "rgcn_transform_bwd_params_begin": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, c_size_t, _P,
+                                                POINTER(SlabJob)]),
+    "rgcn_slab_reduce": (c_int, [POINTER(SlabJob), _P]),
+    "rgcn_aggregate_and_reduce": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, POINTER(SlabJob), _P]),
     "distmult_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "distmult_rank_tails": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "distmult_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),

@@ -60,7 +60,8 @@ class _BasisCompose(torch.autograd.Function):
         return g_comp, g_basis
 
 
-def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Optional[Tensor]) -> Tensor:
+def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Optional[Tensor],
+                tail: Optional["ops.PendingParamGrads"] = None) -> Tensor:
     """``d loss / d x`` of one layer from ``g = d loss / d out``.
 
     Default: gather first (``gagg = transposed aggregate of g``, then one GEMM with
@@ -74,12 +75,13 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
     r, d_in, d_out = weight.shape
     merged = (graph.merged_transposed()
               if (d_out >= 4 * d_in and root is not None and not graph.bipartite) else None)
+    # `tail`: the pending slab reduction of this layer's parameter gradients rides in the gather launch
     if merged is None:
-        gagg = ops.aggregate(graph, g, transposed=True)                 # autograd of A3 + A4 (fp32 grads)
+        gagg = ops.aggregate(graph, g, transposed=True, tail=tail)      # autograd of A3 + A4 (fp32 grads)
         return ops.transform_bwd_input(gagg, g, weight, root, graph=graph)  # autograd of A6 wrt x
     wcat = torch.cat([weight.reshape(r * d_in, d_out), root]).view(1, (r + 1) * d_in, d_out)
     t = ops.transform_bwd_input(g, g, wcat, None)                        # [N, (R+1) d_in] = g @ wcat^T
-    return ops.aggregate(merged, t.view(-1, d_in))
+    return ops.aggregate(merged, t.view(-1, d_in), tail=tail)
 
 
 class _RGCNConvFunction(torch.autograd.Function):
@@ -110,11 +112,15 @@ class _RGCNConvFunction(torch.autograd.Function):
         g = g.contiguous()
         need_x, need_w, need_root, need_bias = ctx.needs_input_grad[:4]
         gx = gw = groot = gbias = None
+        pending = None
         if need_w or (need_root and ctx.has_root) or (need_bias and ctx.has_bias):
-            gw, groot, gbias = ops.transform_bwd_params(
-                agg, x, g, graph.num_relations, want_root=ctx.has_root, want_bias=ctx.has_bias, graph=graph)
+            pending = ops.transform_bwd_params(agg, x, g, graph.num_relations, want_root=ctx.has_root,
+                                               want_bias=ctx.has_bias, graph=graph, defer=True)
         if need_x:
-            gx = _input_grad(graph, g, weight, root)
+            gx = _input_grad(graph, g, weight, root, tail=pending)
+        if pending is not None:
+            pending.finish()                                                # no gather took it along
+            gw, groot, gbias = pending.grads
         return gx, gw, groot, gbias, None, None, None
 
 
@@ -152,18 +158,22 @@ class _Encoder2Function(torch.autograd.Function):
         graph, r = ctx.graph, ctx.graph.num_relations
         has_root1, has_b1, has_root2, has_b2 = ctx.flags
         g = g.contiguous()
-        gw2, groot2, gb2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2,
-                                                    graph=graph)
-        gagg2 = ops.aggregate(graph, g, transposed=True)
+        # the slab reductions of the parameter gradients ride in the transposed gathers that follow them
+        red2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2, graph=graph,
+                                        defer=True)
+        gagg2 = ops.aggregate(graph, g, transposed=True, tail=red2)
         if ctx.p > 0:
             scale = 1.0 / (1.0 - ctx.p)
             w2, root2 = w2 * scale, (root2 * scale if root2 is not None else None)
         gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph)   # d loss / d (pre-ReLU of conv1)
-        gw1, groot1, gb1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1,
-                                                    graph=graph)
+        red1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1, graph=graph,
+                                        defer=True)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = _input_grad(graph, gz, w1, root1)
+            gx = _input_grad(graph, gz, w1, root1, tail=red1)
+        red2.finish()
+        red1.finish()
+        (gw2, groot2, gb2), (gw1, groot1, gb1) = red2.grads, red1.grads
         return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None, None
 
 

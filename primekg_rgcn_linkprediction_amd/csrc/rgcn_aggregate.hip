@@ -22,6 +22,7 @@
 #include <hip/hip_fp16.h>
 
 #include "rgcn_common.h"
+#include "rgcn_slab_reduce.h"
 
 namespace {
 
@@ -93,8 +94,12 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
     const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
     float* __restrict__ agg, float* __restrict__ partial, int d, const int32_t* __restrict__ head_col,
-    const float* __restrict__ head_w) {
+    const float* __restrict__ head_w, const rgcn_slab_job job, int gather_blocks) {
   __shared__ float4 red[kThreads];               // pack combine (see rgcn_common.h)
+  if ((int)blockIdx.x >= gather_blocks) {        // workgroups past the gather: a pending slab reduction rides along
+    rgcn_slab_reduce_block<RGCN_SLAB_OUTS, RGCN_SLAB_GROUPS>(job, (int64_t)blockIdx.x - gather_blocks, red);
+    return;
+  }
   const int64_t item_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   const int c4 = ((int)threadIdx.x % G + (int)blockIdx.y * G) * 4;
   if (item_id >= nitems) return;                 // whole lane groups only
@@ -338,18 +343,20 @@ __global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* _
 
 template <int G>
 void launch_level(const rgcn_csr* c, int level, bool weighted, const float* x, const float* cnt, float* agg,
-                  float* partial, int d, hipStream_t stream) {
+                  float* partial, int d, hipStream_t stream, const rgcn_slab_job* tail = nullptr) {
   const int64_t nitems = c->num_items[level];
   if (nitems == 0) return;
   const unsigned gy = (unsigned)ceil_div64(d, 4 * G);
   if (level == 0) {
-    dim3 grid((unsigned)ceil_div64(nitems, kThreads / G), gy);
+    const unsigned gather_blocks = (unsigned)ceil_div64(nitems, kThreads / G);
+    const rgcn_slab_job job = tail ? *tail : rgcn_slab_job{};
+    dim3 grid(gather_blocks + (tail ? (unsigned)rgcn_slab_reduce_blocks(job) : 0u), gy);   // tail only with gy == 1
     if (weighted)
       k_aggregate<G, true><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, c->val, cnt, agg, partial, d,
-                                                          c->head_col, c->head_w);
+                                                          c->head_col, c->head_w, job, (int)gather_blocks);
     else
       k_aggregate<G, false><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, nullptr, cnt, agg, partial, d,
-                                                           c->head_col, nullptr);
+                                                           c->head_col, nullptr, job, (int)gather_blocks);
   } else {
     dim3 grid((unsigned)nitems, gy);
     k_reduce_partials<G><<<grid, kThreads, 0, stream>>>(c->items[level], cnt, agg, partial, d);
@@ -371,7 +378,8 @@ void launch_level0_h(const rgcn_csr* c, bool weighted, const __half* x, const fl
 }
 
 int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, const float* x, int64_t d,
-                     float* agg, void* workspace, size_t workspace_bytes, void* stream_, bool half_in = false) {
+                     float* agg, void* workspace, size_t workspace_bytes, void* stream_, bool half_in = false,
+                     const rgcn_slab_job* tail = nullptr) {
   if (!g || !agg || d <= 0 || (d & 3) || (half_in && (d & 7))) return RGCN_ERR_ARG;
   const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
   if (!c->rowptr) return RGCN_ERR_ARG;   // direction not built
@@ -387,7 +395,19 @@ int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, c
   const float* cnt = c->weighted ? nullptr : c->val;
   const bool weighted = c->weighted;
   const int q = (int)(d / 4);
+  // a pending slab reduction rides in the level-0 launch when that launch is a plain 1-D grid of the
+  // fp32 gather with work of its own; otherwise it is launched by itself, first
+  if (tail && tail->slab) {
+    const bool can_ride = !half_in && first == 0 && last > 0 && d <= 256 && c->num_items[0] > 0;
+    if (!can_ride) {
+      k_slab_reduce<<<(unsigned)rgcn_slab_reduce_blocks(*tail), 256, 0, stream>>>(*tail);
+      tail = nullptr;
+    }
+  } else {
+    tail = nullptr;
+  }
   for (int l = first; l < last; ++l) {
+    const rgcn_slab_job* t0 = l == 0 ? tail : nullptr;
     if (l == 0 && half_in) {                    // fp16 table: 8 columns per lane
       const __half* xh = reinterpret_cast<const __half*>(x);
       const int q8 = (int)(d / 8);
@@ -400,13 +420,13 @@ int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, c
       else launch_level0_h<64>(c, weighted, xh, cnt, agg, partial, (int)d, stream);
       continue;
     }
-    if (q <= 1) launch_level<1>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
-    else if (q <= 2) launch_level<2>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
-    else if (q <= 4) launch_level<4>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
-    else if (q <= 8) launch_level<8>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
-    else if (q <= 16) launch_level<16>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
-    else if (q <= 32) launch_level<32>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
-    else launch_level<64>(c, l, weighted, x, cnt, agg, partial, (int)d, stream);
+    if (q <= 1) launch_level<1>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
+    else if (q <= 2) launch_level<2>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
+    else if (q <= 4) launch_level<4>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
+    else if (q <= 8) launch_level<8>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
+    else if (q <= 16) launch_level<16>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
+    else if (q <= 32) launch_level<32>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
+    else launch_level<64>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
   }
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
@@ -426,6 +446,21 @@ int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t 
   if (!g) return RGCN_ERR_ARG;
   return aggregate_levels(g, transposed, 0, g->dir[transposed ? 1 : 0].num_levels, x, d, agg, workspace,
                           workspace_bytes, stream);
+}
+
+int rgcn_aggregate_and_reduce(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
+                              void* workspace, size_t workspace_bytes, const rgcn_slab_job* job, void* stream) {
+  if (!g) return RGCN_ERR_ARG;
+  if (job && job->slab &&
+      (!job->grad_weight || job->splits <= 0 || job->Kc <= 0 || job->N <= 0 || (job->N & 3)))
+    return RGCN_ERR_ARG;
+  const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
+  if (job && job->slab && c->rowptr && c->n_key == 0) {      // nothing to gather: the reduction still has to run
+    k_slab_reduce<<<(unsigned)rgcn_slab_reduce_blocks(*job), 256, 0, (hipStream_t)stream>>>(*job);
+    RGCN_HIP_TRY(hipGetLastError());
+    return RGCN_OK;
+  }
+  return aggregate_levels(g, transposed, 0, c->num_levels, x, d, agg, workspace, workspace_bytes, stream, false, job);
 }
 
 int rgcn_aggregate_f16(const rgcn_graph* g, int transposed, const void* x_f16, int64_t d, float* agg,

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "rgcn_common.h"
+#include "rgcn_slab_reduce.h"
 
 namespace {
 
@@ -810,69 +811,6 @@ __global__ __launch_bounds__(kThreads * WG) void k_gemm_tn_dma(const float* __re
   if (do_bias && n0 + tid < N) bias_part[(size_t)split * N + n0 + tid] = bsum;
 }
 
-// Fixed-order sum of the slabs (deterministic), split between grad_weight and grad_root.
-// OUTS outputs (float4 each) x GROUPS slab groups per workgroup: group g sums slabs
-// [g*S/GROUPS, (g+1)*S/GROUPS) in order, then the partials are added in group order.
-template <int OUTS, int GROUPS>
-__global__ __launch_bounds__(kThreads) void k_reduce_slabs(const float* __restrict__ slab,
-                                                           const float* __restrict__ bias_part, int S, int K1,
-                                                           int Kc, int N, float* __restrict__ grad_weight,
-                                                           float* __restrict__ grad_root,
-                                                           float* __restrict__ grad_bias) {
-  __shared__ float4 red[kThreads];
-  const int64_t nq = (int64_t)Kc * N / 4;                       // float4 outputs of the weight grads
-  static_assert(OUTS * GROUPS == kThreads, "one thread per (output, slab group)");
-  const int64_t q = (int64_t)blockIdx.x * OUTS + ((int)threadIdx.x % OUTS);
-  const int grp = (int)threadIdx.x / OUTS;
-  const int s0 = (int)((int64_t)S * grp / GROUPS), s1 = (int)((int64_t)S * (grp + 1) / GROUPS);
-  float4 acc = f4zero();
-  if (q < nq) {
-    const float* p = slab + (size_t)q * 4;
-    const size_t stride = (size_t)Kc * N;
-    int i = s0;
-    for (; i + 8 <= s1; i += 8) {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ldg4(p + (size_t)(i + u) * stride);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-    }
-    for (; i < s1; ++i) {
-      const float4 v = ldg4(p + (size_t)i * stride);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-  } else if (grad_bias && q - nq < (N + 3) / 4) {               // tail workgroups: bias partials
-    const int n = (int)(q - nq) * 4;
-    for (int i = s0; i < s1; ++i) {
-      const float* b = bias_part + (size_t)i * N + n;
-      acc.x += b[0];
-      if (n + 1 < N) acc.y += b[1];
-      if (n + 2 < N) acc.z += b[2];
-      if (n + 3 < N) acc.w += b[3];
-    }
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  if (grp != 0) return;
-  float4 s = red[threadIdx.x];
-#pragma unroll
-  for (int g = 1; g < GROUPS; ++g) {
-    const float4 v = red[g * OUTS + threadIdx.x];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-  }
-  if (q < nq) {
-    const int64_t e = q * 4, k1n = (int64_t)K1 * N;
-    if (e < k1n) *reinterpret_cast<float4*>(grad_weight + e) = s;
-    else if (grad_root) *reinterpret_cast<float4*>(grad_root + (e - k1n)) = s;
-  } else if (grad_bias && q - nq < (N + 3) / 4) {
-    const int n = (int)(q - nq) * 4;
-    grad_bias[n] = s.x;
-    if (n + 1 < N) grad_bias[n + 1] = s.y;
-    if (n + 2 < N) grad_bias[n + 2] = s.z;
-    if (n + 3 < N) grad_bias[n + 3] = s.w;
-  }
-}
-
 struct SplitPlan { int kc_tiles, n_tiles, splits, rows_per_split; };
 
 constexpr int TN_TKC = 64;          // kc columns per workgroup of k_gemm_tn_slab<1>
@@ -1030,10 +968,12 @@ size_t rgcn_transform_bwd_params_workspace_bytes(int64_t N, int64_t R, int64_t d
   return ((size_t)p.splits * Kc * d_out + (size_t)p.splits * d_out) * sizeof(float);
 }
 
-int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, const uint32_t* tile_mask,
-                              int64_t N, int64_t R, int64_t d_in, int64_t d_out, float* grad_weight,
-                              float* grad_root, float* grad_bias, void* workspace, size_t workspace_bytes,
-                              void* stream_) {
+int rgcn_transform_bwd_params_begin(const float* agg, const float* x, const float* g, const uint32_t* tile_mask,
+                                    int64_t N, int64_t R, int64_t d_in, int64_t d_out, float* grad_weight,
+                                    float* grad_root, float* grad_bias, void* workspace, size_t workspace_bytes,
+                                    void* stream_, rgcn_slab_job* job) {
+  if (!job) return RGCN_ERR_ARG;
+  *job = rgcn_slab_job{};
   if (bad_dims(N, R, d_in, d_out) || !grad_weight) return RGCN_ERR_ARG;
   if (N > 0 && (!agg || !x || !g)) return RGCN_ERR_ARG;
   if (N > INT32_MAX / 2 || (R + 1) * d_in > (1 << 24) || d_out > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
@@ -1071,20 +1011,38 @@ int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, 
   else
     k_gemm_tn_slab<1><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
                                                      p.rows_per_split, slab, grad_bias ? bias_part : nullptr);
-  const int64_t nq = (int64_t)Kc * d_out / 4 + (d_out + 3) / 4;
-  {
-    // 16 outputs x 16 slab groups per workgroup: short load chains and >= 4 workgroups per CU for a
-    // reduction that is all latency (RGCN_SLAB_GROUPS=4: 64 x 4, for A/B runs)
-    static const int groups = [] { const char* e = getenv("RGCN_SLAB_GROUPS"); return e ? atoi(e) : 16; }();
-    if (groups == 4)
-      k_reduce_slabs<64, 4><<<(unsigned)ceil_div64(nq, 64), kThreads, 0, stream>>>(
-          slab, bias_part, p.splits, K1, Kc, (int)d_out, grad_weight, grad_root, grad_bias);
-    else
-      k_reduce_slabs<16, 16><<<(unsigned)ceil_div64(nq, 16), kThreads, 0, stream>>>(
-          slab, bias_part, p.splits, K1, Kc, (int)d_out, grad_weight, grad_root, grad_bias);
-  }
+  RGCN_HIP_TRY(hipGetLastError());
+  job->slab = slab;
+  job->bias_part = bias_part;
+  job->splits = p.splits;
+  job->K1 = K1;
+  job->Kc = Kc;
+  job->N = (int32_t)d_out;
+  job->grad_weight = grad_weight;
+  job->grad_root = grad_root;
+  job->grad_bias = grad_bias;
+  return RGCN_OK;
+}
+
+// the pending reduction of a job, as a launch of its own (16 outputs x 16 slab groups per workgroup:
+// short load chains and >= 4 workgroups per CU for a reduction that is all latency)
+int rgcn_slab_reduce(const rgcn_slab_job* job, void* stream) {
+  if (!job) return RGCN_ERR_ARG;
+  if (!job->slab) return RGCN_OK;                              // nothing pending (empty graph)
+  if (!job->grad_weight || job->splits <= 0 || job->Kc <= 0 || job->N <= 0 || (job->N & 3)) return RGCN_ERR_ARG;
+  k_slab_reduce<<<(unsigned)rgcn_slab_reduce_blocks(*job), 256, 0, (hipStream_t)stream>>>(*job);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
+}
+
+int rgcn_transform_bwd_params(const float* agg, const float* x, const float* g, const uint32_t* tile_mask,
+                              int64_t N, int64_t R, int64_t d_in, int64_t d_out, float* grad_weight,
+                              float* grad_root, float* grad_bias, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  rgcn_slab_job job;
+  const int rc = rgcn_transform_bwd_params_begin(agg, x, g, tile_mask, N, R, d_in, d_out, grad_weight, grad_root,
+                                                 grad_bias, workspace, workspace_bytes, stream, &job);
+  return rc != RGCN_OK ? rc : rgcn_slab_reduce(&job, stream);
 }
 
 }  // extern "C"

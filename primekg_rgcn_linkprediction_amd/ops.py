@@ -361,7 +361,30 @@ def clear_graph_cache() -> None:
 GATHER_EVENTS = None
 
 
-def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+class PendingParamGrads:
+    """Parameter gradients whose slab reduction has not been launched yet
+    (``transform_bwd_params(..., defer=True)``).  Hand it to the next ``aggregate`` of the same
+    backward (``tail=``): the 5 us reduction then rides in that gather launch as extra
+    workgroups instead of sitting between two launch boundaries; or call ``finish()``.
+    ``grads`` = (grad_weight, grad_root | None, grad_bias | None), valid once either happened."""
+
+    def __init__(self, grads, job, workspace):
+        self.grads, self.job, self._workspace, self.done = grads, job, workspace, False
+
+    def finish(self) -> None:
+        if not self.done:
+            dev = self.grads[0].device
+            with _on(dev):
+                rc = _lib.load().rgcn_slab_reduce(ctypes.byref(self.job), _stream())
+            _lib.check(rc, "rgcn_slab_reduce")
+            self._launched()
+
+    def _launched(self) -> None:
+        self.done, self._workspace = True, None        # stream-ordered allocator: safe to release after the launch
+
+
+def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
+              tail: Optional[PendingParamGrads] = None) -> torch.Tensor:
     """``[N, R*d]``: per-(dst, rel) mean of source rows (``transposed=False``) or the
     1/cnt-weighted sum over out-edges per (src, rel) (``transposed=True``).  For a shard
     (``BucketedGraph.from_shard``) x holds the gathered rows of all ranks and the result has
@@ -383,9 +406,16 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False) -
         out = torch.empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
         nbytes = graph.workspace_bytes(transposed, d)
         ws = _workspace(nbytes, x.device)
+        if tail is not None and not tail.done and (half_in or GATHER_EVENTS is not None):
+            tail.finish()                       # no ride in these modes: launch the reduction by itself
         if half_in:
             rc = lib.rgcn_aggregate_f16(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
                                         _stream())
+        elif GATHER_EVENTS is None and tail is not None and not tail.done:
+            rc = lib.rgcn_aggregate_and_reduce(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
+                                               ctypes.byref(tail.job), _stream())
+            if rc == 0:
+                tail._launched()
         elif GATHER_EVENTS is None:
             rc = lib.rgcn_aggregate(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
                                     _stream())
@@ -502,8 +532,9 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
 
 
 def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, want_bias: bool = True,
-                         graph: Optional[BucketedGraph] = None):
-    """``(grad_weight[R, d_in, d_out], grad_root | None, grad_bias | None)``."""
+                         graph: Optional[BucketedGraph] = None, defer: bool = False):
+    """``(grad_weight[R, d_in, d_out], grad_root | None, grad_bias | None)``; with ``defer=True`` a
+    ``PendingParamGrads`` whose reduction the caller attaches to the next gather (or finishes)."""
     _need_gpu("x", x, torch.float32)
     _need_gpu("agg", agg, torch.float32)
     _need_gpu("g", g, torch.float32)
@@ -519,6 +550,13 @@ def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, 
         gbias = torch.empty(d_out, dtype=torch.float32, device=x.device) if want_bias else None
         nbytes = lib.rgcn_transform_bwd_params_workspace_bytes(n, r, d_in, d_out)
         ws = _workspace(nbytes, x.device)
+        if defer:
+            job = _lib.SlabJob()
+            rc = lib.rgcn_transform_bwd_params_begin(_ptr(agg), _ptr(x), _ptr(g), _mask_for(graph, False, n, r), n, r,
+                                                     d_in, d_out, _ptr(gw), _ptr(groot), _ptr(gbias), _ptr(ws), nbytes,
+                                                     _stream(), ctypes.byref(job))
+            _lib.check(rc, "rgcn_transform_bwd_params_begin")
+            return PendingParamGrads((gw, groot, gbias), job, ws)
         rc = lib.rgcn_transform_bwd_params(_ptr(agg), _ptr(x), _ptr(g), _mask_for(graph, False, n, r), n, r, d_in,
                                            d_out, _ptr(gw),
                                            _ptr(groot), _ptr(gbias), _ptr(ws), nbytes, _stream())

@@ -892,3 +892,31 @@ def test_segment_lengths_around_run_and_pack_boundaries(d):
     g2 = ops.BucketedGraph(ei2.to(dev), et.to(dev), n, r)
     assert rel_err(ops.aggregate(g2, x.to(dev), transposed=True), weighted_ref(ei2)) <= tol
     assert g.num_levels(False) == 2 and g2.num_levels(True) == 2
+
+
+def test_deferred_slab_reduction_rides_in_a_gather_and_changes_nothing():
+    """transform_bwd_params(defer=True) + aggregate(tail=...) vs the two separate calls: gradients and
+    the gathered rows bit for bit; widths where the gather cannot carry it (d > 256, fp16 table) and the
+    stand-alone finish() too."""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=60000, seed=13)
+    graph = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(n, 64, generator=gen).to(dev)
+    g = torch.randn(n, 128, generator=gen).to(dev)
+    agg = ops.aggregate(graph, x)
+    want = ops.transform_bwd_params(agg, x, g, r, graph=graph)
+    for carrier in (g, torch.randn(n, 320, generator=gen).to(dev), g.half()):
+        want_rows = ops.aggregate(graph, carrier, transposed=carrier.dtype == torch.float32)
+        pend = ops.transform_bwd_params(agg, x, g, r, graph=graph, defer=True)
+        assert not pend.done
+        rows = ops.aggregate(graph, carrier, transposed=carrier.dtype == torch.float32, tail=pend)
+        assert pend.done and torch.equal(rows, want_rows)
+        for a, b in zip(pend.grads, want):
+            assert torch.equal(a, b)
+        pend.finish()                                          # idempotent
+    pend = ops.transform_bwd_params(agg, x, g, r, want_root=False, want_bias=False, graph=graph, defer=True)
+    pend.finish()
+    assert pend.grads[1] is None and pend.grads[2] is None
+    assert torch.equal(pend.grads[0], ops.transform_bwd_params(agg, x, g, r, want_root=False, want_bias=False,
+                                                              graph=graph)[0])
