@@ -264,3 +264,113 @@ def encoder_ref(emb_weight, conv1: dict, conv2: dict, edge_index, edge_type,
     x = F.dropout(x, dropout_p, training)
     return rgcn_conv_ref(x, edge_index, edge_type, conv2["weight"], conv2["root"],
                          conv2["bias"], conv2.get("comp"))
+
+
+# --------------------------------------------------------------------------
+# restatement #3: the two-layer encoder with its backward spelled out, in float64
+# --------------------------------------------------------------------------
+def _r16(t: torch.Tensor) -> torch.Tensor:
+    """round to fp16 (nearest even) and come back in the input dtype"""
+    return t.to(torch.float32).half().to(t.dtype)
+
+
+def _segment_counts(edge_index, edge_type, n, r, dtype):
+    key = edge_index[1] * r + edge_type
+    return torch.bincount(key, minlength=n * r).clamp(min=1).to(dtype)          # cnt[dst * R + rel]
+
+
+def _mean_agg(x, edge_index, edge_type, n, r, cnt):
+    """[N, R*d]: per-(dst, rel) mean of source rows (rows A3 + A4), any float dtype"""
+    d = x.size(1)
+    key = edge_index[1] * r + edge_type
+    s = x.new_zeros(n * r, d).index_add_(0, key, x.index_select(0, edge_index[0]))
+    return (s / cnt.view(-1, 1)).view(n, r * d)
+
+
+def _mean_agg_transposed(g, edge_index, edge_type, n, r, cnt):
+    """autograd of ``_mean_agg``: out[src, rel] += g[dst] / cnt[dst, rel]  -> [N, R*d]"""
+    d = g.size(1)
+    w = 1.0 / cnt[edge_index[1] * r + edge_type]
+    rows = g.index_select(0, edge_index[1]) * w.view(-1, 1)
+    return g.new_zeros(n * r, d).index_add_(0, edge_index[0] * r + edge_type, rows).view(n, r * d)
+
+
+def encoder_explicit_f64(emb, conv1: dict, conv2: dict, edge_index, edge_type, cot,
+                         relu_mask: Optional[torch.Tensor] = None, half_forward: bool = False,
+                         half_backward: bool = False):
+    """conv1 -> relu -> conv2 (rgcn.py:117-130) and its whole backward evaluated in float64,
+    every step written out (no autograd), from float32 parameters.
+
+    ``half_forward=False``: the float64 evaluation of the formula the loop path above computes -
+    the yardstick the fp32 results (the HIP path's and restatement #1's) are measured against.
+
+    ``half_forward=True``: the EXACT MEANING of BASELINE configs[4] ("fp16 features + fp32
+    accumulate") as the HIP path defines it: each gather reads the fp16-rounded feature table,
+    each transform rounds both operands ``[agg | x]`` and ``[W ; root]`` to fp16 (nearest even),
+    products are exact and sums wide; the backward is the fp32 formula on the tensors the forward
+    saved (un-rounded ``agg``, ``x``, ``h``, fp32 weights).  ``half_backward=True`` additionally
+    rounds the operands of the three gradient GEMMs per layer to fp16 (gradient tables, ``agg``,
+    ``x`` and weights), sums wide.
+
+    ``relu_mask`` [N, hidden] (bool): the ReLU decisions to use in the backward (pass the
+    device's ``h > 0`` so that a pre-activation within rounding of zero cannot flip a unit
+    between the two sides); default ``h > 0`` of this evaluation.
+
+    -> dict(out, h, grads={"emb", "conv1.weight", ..., "conv2.bias"[, "convN.comp"]})"""
+    f64 = torch.float64
+    n, r = emb.size(0), (conv1["comp"].size(0) if conv1.get("comp") is not None else conv1["weight"].size(0))
+    cnt = _segment_counts(edge_index, edge_type, n, r, f64)
+    rf = _r16 if half_forward else (lambda t: t)
+    rb = _r16 if half_backward else (lambda t: t)
+
+    def weights(c):
+        w = effective_weight(c["weight"].to(f64), None if c.get("comp") is None else c["comp"].to(f64), r)
+        wcat = w.reshape(-1, w.size(-1))
+        if c.get("root") is not None:
+            wcat = torch.cat([wcat, c["root"].to(f64)])
+        return w, wcat
+
+    def layer_fwd(x, c):
+        _, wcat = weights(c)
+        agg = _mean_agg(rf(x), edge_index, edge_type, n, r, cnt)
+        a = torch.cat([agg, x], 1) if c.get("root") is not None else agg
+        z = rf(a) @ rf(wcat)
+        if c.get("bias") is not None:
+            z = z + c["bias"].to(f64)
+        return agg, a, z
+
+    def layer_bwd(g, a, c, want_x=True):
+        w, wcat = weights(c)
+        d_in = w.size(1)
+        gwcat = rb(a).t() @ rb(g)
+        gw_eff = gwcat[: r * d_in].view(r, d_in, -1)
+        out = {"root": gwcat[r * d_in:] if c.get("root") is not None else None,
+               "bias": g.sum(0) if c.get("bias") is not None else None}
+        if c.get("comp") is not None:
+            basis = c["weight"].to(f64)
+            out["comp"] = torch.einsum("rio,bio->rb", gw_eff, basis)
+            out["weight"] = torch.einsum("rb,rio->bio", c["comp"].to(f64), gw_eff)
+        else:
+            out["weight"] = gw_eff
+        gx = None
+        if want_x:
+            gagg = _mean_agg_transposed(g, edge_index, edge_type, n, r, cnt)
+            ga = torch.cat([gagg, g], 1) if c.get("root") is not None else gagg
+            wt = torch.cat([w.transpose(1, 2).reshape(-1, d_in)] +
+                           ([c["root"].to(f64).t()] if c.get("root") is not None else []))
+            gx = rb(ga) @ rb(wt)
+        return out, gx
+
+    x = emb.to(f64)
+    agg1, a1, z1 = layer_fwd(x, conv1)
+    h = z1.clamp(min=0)
+    agg2, a2, out = layer_fwd(h, conv2)
+    g = cot.to(f64)
+    g2, gh = layer_bwd(g, a2, conv2)
+    mask = (h > 0) if relu_mask is None else relu_mask.to(torch.bool)
+    gz = gh * mask
+    g1, gx = layer_bwd(gz, a1, conv1)
+    grads = {"emb": gx}
+    for name, gd in (("conv1", g1), ("conv2", g2)):
+        grads.update({f"{name}.{k}": v for k, v in gd.items() if v is not None})
+    return {"out": out, "h": h, "grads": grads}

@@ -3,6 +3,9 @@
 Tolerances (BASELINE.json north_star / SURVEY.md section 8d): bucketing bit exact;
 forward max|delta| <= 1e-5 fp32; gradients <= 1e-4 relative to the largest entry.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -434,14 +437,34 @@ def test_distmult_duplicate_rows_and_dropout_path():
 
 
 # ------------------------------------------------------------------ BASELINE configs
-def _encoder_vs_oracle(dev, ei, et, n, r, dims, num_bases=None, seed=0, fwd_atol=FWD_ATOL):
+PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r02.json")
+
+
+def _record(tag, **numbers):
+    """observed errors of the full-size configs -> gpurun_out/parity_r02.json (copied to profiles/)"""
+    try:
+        os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+        log = json.load(open(PARITY_LOG)) if os.path.exists(PARITY_LOG) else {}
+        log[tag] = {k: float(v) for k, v in numbers.items()}
+        json.dump(log, open(PARITY_LOG, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _encoder_vs_oracle(dev, ei, et, n, r, dims, num_bases=None, seed=0, fwd_atol=FWD_ATOL, tag=None,
+                       oracle32_atol=None):
+    """The HIP encoder (three routes) against BOTH restatements on the same seeded inputs:
+    the float64 evaluation of the oracle formula with the backward spelled out
+    (``O.encoder_explicit_f64``, the device's own ReLU decisions) at the north-star gates
+    - forward 1e-5, every gradient 1e-4 of its largest entry - and the fp32 loop path
+    (``O.encoder_ref`` + autograd), whose own distance from float64 is measured beside it."""
     torch.manual_seed(seed)
     emb = torch.nn.init.xavier_uniform_(torch.empty(n, dims[0]))
     convs = [RGCNConv(dims[0], dims[1], r, num_bases=num_bases), RGCNConv(dims[1], dims[2], r, num_bases=num_bases)]
     for c in convs:
         c.bias.data.uniform_(-0.1, 0.1)
     cot = torch.randn(n, dims[2])
-    # oracle
+    # oracle #1: fp32 loop path + autograd
     ref_p = [{k: v.detach().clone().requires_grad_(True) for k, v in c.named_parameters()} for c in convs]
     e_ref = emb.clone().requires_grad_(True)
     out_ref = O.encoder_ref(e_ref, ref_p[0], ref_p[1], ei, et)
@@ -449,7 +472,13 @@ def _encoder_vs_oracle(dev, ei, et, n, r, dims, num_bases=None, seed=0, fwd_atol
     # HIP
     convs = [c.to(dev) for c in convs]
     eid, etd = ei.to(dev), et.to(dev)
+    with torch.no_grad():
+        mask = (convs[0](emb.to(dev), eid, etd, activation="relu") > 0).cpu()
+    # oracle #3: float64, explicit backward, the device's ReLU decisions
+    p64 = [{k: v.detach() for k, v in rp.items()} for rp in ref_p]
+    f64 = O.encoder_explicit_f64(emb, p64[0], p64[1], ei, et, cot, relu_mask=mask)
     outs = []
+    errs = {}
     # three routes to the same numbers: separate layers + torch relu, relu fused into conv1's
     # epilogue, and the fused two-layer autograd node (relu backward in conv2's grad epilogue)
     for route in ("layers", "fused_relu", "encoder2"):
@@ -463,28 +492,53 @@ def _encoder_vs_oracle(dev, ei, et, n, r, dims, num_bases=None, seed=0, fwd_atol
         else:
             out = rgcn_encoder2(e_gpu, eid, etd, convs[0], convs[1])
         (out * cot.to(dev)).sum().backward()
-        assert_fwd(out, out_ref.detach(), fwd_atol)
-        assert_grad(e_gpu.grad, e_ref.grad)
-        for c, rp in zip(convs, ref_p):
+        assert_fwd(out, f64["out"], fwd_atol)
+        assert_grad(e_gpu.grad, f64["grads"]["emb"])
+        for name, c, rp in zip(("conv1", "conv2"), convs, ref_p):
             for k, v in c.named_parameters():
+                assert_grad(v.grad, f64["grads"][f"{name}.{k}"])
                 assert_grad(v.grad, rp[k].grad)
+        assert_fwd(out, out_ref.detach(), oracle32_atol or fwd_atol)
+        assert_grad(e_gpu.grad, e_ref.grad)
+        if route == "encoder2":
+            errs = {"fwd_max_abs_vs_f64": (out.double().cpu() - f64["out"]).abs().max(),
+                    "fwd_max_abs_vs_oracle32": (out.cpu() - out_ref.detach()).abs().max(),
+                    "oracle32_fwd_max_abs_vs_f64": (out_ref.detach().double() - f64["out"]).abs().max(),
+                    "grad_emb_rel_vs_f64": rel_err(e_gpu.grad, f64["grads"]["emb"]),
+                    "oracle32_grad_emb_rel_vs_f64": rel_err(e_ref.grad, f64["grads"]["emb"]),
+                    "grad_params_rel_vs_f64_max": max(rel_err(v.grad, f64["grads"][f"{name}.{k}"])
+                                                      for name, c in zip(("conv1", "conv2"), convs)
+                                                      for k, v in c.named_parameters()),
+                    "out_abs_max": f64["out"].abs().max()}
         outs.append((out.detach(), e_gpu.grad.clone()))
     for o, g in outs[1:]:
         assert torch.equal(o, outs[0][0]) and torch.equal(g, outs[0][1])    # same kernels, same bits
+    if tag:
+        _record(tag, **errs)
+    return errs
 
 
 def test_config_c1_two_layers_vs_oracle():
     """BASELINE configs[0]: 1k nodes / 10k edges / 3 relations, hidden 64, 2 layers."""
     dev = need_gpu()
     ei, et, n, r = synth.uniform_graph(1000, 10000, 3, seed=42)
-    _encoder_vs_oracle(dev, ei, et, n, r, (64, 64, 64))
+    _encoder_vs_oracle(dev, ei, et, n, r, (64, 64, 64), tag="C1")
 
 
 def test_config_c2_full_size_vs_oracle():
-    """BASELINE configs[1]: PrimeKG shape 30,926 / 849,456 / 3, 64 -> 128 -> 128."""
+    """BASELINE configs[1]: PrimeKG shape 30,926 / 849,456 / 3, 64 -> 128 -> 128: forward within
+    1e-5 of the float64 evaluation (the north-star bar).  The fp32 loop path sums a 30,730-edge
+    hub sequentially; its own distance from float64 is recorded beside the device's."""
     dev = need_gpu()
     ei, et, n, r = synth.primekg_like(seed=42)
-    _encoder_vs_oracle(dev, ei, et, n, r, (64, 128, 128), fwd_atol=2e-5)
+    _encoder_vs_oracle(dev, ei, et, n, r, (64, 128, 128), tag="C2", oracle32_atol=2e-5)
+
+
+def test_config_c2_true_train_graph_size():
+    """the real train graph has 1,677,772 edge columns; same encoder, same gates."""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=synth.PRIMEKG_TRAIN_EDGES, seed=7)
+    _encoder_vs_oracle(dev, ei, et, n, r, (64, 128, 128), tag="C2_E1677772", oracle32_atol=2e-5)
 
 
 def test_config_c3_bases_on_real_subgraph():
@@ -492,6 +546,14 @@ def test_config_c3_bases_on_real_subgraph():
     dev = need_gpu()
     z = load_golden("primekg_test_edges.npz")
     _encoder_vs_oracle(dev, z["edge_index"].long(), z["edge_type"].long(), 30926, 3, (64, 256, 256), num_bases=4)
+
+
+def test_config_c3_full_size_vs_oracle():
+    """BASELINE configs[2] at full size: 30,926 / 849,456 / 3, 64 -> 256 -> 256, num_bases = 4 - d = 256
+    gathers over the 30k-edge hub and the transform-first input gradient of conv1 (conv.py `_input_grad`)."""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(seed=42)
+    _encoder_vs_oracle(dev, ei, et, n, r, (64, 256, 256), num_bases=4, tag="C3", oracle32_atol=2e-5)
 
 
 def test_encoder_training_mode_uses_torch_dropout_stream():
@@ -708,43 +770,61 @@ def test_fp16_matrix_core_transform_respects_relation_masks():
                        ops.transform_fwd(agg, x, w, root, None, half=True))       # skipped tiles were exact zeros
 
 
-def test_config_c5_fp16_features_vs_fp32_oracle():
-    """configs[4]: PrimeKG shape, fp16 feature table + fp32 accumulate vs the fp32 oracle:
-    <= 2e-3 relative (SURVEY 8d parity gate)."""
+def test_config_c5_fp16_features_exact_meaning_and_fp32_oracle():
+    """configs[4]: PrimeKG shape, fp16 feature tables + fp16 matrix-core transforms, fp32 accumulate.
+    Gate: the path's EXACT MEANING (``O.encoder_explicit_f64(half_forward=True)``: fp16-rounded gather
+    tables and GEMM operands in the forward, the fp32 backward formulas on the saved forward tensors, the
+    device's own ReLU decisions) - forward 1e-5, every gradient 1e-4.  Against the fp32 oracle the
+    forward keeps SURVEY 8d's 2e-3 gate; the gradient distance to the fp32 oracle is REPORTED, not
+    gated: rounding the features flips the ReLU of the pre-activations within fp16 precision of zero,
+    which no fp16 feature path can avoid (observed 6e-3 .. 7e-3 relative L2)."""
     dev = need_gpu()
     ei, et, n, r = synth.primekg_like(seed=42)
     torch.manual_seed(5)
     emb = torch.nn.init.xavier_uniform_(torch.empty(n, 64))
     convs = [RGCNConv(64, 128, r, gather_dtype=torch.float16), RGCNConv(128, 128, r, gather_dtype=torch.float16)]
+    for c in convs:
+        c.bias.data.uniform_(-0.1, 0.1)
     cot = torch.randn(n, 128)
     ref_p = [{k: v.detach().clone().requires_grad_(True) for k, v in c.named_parameters()} for c in convs]
     e_ref = emb.clone().requires_grad_(True)
     out_ref = O.encoder_ref(e_ref, ref_p[0], ref_p[1], ei, et)
     (out_ref * cot).sum().backward()
     convs = [c.to(dev) for c in convs]
+    eid, etd = ei.to(dev), et.to(dev)
     e_gpu = emb.to(dev).requires_grad_(True)
-    out = rgcn_encoder2(e_gpu, ei.to(dev), et.to(dev), convs[0], convs[1])
+    out = rgcn_encoder2(e_gpu, eid, etd, convs[0], convs[1])
     (out * cot.to(dev)).sum().backward()
+    with torch.no_grad():
+        mask = (convs[0](emb.to(dev), eid, etd, activation="relu") > 0).cpu()
+    p64 = [{k: v.detach() for k, v in rp.items()} for rp in ref_p]
+    exact = O.encoder_explicit_f64(emb, p64[0], p64[1], ei, et, cot, relu_mask=mask, half_forward=True,
+                                   half_backward=getattr(convs[0], "half_backward", False))
+    assert_fwd(out, exact["out"], 1e-5)
+    assert_grad(e_gpu.grad, exact["grads"]["emb"])
+    for name, c in zip(("conv1", "conv2"), convs):
+        for k, v in c.named_parameters():
+            assert_grad(v.grad, exact["grads"][f"{name}.{k}"])
     assert rel_err(out, out_ref.detach()) <= 2e-3
 
     def l2_rel(got, want):
         want = want.double()
         return ((got.double().cpu() - want).norm() / want.norm()).item()
 
-    # Gradients: rounding the features to fp16 (5e-4 relative) flips the ReLU of the ~1e-4 of the
-    # pre-activations that sit that close to zero, and every flip switches one unit's whole
-    # gradient on or off: a relative L2 error of about sqrt(flipped fraction) ~ 1e-2 that no
-    # fp16 feature path can avoid.  The 2e-3 gate is the forward; gradients get 2e-2 (L2), and
-    # the functional gate is the AUC parity test (tests/test_train.py).
-    assert l2_rel(e_gpu.grad, e_ref.grad) <= 2e-2
-    for c, rp in zip(convs, ref_p):
-        for k, v in c.named_parameters():
-            assert l2_rel(v.grad, rp[k].grad) <= 2e-2, k
+    _record("C5", fwd_max_abs_vs_exact_meaning=(out.double().cpu() - exact["out"]).abs().max(),
+            fwd_rel_vs_oracle32=rel_err(out, out_ref.detach()),
+            grad_emb_rel_vs_exact_meaning=rel_err(e_gpu.grad, exact["grads"]["emb"]),
+            grad_params_rel_vs_exact_meaning_max=max(rel_err(v.grad, exact["grads"][f"{name}.{k}"])
+                                                     for name, c in zip(("conv1", "conv2"), convs)
+                                                     for k, v in c.named_parameters()),
+            grad_emb_l2_rel_vs_oracle32=l2_rel(e_gpu.grad, e_ref.grad),
+            grad_params_l2_rel_vs_oracle32_max=max(l2_rel(v.grad, rp[k].grad) for c, rp in zip(convs, ref_p)
+                                                   for k, v in c.named_parameters()))
     # and it is not the fp32 path in disguise
     convs32 = [RGCNConv(64, 128, r).to(dev), RGCNConv(128, 128, r).to(dev)]
     for a, b in zip(convs32, convs):
         a.load_state_dict(b.state_dict())
-    out32 = rgcn_encoder2(emb.to(dev), ei.to(dev), et.to(dev), convs32[0], convs32[1])
+    out32 = rgcn_encoder2(emb.to(dev), eid, etd, convs32[0], convs32[1])
     assert not torch.equal(out32, out.detach())
 
 
