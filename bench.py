@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: edges/sec per R-GCN layer (fwd+bwd) on the PrimeKG-shaped
 synthetic graph (BASELINE.json metric; configs[1] = C2: 30,926 nodes / 849,456 edges /
-3 relations, 64 -> 128 -> 128, fp32).
+3 relations, 64 -> 128 -> 128, fp32 in / fp32 out).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4-1gpu]
 
 A step = one pass of the two-layer encoder over the whole graph, forward + backward
 (conv1 -> relu -> conv2, seeded cotangent; dropout p = 0; bucketing excluded - the graph is
 static and bucketed once, the one-time cost is reported in `bucket_ms`).
 value = L * E * K / t with L = 2 layers.  N > 1: node-partitioned across the ranks with an
-RCCL exchange per layer and direction (primekg_rgcn_linkprediction_amd/dist.py), one process
+exchange per layer and direction (primekg_rgcn_linkprediction_amd/dist.py), one process
 per GPU, launched by torch.distributed.run.
 
-Rank 0 prints ONE JSON line, carrying `roofline` (the dominant gather kernel, HIP events
-recorded live inside the timed region on the launch stream) and, at N = 1, `cpu_baseline`
-(the PyG-equivalent CPU path of oracle/ timed on this host's cores on a bounded sample).
+Rank 0 prints ONE JSON line.  Beside the contract's fields it carries
+  roofline       the dominant gather kernel: algorithmic bytes / live HIP-event time against the HBM peak
+                 (the contract's figure; exceeds 1 at C2 because the 8-16 MB row table is L2/Infinity-Cache
+                 resident) AND the two figures that mean something there: compulsory HBM bytes / time
+                 against the HBM peak, and the achieved rate against the chip's measured L2-resident
+                 indexed-row ceiling (MI355X_MICROARCH.md, "Indexed rows: gather into LDS")
+  roofline_mfma  the time-dominant dense transform: flops / live HIP-event time against the fp32 matrix
+                 peak (the arithmetic the caller asked for) and, in split precision, the executed fp16
+                 MFMA flops (3 passes) against the fp16 matrix peak
+  cpu_baseline   (N = 1) the oracle's PyG-equivalent CPU path on this host, thread count swept
+The secondary workloads (`--workload c3`, `--workload c4-1gpu`: C4's 500k-node / 20M-edge / 16-relation
+graph on ONE GPU, where the 256 MB table is no longer cache resident) print the same line for their
+shape; the headline stays C2.
 """
 import argparse
 import json
@@ -28,8 +38,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-DIMS = (64, 128, 128)
+L2_GATHER_CEILING_GBS = (16800.0, 18800.0)   # same guide: rows gathered from the XCD's L2, chip-wide
+MALL_GATHER_GBS = 8600.0       # same guide: 38 MB table, uniformly random rows (Infinity Cache)
+F32_MATRIX_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 (= fp32 vector rate)
+F16_MATRIX_PEAK_TF = 2500.0    # dense fp16 MFMA
 LAYERS = 2
+PMC_FILES = ("r02_pmc_counters.json", "r01_pmc_counters.json")
+
+WORKLOADS = {
+    "c2": {"dims": (64, 128, 128), "bases": None, "graph": "primekg",
+           "name": "C2: PrimeKG-shaped synthetic graph"},
+    "c3": {"dims": (64, 256, 256), "bases": 4, "graph": "primekg",
+           "name": "C3 (secondary): PrimeKG-shaped synthetic graph, num_bases=4"},
+    "c4-1gpu": {"dims": (64, 128, 128), "bases": None, "graph": "uniform", "nodes": 500_000, "edges": 20_000_000,
+                "relations": 16, "name": "C4 on ONE GPU (secondary): uniform synthetic graph"},
+}
 
 
 def parse_args():
@@ -37,13 +60,14 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--edges", type=int, default=None, help="override E (default 849,456)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--edges", type=int, default=None, help="override E of the PrimeKG-shaped graph (default 849,456)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches, never a HIP graph replay")
     ap.add_argument("--graph", action="store_true", help="time the HIP graph replay even if eager calibrates faster")
     ap.add_argument("--no-replica", action="store_true",
                     help="N > 1: skip the batch-replica leg reported beside the node-partitioned number")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--fp16-gather", action="store_true",
                     help="BASELINE configs[4]: forward gathers read an fp16 copy of the feature table "
                          "(fp32 accumulate); NOT the headline configuration")
@@ -61,31 +85,43 @@ def gather_bytes(num_edges, num_nodes, num_relations, d, weighted):
     return b
 
 
+def gather_compulsory_bytes(num_edges, num_nodes, num_relations, d, weighted):
+    """What HBM must move for that launch if every cache were perfect: the row table ONCE, the ids
+    (and weights) once, rowptr / cnt once, the output once."""
+    nr = num_nodes * num_relations
+    b = 4 * num_nodes * d + 4 * num_edges + 4 * (nr + 1) + 4 * nr * d
+    b += 4 * num_edges if weighted else 4 * nr
+    return b
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate runs, gfx950 correction applied: profiles/r01_pmc_counters.json);
-    None when the summary is absent.  Counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_counters.json")
-    try:
-        with open(path) as fh:
-            table = json.load(fh)["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    for name, entry in table.items():
-        if name.replace(" ", "") == kernel.replace(" ", ""):
-            return entry.get("hbm_bytes")
-    return None
+    """HBM-side bytes per launch of `kernel` from a COMMITTED PMC pass (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, gfx950 correction applied) - counters cannot be read from inside
+    this process, so this is a file constant, labelled as such.  -> (bytes | None, source)"""
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as fh:
+                table = json.load(fh)["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for kname, entry in table.items():
+            if kname.replace(" ", "") == kernel.replace(" ", ""):
+                return entry.get("hbm_bytes"), f"profiles/{name} (committed rocprofv3 --pmc passes, not measured in this run)"
+    return None, "no committed PMC pass for this kernel"
 
 
-def cpu_baseline(ei, et, n, r, seconds):
+def cpu_baseline(ei, et, n, r, dims, bases, seconds):
     """PyG-equivalent CPU path (restated; torch_geometric unavailable offline): the oracle's
-    op-for-op loop path incl. autograd, all host cores, same graph/seed/step definition.
-    Mask/bucketing time is included, as PyG redoes it every call."""
+    op-for-op loop path incl. autograd on this host's cores, same graph/seed/step definition.
+    Mask/bucketing time is included, as PyG redoes it every call.  The thread count is swept over
+    {8, 16, 32, all}: `scatter_add_` stops scaling (and degrades) long before 128 threads; the
+    fastest setting is the baseline."""
     from oracle import rgcn_oracle as O
     torch.manual_seed(0)
-    emb = torch.nn.init.xavier_uniform_(torch.empty(n, DIMS[0])).requires_grad_(True)
-    convs = [O.RGCNConvRef(DIMS[0], DIMS[1], r), O.RGCNConvRef(DIMS[1], DIMS[2], r)]
-    cot = torch.randn(n, DIMS[2])
+    emb = torch.nn.init.xavier_uniform_(torch.empty(n, dims[0])).requires_grad_(True)
+    convs = [O.RGCNConvRef(dims[0], dims[1], r, num_bases=bases), O.RGCNConvRef(dims[1], dims[2], r, num_bases=bases)]
+    cot = torch.randn(n, dims[2])
 
     def step():
         h = torch.relu(convs[0](emb, ei, et))
@@ -95,19 +131,30 @@ def cpu_baseline(ei, et, n, r, seconds):
             c.zero_grad(set_to_none=True)
         out.backward(cot)
 
-    step()
-    times = []
-    t_end = time.perf_counter() + seconds
-    while time.perf_counter() < t_end or len(times) < 3:
-        t0 = time.perf_counter()
-        step()
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    return {"value": LAYERS * ei.size(1) / med, "unit": "edges/s", "cores": torch.get_num_threads(),
+    all_threads = torch.get_num_threads()
+    settings = sorted({t for t in (8, 16, 32, all_threads) if t <= all_threads})
+    sweep = {}
+    try:
+        for threads in settings:
+            torch.set_num_threads(threads)
+            step()
+            times = []
+            t_end = time.perf_counter() + seconds / len(settings)
+            while time.perf_counter() < t_end or len(times) < 2:
+                t0 = time.perf_counter()
+                step()
+                times.append(time.perf_counter() - t0)
+            times.sort()
+            sweep[threads] = (times[len(times) // 2], len(times))
+    finally:
+        torch.set_num_threads(all_threads)
+    best = min(sweep, key=lambda t: sweep[t][0])
+    med, count = sweep[best]
+    return {"value": LAYERS * ei.size(1) / med, "unit": "edges/s", "cores": best,
             "kind": "port", "ms_per_step": med * 1e3,
-            "sample": f"{len(times)} full C2 encoder fwd+bwd steps (median) of the oracle's "
-                      f"PyG-equivalent loop path, {torch.get_num_threads()} threads"}
+            "thread_sweep_edges_per_s": {str(t): LAYERS * ei.size(1) / m for t, (m, _) in sweep.items()},
+            "sample": f"{count} full encoder fwd+bwd steps (median) of the oracle's PyG-equivalent loop path "
+                      f"at {best} threads, the fastest of {settings} on this {os.cpu_count()}-cpu host"}
 
 
 def main():
@@ -120,6 +167,8 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 "
                              f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if world > 1 and args.workload != "c2":
+        raise SystemExit("N > 1 runs the headline workload (c2) only")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the measured path")
 
@@ -147,13 +196,19 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    ei, et, n, r = synth.primekg_like(num_edges=args.edges or synth.PRIMEKG_EDGES, seed=42)
+    wl = WORKLOADS[args.workload]
+    dims, bases = wl["dims"], wl["bases"]
+    if wl["graph"] == "primekg":
+        ei, et, n, r = synth.primekg_like(num_edges=args.edges or synth.PRIMEKG_EDGES, seed=42)
+    else:
+        ei, et, n, r = synth.uniform_graph(wl["nodes"], wl["edges"], wl["relations"], seed=42)
     num_edges = ei.size(1)
     torch.manual_seed(0)
-    emb_cpu = torch.nn.init.xavier_uniform_(torch.empty(n, DIMS[0]))
+    emb_cpu = torch.nn.init.xavier_uniform_(torch.empty(n, dims[0]))
     gdt = torch.float16 if args.fp16_gather else None
-    convs = [RGCNConv(DIMS[0], DIMS[1], r, gather_dtype=gdt), RGCNConv(DIMS[1], DIMS[2], r, gather_dtype=gdt)]
-    cot_cpu = torch.randn(n, DIMS[2])
+    convs = [RGCNConv(dims[0], dims[1], r, num_bases=bases, gather_dtype=gdt),
+             RGCNConv(dims[1], dims[2], r, num_bases=bases, gather_dtype=gdt)]
+    cot_cpu = torch.randn(n, dims[2])
 
     if world == 1:
         eid, etd = ei.to(dev), et.to(dev)
@@ -182,7 +237,8 @@ def main():
         bucket_ms = (time.perf_counter() - t0) * 1e3
         cot = enc.shard_rows(cot_cpu).to(dev)
         step = lambda: enc.step(cot)                                     # noqa: E731
-        parallelism = f"node-partitioned x{world} (edge-balanced ranges), RCCL exchange per layer"
+        exchange = "RCCL over xGMI" if backend == "nccl" else f"{backend} (host-staged rehearsal, NOT RCCL)"
+        parallelism = f"node-partitioned x{world} (edge-balanced ranges), exchange per layer and direction: {exchange}"
 
     def sync():
         if dist is not None:
@@ -213,40 +269,27 @@ def main():
         dist.all_reduce(t, op=op)
         return t.item()
 
-    def pick_launch_mode(step_fn):
-        """eager launches or replay of ONE captured HIP graph of the same step (RCCL collectives
-        included at N > 1: they capture like kernels), whichever calibrates faster here."""
-        allow = not args.no_graph and (world == 1 or os.environ.get("RGCN_BENCH_GRAPH_N", "1") != "0")
-        if not allow:
-            return step_fn, "eager"
-        hip_graph, ok = None, 1.0
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step_fn()
-            torch.cuda.current_stream().wait_stream(side)
-            hip_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(hip_graph, capture_error_mode="thread_local"):
-                step_fn()
-            for _ in range(3):
-                hip_graph.replay()
-            torch.cuda.synchronize()
-        except Exception as exc:                                   # pragma: no cover
-            print(f"bench: HIP graph capture failed ({exc!r}); timing eager launches", file=sys.stderr)
-            ok = 0.0
-        if agree(ok, dist.ReduceOp.MIN if dist is not None else None) < 1.0:
-            return step_fn, "eager"
-        t_graph = agree(timed(hip_graph.replay, 10), dist.ReduceOp.MAX if dist is not None else None)
-        t_eager = agree(timed(step_fn, 10), dist.ReduceOp.MAX if dist is not None else None)
-        if args.graph or t_graph < t_eager:
-            return hip_graph.replay, "hipGraph replay"
-        return step_fn, "eager"
+    def capture(step_fn):
+        """ONE HIP graph of the step (RCCL collectives included at N > 1: they capture like kernels)"""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        hip_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(hip_graph, capture_error_mode="thread_local"):
+            step_fn()
+        for _ in range(3):
+            hip_graph.replay()
+        torch.cuda.synchronize()
+        return hip_graph
 
-    # N = 1: calibrate now.  N > 1: time the eager launches first - that result is safe whatever
-    # happens later - and try the captured graph (RCCL collectives included) at the very end: a capture
-    # that fails leaves HIP unusable for the rest of the process, so nothing may depend on it.
-    run, launch_mode = pick_launch_mode(step) if world == 1 else (step, "eager")
+    run, launch_mode = step, "eager"
+    if world == 1 and not args.no_graph:
+        hip_graph = capture(step)                          # a failure here is a failure of the run: no silent fallback
+        t_graph, t_eager = timed(hip_graph.replay, 10), timed(step, 10)
+        if args.graph or t_graph < t_eager:
+            run, launch_mode = hip_graph.replay, "hipGraph replay"
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -254,20 +297,20 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
 
-    # Per-kernel durations of the gather, live, from HIP events on the launch stream: an eager
-    # pass of the same step (events cannot be read back from inside a captured graph).
-    # (At N > 1 every rank runs the pass - the exchanges are collective - and rank 0 reports the
-    # gather over its own shard, whose edge count sizes the algorithmic bytes.)
+    # Per-kernel durations, live, from HIP events on the launch stream: an eager pass of the same
+    # step (events cannot be read back from inside a captured graph).  (At N > 1 every rank runs
+    # the pass - the exchanges are collective - and rank 0 reports its own shard.)
     event_steps = min(args.steps, 20)
-    ops.GATHER_EVENTS = []
+    ops.GATHER_EVENTS, ops.GEMM_EVENTS = [], []
     for _ in range(event_steps):
         # a short device-side spin first, so that the host has queued the step's launches
         # before they execute: the events then bracket back-to-back kernels, not launch gaps
         if world == 1:
-            torch.cuda._sleep(2_000_000)
+            torch.cuda._sleep(4_000_000)
         step()
     sync()
     events, ops.GATHER_EVENTS = ops.GATHER_EVENTS, None
+    gemm_events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
     # what an empty bracket costs on this stream (two event records, nothing between): reported, not
     # subtracted - the profiler's kernel-only durations in profiles/ are shorter by about this much
     if world == 1:
@@ -285,6 +328,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    headline = args.workload == "c2" and not args.fp16_gather and args.edges in (None, synth.PRIMEKG_EDGES)
     result = {
         "metric": "edges/sec per RGCN layer (fwd+bwd), PrimeKG 30.9k nodes/849k edges/3 rels",
         "value": LAYERS * num_edges * args.steps / elapsed,
@@ -292,12 +336,15 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32" if not args.fp16_gather else "f16 feature table, f32 accumulate/transform",
+        "dtype": ("f32" if not args.fp16_gather else "f16 feature table, f32 accumulate/transform"),
         "data": "synthetic",
-        "config": {"workload": f"C2: PrimeKG-shaped synthetic graph, {n} nodes / {num_edges} edge columns / "
-                               f"{r} relations, encoder {DIMS[0]}->{DIMS[1]}->{DIMS[2]}, 2 layers fwd+bwd, "
-                               f"full graph per step, dropout 0",
-                   "parallelism": parallelism, "launch": launch_mode},
+        "config": {"workload": f"{wl['name']}, {n} nodes / {num_edges} edge columns / {r} relations, encoder "
+                               f"{dims[0]}->{dims[1]}->{dims[2]}, 2 layers fwd+bwd, full graph per step, dropout 0"
+                               + ("" if headline else "  [NOT the headline configuration]"),
+                   "parallelism": parallelism, "launch": launch_mode,
+                   "transform_arithmetic": ("fp32 values as fp16 hi/lo pairs on the fp16 matrix cores, fp32 accumulate "
+                                            "(3 MFMA passes; 1e-5 gates of tests/test_gpu_parity.py)"
+                                            if ops.GEMM_PRECISION == "split" else "fp32 MFMA")},
         "bucket_ms": bucket_ms,
     }
 
@@ -312,18 +359,58 @@ def main():
             avg = sum(ts) / len(ts)
             edges, segments = shape[(transposed, d)]
             nbytes = gather_bytes(edges, segments // r, r, d, transposed)
+            comp = gather_compulsory_bytes(edges, segments // r, r, d, transposed)
             kernels.append({"kernel": f"k_aggregate<{d // 4},{'true' if transposed else 'false'}>",
                             "d": d, "transposed": transposed, "launches_per_step": len(ts) // event_steps,
                             "avg_us": avg * 1e6, "bytes": nbytes, "gbs": nbytes / avg / 1e9,
+                            "compulsory_hbm_bytes": comp, "table_bytes": 4 * (segments // r) * d,
                             "total_us_per_step": sum(ts) / event_steps * 1e6})
         dom = max(kernels, key=lambda k: k["total_us_per_step"])
-        result["roofline"] = {"bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": dom["gbs"] / HBM_PEAK_GBS,
-                              "traffic": pmc_traffic(dom["kernel"]) if world == 1 else None,
-                              "kernel": dom["kernel"],
-                              "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"],
-                              "event_bracket_overhead_us": event_overhead_us}
+        traffic, traffic_source = pmc_traffic(dom["kernel"]) if (world == 1 and headline) else (None, "not applicable")
+        cache_resident = dom["table_bytes"] <= 200e6          # fits the 256 MiB Infinity Cache beside the streams
+        result["roofline"] = {
+            "bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["gbs"] / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": dom["kernel"], "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"],
+            "compulsory_hbm_bytes": dom["compulsory_hbm_bytes"],
+            "frac_compulsory": dom["compulsory_hbm_bytes"] / (dom["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "table_bytes": dom["table_bytes"], "table_cache_resident": cache_resident,
+            "l2_indexed_row_ceiling_gbs": list(L2_GATHER_CEILING_GBS),
+            "frac_of_l2_ceiling": [dom["gbs"] / L2_GATHER_CEILING_GBS[1], dom["gbs"] / L2_GATHER_CEILING_GBS[0]],
+            "note": ("the gathered row table is L2 / Infinity-Cache resident: `frac` (algorithmic bytes against the HBM "
+                     "peak, the contract's figure) can exceed 1; `frac_of_l2_ceiling` is the meaningful fraction here and "
+                     "`frac_compulsory` is what HBM itself has to deliver"
+                     if cache_resident else
+                     "the gathered row table exceeds the caches: `frac` is a true fraction of the HBM peak"),
+            "event_bracket_overhead_us": event_overhead_us}
         result["gather_kernels"] = kernels
+
+    if gemm_events:
+        per = {}
+        for kind, m, k, nn, prec, beg, end in gemm_events:
+            per.setdefault((kind, m, k, nn, prec), []).append(beg.elapsed_time(end) * 1e-3)
+        calls = []
+        for (kind, m, k, nn, prec), ts in sorted(per.items()):
+            avg = sum(ts) / len(ts)
+            flops = 2.0 * m * k * nn
+            calls.append({"call": kind, "M": m, "K": k, "N": nn, "arithmetic": prec,
+                          "launches_per_step": len(ts) // event_steps, "avg_us": avg * 1e6, "flops": flops,
+                          "tflops": flops / avg / 1e12, "total_us_per_step": sum(ts) / event_steps * 1e6})
+        domg = max(calls, key=lambda c: c["total_us_per_step"])
+        executed = domg["flops"] * (3 if domg["arithmetic"] == "split" else 1)
+        result["roofline_mfma"] = {
+            "bound": "mfma", "call": f"{domg['call']} [{domg['M']} x {domg['K']}] x [{domg['K']} x {domg['N']}]",
+            "arithmetic": domg["arithmetic"], "avg_us": domg["avg_us"],
+            "achieved": domg["tflops"], "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+            "frac": domg["tflops"] / F32_MATRIX_PEAK_TF,
+            "executed_tflops": executed / (domg["avg_us"] * 1e-6) / 1e12,
+            "executed_peak": F16_MATRIX_PEAK_TF if domg["arithmetic"] in ("split", "f16") else F32_MATRIX_PEAK_TF,
+            "note": ("flops = 2 M K N of the fp32 contraction the caller asked for, against the fp32 matrix peak; "
+                     "in split precision the call executes 3 fp16 MFMA passes (`executed_tflops`, against the dense fp16 "
+                     "peak) and its bracket includes the operand scan and the weight split launches"),
+            "sum_transform_us_per_step": sum(c["total_us_per_step"] for c in calls)}
+        result["transform_calls"] = calls
 
     if world > 1 and not args.no_replica:
         # Reported beside the node-partitioned number (never instead of it): batch-replica mode,
@@ -341,49 +428,47 @@ def main():
                              "parallelism": f"batch replicas x{world}: full graph and encoder per GPU, one "
                                             f"{rep._flat.numel() * 4 / 1e6:.1f} MB gradient all-reduce per step"}
 
-    if world > 1 and (backend == "nccl" or os.environ.get("RGCN_BENCH_TRY_GRAPH") == "1"):   # (the env: fallback rehearsal)
-        # Everything above is measured and safe in `result`.  Now the captured-graph launch mode of
-        # both N > 1 legs; the faster mode is the one reported.
-        import threading
-        safe_line = json.dumps(result)
+    exit_code = 0
+    if world > 1:
+        # The numbers above are eager launches and are what is reported.  Capturing the N > 1 step -
+        # collectives included - into one HIP graph is OPT-IN (RGCN_BENCH_GRAPH_N=1): a capture that
+        # fails leaves HIP unusable for the rest of the process and a collective inside a replay can
+        # hang, so the attempt comes last, its outcome is written into the line, and the process exits
+        # non-zero if it failed or hung (the eager line is still printed first).
+        result["graph_attempt"] = "not attempted (opt in with RGCN_BENCH_GRAPH_N=1)"
+        if os.environ.get("RGCN_BENCH_GRAPH_N", "0") == "1" and not args.no_graph:
+            import threading
 
-        def bail_out():                                                    # pragma: no cover
-            # the graph attempt hung (a collective that never completes): report what was measured
-            if rank == 0:
-                print(safe_line, flush=True)
-            os._exit(0)
+            def bail_out():                                                    # pragma: no cover
+                result["graph_attempt"] = "hung: a replayed collective never completed; eager numbers reported"
+                if rank == 0:
+                    print(json.dumps(result), flush=True)
+                os._exit(4)
 
-        watchdog = threading.Timer(float(os.environ.get("RGCN_BENCH_GRAPH_TIMEOUT", "120")), bail_out)
-        watchdog.daemon = True
-        watchdog.start()
-        try:
-            g_run, g_mode = pick_launch_mode(step)
-            if g_mode != "eager":
-                g_s = agree(timed(g_run, args.steps), dist.ReduceOp.MAX)
+            watchdog = threading.Timer(float(os.environ.get("RGCN_BENCH_GRAPH_TIMEOUT", "120")), bail_out)
+            watchdog.daemon = True
+            watchdog.start()
+            try:
+                g = capture(step)
+                g_s = agree(timed(g.replay, args.steps), dist.ReduceOp.MAX)
+                result["graph_attempt"] = "ok"
+                result["graph_ms_per_step"] = g_s * 1e3
                 if g_s < result["ms_per_step"] * 1e-3:
+                    result["eager_ms_per_step"] = result["ms_per_step"]
                     result.update(value=LAYERS * num_edges / g_s, ms_per_step=g_s * 1e3)
-                    result["config"]["launch"] = g_mode
-                    result["eager_ms_per_step"] = elapsed / args.steps * 1e3
-            if "replica" in result:
-                r_run, r_mode = pick_launch_mode(rep_step)
-                if r_mode != "eager":
-                    r_s = agree(timed(r_run, args.steps), dist.ReduceOp.MAX)
-                    if r_s < result["replica"]["ms_per_step"] * 1e-3:
-                        result["replica"].update(value=world * LAYERS * num_edges / r_s, ms_per_step=r_s * 1e3,
-                                                 launch=r_mode)
-        except Exception as exc:                                           # pragma: no cover
-            print(f"bench: graph launch mode not measured ({exc!r}); reporting eager launches", file=sys.stderr)
-            watchdog.cancel()
-            # HIP is unusable in this process now: report the eager line and leave without teardown
-            if rank == 0:
-                print(safe_line, flush=True)
-            sys.stderr.flush()
-            os._exit(0)
-        finally:
-            watchdog.cancel()
+                    result["config"]["launch"] = "hipGraph replay"
+            except Exception as exc:                                           # pragma: no cover
+                result["graph_attempt"] = f"failed: {exc!r}; eager numbers reported"
+                watchdog.cancel()
+                if rank == 0:
+                    print(json.dumps(result), flush=True)
+                sys.stderr.flush()
+                os._exit(3)                       # HIP is unusable in this process now: no teardown, non-zero exit
+            finally:
+                watchdog.cancel()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(ei, et, n, r, args.cpu_seconds)
+        result["cpu_baseline"] = cpu_baseline(ei, et, n, r, dims, bases, args.cpu_seconds)
         result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
 
     if rank == 0:
@@ -393,6 +478,7 @@ def main():
             dist.destroy_process_group()
         except Exception:                                                  # pragma: no cover
             pass
+    sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 8
+#define RGCN_ABI_VERSION 9
 
 enum {
   RGCN_OK = 0,
@@ -83,6 +83,9 @@ void rgcn_graph_destroy(rgcn_graph* g);
 int64_t rgcn_graph_num_edges(const rgcn_graph* g);
 int64_t rgcn_graph_num_nodes(const rgcn_graph* g);
 int64_t rgcn_graph_num_relations(const rgcn_graph* g);
+/* max over the segments of that direction of the sum of their |edge weights| (1 for the mean structure):
+ * |aggregate row| <= bound * max |gathered table|.  0 if the direction does not exist. */
+float rgcn_graph_weight_bound(const rgcn_graph* g, int transposed);
 /* number of aggregate launches (tree levels) one rgcn_aggregate call issues */
 int rgcn_graph_num_levels(const rgcn_graph* g, int transposed);
 
@@ -156,10 +159,22 @@ int rgcn_aggregate_and_reduce(const rgcn_graph* g, int transposed, const float* 
  * features + fp32 accumulate").  agg and the workspace stay fp32. */
 int rgcn_aggregate_f16(const rgcn_graph* g, int transposed, const void* x_f16, int64_t d, float* agg,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* "amax buffer": DEVICE float[RGCN_AMAX_FLOATS]; its VALUE, max |tensor|, is the maximum over its 256 "heads"
+ * (entries 0, 8, 16, ...; the other entries are never touched).  Kernels that produce a tensor publish wave
+ * maxima into 64 of the heads, 128 bytes apart, with an atomic max on the bit pattern (order-free, so the value
+ * is deterministic; spread so a launch's atomics do not queue on one address): every head must be zero before
+ * such a producer runs (rgcn_absmax clears buffers on the side).  The split-precision transforms below scale
+ * their operands by it. */
+#define RGCN_AMAX_FLOATS 2048
+/* rgcn_aggregate_and_reduce that also leaves max |agg| in the amax buffer `amax` (zeroed by the caller). */
+int rgcn_aggregate_amax(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
+                        void* workspace, size_t workspace_bytes, const rgcn_slab_job* job, float* amax,
+                        void* stream);
 /* One launch of the above (level in [0, rgcn_graph_num_levels)); calling the levels in order
  * equals rgcn_aggregate.  Lets a profiler bracket the level-0 gather kernel by itself. */
 int rgcn_aggregate_level(const rgcn_graph* g, int transposed, int level, const float* x, int64_t d,
-                         float* agg, void* workspace, size_t workspace_bytes, void* stream);
+                         float* agg, void* workspace, size_t workspace_bytes, float* amax /* or NULL */,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Per-relation transform + root + bias (row A6), fp32 MFMA (v_mfma_f32_32x32x2_f32):
@@ -221,6 +236,61 @@ int rgcn_transform_bwd_params_begin(const float* agg, const float* x, const floa
                                     float* grad_bias, void* workspace, size_t workspace_bytes, void* stream,
                                     rgcn_slab_job* job);
 int rgcn_slab_reduce(const rgcn_slab_job* job, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * The three transforms above (rows A6 / A7) on the fp16 matrix cores in SPLIT PRECISION: fp32 in,
+ * fp32 out, 1e-5-class results at 3/16 of the fp32 MFMA's cycles.  Every operand value v is carried
+ * as two fp16 numbers, v * 2^e = hi + lo with one power-of-two scale per operand tensor (its largest
+ * magnitude scaled into [2^14, 2^15)), and a product is lo*hi + hi*lo + hi*hi in three
+ * v_mfma_f32_32x32x16_f16 passes with fp32 accumulation (csrc/rgcn_transform_split.hip): ~2^-22
+ * relative error per product, absolute error 2^-39 of the tensor maximum for elements far below it.
+ *
+ * The aggregate operand (agg / gagg) is scaled by a BOUND on its magnitude, agg_amax_mul * value(agg_amax):
+ * pass the amax buffer of the table the aggregate was gathered FROM and the structure's
+ * rgcn_graph_weight_bound (1 for a mean: a mean of rows cannot exceed the table's maximum) - no pass over
+ * the aggregate, no atomics in the gather; or the aggregate's own maximum (rgcn_aggregate_amax) and 1.
+ * The second operand (x / g) is scaled by its own maximum; the accumulator is carried from the one scale
+ * to the other where the k loop passes between the operands (powers of two: exact).
+ * *_amax arguments: an amax buffer (see rgcn_aggregate_amax) holding max |operand| as left by the operand's producer
+ * (rgcn_aggregate_amax, rgcn_absmax, or the out_amax / grad_x_amax of a previous transform); NULL makes
+ * the call scan that operand itself (one extra pass over it).  out_amax / grad_x_amax (or NULL):
+ * receives max |result| (zeroed by the caller).  Shapes outside the kernels' tiling (d_in resp. d_out
+ * not a multiple of 32; 64 for the parameter gradients) return RGCN_ERR_UNSUPPORTED: use the fp32 calls.
+ * `workspace`: rgcn_transform_split_workspace_bytes (fwd, bwd_input),
+ * rgcn_transform_bwd_params_split_workspace_bytes (bwd_params).
+ * ---------------------------------------------------------------------------------- */
+/* amax buffer `out` <- max |x[i]| in one launch, no atomics, no prior clearing (every head is written); the
+ * same launch clears the heads of `zero_count` (<= 256) further amax buffers laid out back to back from
+ * `zero_buffers` - the buffers the kernels of the coming pass publish into. */
+int rgcn_absmax(const float* x, int64_t n, float* out, float* zero_buffers, int zero_count, void* stream);
+/* The weights of one layer split ONCE per step for both transforms that multiply by them ([W ; root] as fp16
+ * hi / lo images in the forward and in the input-gradient orientation, one scale): pass the result as `packed`
+ * to the two calls below; with packed == NULL each call splits the weights itself (into its workspace). */
+size_t rgcn_weights_split_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
+int rgcn_weights_split_pack(const float* weight, const float* root, int64_t num_relations, int64_t d_in,
+                            int64_t d_out, void* packed, size_t packed_bytes, void* stream);
+size_t rgcn_transform_split_workspace_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
+int rgcn_transform_fwd_split(const float* agg, const float* x, const float* weight, const float* root,
+                             const void* packed, const float* bias, int relu, const uint32_t* tile_mask,
+                             int64_t num_nodes, int64_t num_relations, int64_t d_in, int64_t d_out,
+                             const float* agg_amax, float agg_amax_mul, const float* x_amax, float* out,
+                             float* out_amax, void* workspace, size_t workspace_bytes, void* stream);
+int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const float* weight, const float* root,
+                                   const void* packed, const float* relu_mask, const uint32_t* tile_mask,
+                                   int64_t num_nodes, int64_t num_relations, int64_t d_in, int64_t d_out,
+                                   const float* gagg_amax, float gagg_amax_mul, const float* g_amax,
+                                   float* grad_x, float* grad_x_amax, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+size_t rgcn_transform_bwd_params_split_workspace_bytes(int64_t num_nodes, int64_t num_relations,
+                                                       int64_t d_in, int64_t d_out);
+/* slab GEMM in split precision; the pending fixed-order reduction is consumed exactly like the one of
+ * rgcn_transform_bwd_params_begin (rgcn_slab_reduce / rgcn_aggregate_and_reduce / rgcn_aggregate_amax) */
+int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, const float* g,
+                                          const uint32_t* tile_mask, int64_t num_nodes, int64_t num_relations,
+                                          int64_t d_in, int64_t d_out, const float* agg_amax,
+                                          float agg_amax_mul, const float* x_amax, const float* g_amax, float* grad_weight,
+                                          float* grad_root, float* grad_bias, void* workspace,
+                                          size_t workspace_bytes, void* stream, rgcn_slab_job* job);
 
 /* ------------------------------------------------------------------------------------
  * DistMult head (rows C1 + C2; rgcn.py:325-326 row gathers + rgcn.py:207-211):

@@ -255,12 +255,15 @@ def top_drugs_ref(embeddings, disease_idx, drug_indices, top_k=10, threshold=0.0
 
 
 def encoder_ref(emb_weight, conv1: dict, conv2: dict, edge_index, edge_type,
-                dropout_p: float = 0.0, training: bool = False):
+                dropout_p: float = 0.0, training: bool = False, relu_mask=None):
     """conv1 -> relu -> dropout -> conv2 (rgcn.py:117-130); convN are dicts of
-    weight/root/bias[/comp] tensors."""
+    weight/root/bias[/comp] tensors.  ``relu_mask`` (bool [N, hidden], optional): the ReLU decisions
+    to use instead of this evaluation's own ``z > 0`` - a full-size comparison passes the device's, so
+    that a pre-activation within fp32 rounding of zero cannot switch a unit's whole gradient on one
+    side only (the forward changes by at most that rounding)."""
     x = rgcn_conv_ref(emb_weight, edge_index, edge_type, conv1["weight"], conv1["root"],
                       conv1["bias"], conv1.get("comp"))
-    x = F.relu(x)
+    x = F.relu(x) if relu_mask is None else x * relu_mask.to(x.dtype)
     x = F.dropout(x, dropout_p, training)
     return rgcn_conv_ref(x, edge_index, edge_type, conv2["weight"], conv2["root"],
                          conv2["bias"], conv2.get("comp"))

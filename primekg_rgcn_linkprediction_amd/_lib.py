@@ -13,7 +13,7 @@ from ctypes import c_float, POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -45,6 +45,7 @@ PROTOTYPES = {
     "rgcn_graph_num_nodes": (_I64, [c_void_p]),
     "rgcn_graph_num_relations": (_I64, [c_void_p]),
     "rgcn_graph_num_levels": (c_int, [c_void_p, c_int]),
+    "rgcn_graph_weight_bound": (c_float, [c_void_p, c_int]),
     "rgcn_graph_arrays": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p),
                                   POINTER(c_void_p), POINTER(c_void_p)]),
     "rgcn_graph_export": (c_int, [c_void_p, c_int, _P, _P, _P, _P, _P]),
@@ -52,7 +53,7 @@ PROTOTYPES = {
     "rgcn_aggregate_workspace_bytes": (c_size_t, [c_void_p, c_int, _I64]),
     "rgcn_aggregate": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, _P]),
     "rgcn_aggregate_f16": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, _P]),
-    "rgcn_aggregate_level": (c_int, [c_void_p, c_int, c_int, _P, _I64, _P, _P, c_size_t, _P]),
+    "rgcn_aggregate_level": (c_int, [c_void_p, c_int, c_int, _P, _I64, _P, _P, c_size_t, _P, _P]),
     "rgcn_graph_tile_mask": (c_void_p, [c_void_p, c_int, POINTER(c_int64)]),
     "rgcn_transform_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _I64, _I64, _I64, _I64, _P, _P]),
     "rgcn_transform_fwd_f16_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),
@@ -65,6 +66,18 @@ PROTOTYPES = {
                                                 POINTER(SlabJob)]),
     "rgcn_slab_reduce": (c_int, [POINTER(SlabJob), _P]),
     "rgcn_aggregate_and_reduce": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, POINTER(SlabJob), _P]),
+    "rgcn_aggregate_amax": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, POINTER(SlabJob), _P, _P]),
+    "rgcn_absmax": (c_int, [_P, _I64, _P, _P, c_int, _P]),
+    "rgcn_weights_split_bytes": (c_size_t, [_I64, _I64, _I64]),
+    "rgcn_weights_split_pack": (c_int, [_P, _P, _I64, _I64, _I64, _P, c_size_t, _P]),
+    "rgcn_transform_split_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),
+    "rgcn_transform_fwd_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P,
+                                         _P, _P, c_size_t, _P]),
+    "rgcn_transform_bwd_input_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P,
+                                               _P, _P, c_size_t, _P]),
+    "rgcn_transform_bwd_params_split_workspace_bytes": (c_size_t, [_I64, _I64, _I64, _I64]),
+    "rgcn_transform_bwd_params_split_begin": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P, _P,
+                                                      _P, _P, _P, c_size_t, _P, POINTER(SlabJob)]),
     "distmult_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "distmult_rank_tails": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "distmult_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),

@@ -60,8 +60,29 @@ class _BasisCompose(torch.autograd.Function):
         return g_comp, g_basis
 
 
+class _Scales:
+    """The operand scales of one pass of the split-precision transforms (``ops.GEMM_PRECISION``): one
+    device allocation of amax buffers (``ops.amax_buffer`` layout).  Buffer 0 receives ``max |t|`` of the
+    pass's external tensor ``t`` (the embedding table / the incoming gradient) and the SAME launch clears
+    the others, which the pass's kernels then publish their results' maxima into, handed out slot by
+    slot.  In fp32 mode nothing is allocated and every slot is None."""
+
+    def __init__(self, t: Tensor, slots: int = 2):
+        self._buf, self._next, self.first = None, 1, None
+        if ops.GEMM_PRECISION == "split":
+            self._buf = torch.empty(slots, ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
+            self.first = ops.absmax(t, self._buf[0], clear=self._buf[1:])
+
+    def slot(self) -> Optional[Tensor]:
+        if self._buf is None:
+            return None
+        self._next += 1
+        return self._buf[self._next - 1]
+
+
 def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Optional[Tensor],
-                tail: Optional["ops.PendingParamGrads"] = None) -> Tensor:
+                tail: Optional["ops.PendingParamGrads"] = None, g_amax: Optional[Tensor] = None,
+                scales: Optional[_Scales] = None, packed: Optional["ops.SplitWeights"] = None) -> Tensor:
     """``d loss / d x`` of one layer from ``g = d loss / d out``.
 
     Default: gather first (``gagg = transposed aggregate of g``, then one GEMM with
@@ -77,10 +98,12 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
               if (d_out >= 4 * d_in and root is not None and not graph.bipartite) else None)
     # `tail`: the pending slab reduction of this layer's parameter gradients rides in the gather launch
     if merged is None:
-        gagg = ops.aggregate(graph, g, transposed=True, tail=tail)      # autograd of A3 + A4 (fp32 grads)
-        return ops.transform_bwd_input(gagg, g, weight, root, graph=graph)  # autograd of A6 wrt x
+        gagg = ops.aggregate(graph, g, transposed=True, tail=tail)       # autograd of A3 + A4 (fp32 grads)
+        # |gagg| <= (largest sum of 1/cnt weights over a node's out-edges of one relation) * max |g|
+        return ops.transform_bwd_input(gagg, g, weight, root, graph=graph, amax=(g_amax, g_amax),
+                                       amax_mul=graph.weight_bound(True), packed=packed)   # autograd of A6 wrt x
     wcat = torch.cat([weight.reshape(r * d_in, d_out), root]).view(1, (r + 1) * d_in, d_out)
-    t = ops.transform_bwd_input(g, g, wcat, None)                        # [N, (R+1) d_in] = g @ wcat^T
+    t = ops.transform_bwd_input(g, g, wcat, None, amax=(g_amax, None))   # [N, (R+1) d_in] = g @ wcat^T
     return ops.aggregate(merged, t.view(-1, d_in), tail=tail)
 
 
@@ -95,17 +118,21 @@ class _RGCNConvFunction(torch.autograd.Function):
         root_c = root.contiguous() if root is not None else None
         bias_c = bias.contiguous() if bias is not None else None
         ctx.gather_dtype = gather_dtype
-        agg = ops.aggregate(graph, _table(x, gather_dtype), transposed=False)   # rows A3 + A4
-        out = ops.transform_fwd(agg, x, weight, root_c, bias_c, relu=relu, graph=graph,
-                                half=gather_dtype == torch.float16)                    # row A6 (+ fused ReLU)
-        ctx.graph, ctx.relu = graph, relu
+        half = gather_dtype == torch.float16
+        scales = _Scales(x, slots=1)
+        x_amax = scales.first            # also the bound of agg: a mean of rows cannot exceed the table's maximum
+        packed = ops.split_weights(weight, root_c)                                    # once, for forward and backward
+        agg = ops.aggregate(graph, _table(x, gather_dtype), transposed=False)          # rows A3 + A4
+        out = ops.transform_fwd(agg, x, weight, root_c, bias_c, relu=relu, graph=graph, half=half,
+                                amax=(x_amax, x_amax), packed=packed)                  # row A6 (+ fused ReLU)
+        ctx.graph, ctx.relu, ctx.packed = graph, relu, packed
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
-        ctx.save_for_backward(x, agg, weight, root_c, out if relu else None)
+        ctx.save_for_backward(x, agg, weight, root_c, out if relu else None, x_amax)
         return out
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        x, agg, weight, root, out = ctx.saved_tensors
+        x, agg, weight, root, out, x_amax = ctx.saved_tensors
         graph = ctx.graph
         if ctx.relu:
             g = g * (out > 0)                                               # ReLU backward
@@ -113,11 +140,14 @@ class _RGCNConvFunction(torch.autograd.Function):
         need_x, need_w, need_root, need_bias = ctx.needs_input_grad[:4]
         gx = gw = groot = gbias = None
         pending = None
+        scales = _Scales(g, slots=1)
+        g_amax = scales.first
         if need_w or (need_root and ctx.has_root) or (need_bias and ctx.has_bias):
             pending = ops.transform_bwd_params(agg, x, g, graph.num_relations, want_root=ctx.has_root,
-                                               want_bias=ctx.has_bias, graph=graph, defer=True)
+                                               want_bias=ctx.has_bias, graph=graph, defer=True,
+                                               amax=(x_amax, x_amax, g_amax))
         if need_x:
-            gx = _input_grad(graph, g, weight, root, tail=pending)
+            gx = _input_grad(graph, g, weight, root, tail=pending, g_amax=g_amax, scales=scales, packed=ctx.packed)
         if pending is not None:
             pending.finish()                                                # no gather took it along
             gw, groot, gbias = pending.grads
@@ -140,37 +170,53 @@ class _Encoder2Function(torch.autograd.Function):
     def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph, gather_dtype=None, p: float = 0.0):
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
         ctx.gather_dtype = gather_dtype
-        agg1 = ops.aggregate(graph, _table(x, gather_dtype))
         half = gather_dtype == torch.float16          # configs[4]: fp16 operands on the fp16 matrix cores too
-        h = ops.transform_fwd(agg1, x, w1, root1, b1, relu=True, graph=graph, half=half)
+        # operand scales of the split-precision transforms: max |.| of every dense tensor, left behind by
+        # the kernel that produced it (one zeroed buffer per pass); None throughout in fp32 / fp16 mode
+        # A dense tensor's maximum is left behind by the launch that produces it (the first launch of the pass
+        # for x, the epilogue of conv1's transform for h); an aggregate is scaled by the bound its table's
+        # maximum gives (a mean of rows cannot exceed it), so the gathers publish nothing.
+        scales = _Scales(x)
+        x_amax, h_amax = scales.first, scales.slot()
+        pk1, pk2 = ops.split_weights(w1, root1), ops.split_weights(w2, root2)   # once, for forward and backward
+        agg1 = ops.aggregate(graph, _table(x, gather_dtype))
+        h = ops.transform_fwd(agg1, x, w1, root1, b1, relu=True, graph=graph, half=half, amax=(x_amax, x_amax),
+                              amax_out=h_amax, packed=pk1)
         if p > 0:
             h = torch.native_dropout(h, p, True)[0]
+            h_amax = h_amax * (1.0 / (1.0 - p)) if h_amax is not None else None     # kept units are scaled up
         agg2 = ops.aggregate(graph, _table(h, gather_dtype))
-        out = ops.transform_fwd(agg2, h, w2, root2, b2, graph=graph, half=half)
-        ctx.graph, ctx.p = graph, p
+        out = ops.transform_fwd(agg2, h, w2, root2, b2, graph=graph, half=half, amax=(h_amax, h_amax), packed=pk2)
+        ctx.graph, ctx.p, ctx.packed = graph, p, (pk1, pk2)
         ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
-        ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2)
+        ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, agg1, h, agg2, w1, root1, w2, root2 = ctx.saved_tensors
+        x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax = ctx.saved_tensors
         graph, r = ctx.graph, ctx.graph.num_relations
         has_root1, has_b1, has_root2, has_b2 = ctx.flags
         g = g.contiguous()
+        scales = _Scales(g)
+        g_amax, gz_amax = scales.first, scales.slot()
+        pk1, pk2 = ctx.packed
+        wb = graph.weight_bound(True)        # |transposed aggregate| <= wb * max |gradient table|
         # the slab reductions of the parameter gradients ride in the transposed gathers that follow them
         red2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2, graph=graph,
-                                        defer=True)
+                                        defer=True, amax=(h_amax, h_amax, g_amax))
         gagg2 = ops.aggregate(graph, g, transposed=True, tail=red2)
         if ctx.p > 0:
             scale = 1.0 / (1.0 - ctx.p)
             w2, root2 = w2 * scale, (root2 * scale if root2 is not None else None)
-        gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph)   # d loss / d (pre-ReLU of conv1)
+            pk2 = None                                                      # split for the unscaled weights
+        gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph, amax=(g_amax, g_amax),
+                                     amax_mul=wb, amax_out=gz_amax, packed=pk2)   # d loss / d (pre-ReLU of conv1)
         red1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1, graph=graph,
-                                        defer=True)
+                                        defer=True, amax=(x_amax, x_amax, gz_amax))
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = _input_grad(graph, gz, w1, root1, tail=red1)
+            gx = _input_grad(graph, gz, w1, root1, tail=red1, g_amax=gz_amax, scales=scales, packed=pk1)
         red2.finish()
         red1.finish()
         (gw2, groot2, gb2), (gw1, groot1, gb1) = red2.grads, red1.grads

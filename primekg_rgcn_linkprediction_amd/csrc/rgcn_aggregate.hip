@@ -34,6 +34,8 @@ constexpr int kUnroll = RGCN_HEAD;   // rows in flight per lane group = ids that
 constexpr int kReduceUnroll = RGCN_REDUCE_UNROLL;   // contiguous partial rows in flight per slot of the hub reduce
 
 __device__ inline float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ inline float f4amax(const float4& a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); }
+
 __device__ inline void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 __device__ inline void f4fma(float4& a, const float4& b, float s) {   // explicit fma: one rounding, in every build
   a.x = fmaf(b.x, s, a.x); a.y = fmaf(b.y, s, a.y); a.z = fmaf(b.z, s, a.z); a.w = fmaf(b.w, s, a.w);
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
     const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
     float* __restrict__ agg, float* __restrict__ partial, int d, const int32_t* __restrict__ head_col,
-    const float* __restrict__ head_w, const rgcn_slab_job job, int gather_blocks) {
+    const float* __restrict__ head_w, const rgcn_slab_job job, int gather_blocks, unsigned* __restrict__ amax_out) {
   __shared__ float4 red[kThreads];               // pack combine (see rgcn_common.h)
   if ((int)blockIdx.x >= gather_blocks) {        // workgroups past the gather: a pending slab reduction rides along
     rgcn_slab_reduce_block<RGCN_SLAB_OUTS, RGCN_SLAB_GROUPS>(job, (int64_t)blockIdx.x - gather_blocks, red);
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
   const int64_t item_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   const int c4 = ((int)threadIdx.x % G + (int)blockIdx.y * G) * 4;
   if (item_id >= nitems) return;                 // whole lane groups only
+  const unsigned seen = rgcn_amax_peek(amax_out);
   const bool live = c4 < d;                      // lanes past the row end still carry ids for their group
   const rgcn_item it = items[item_id];
   // packs come first in the item order: the workgroup's first slot says whether any is in here
@@ -174,15 +177,18 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
     for (int f = 1; f <= followers; ++f) f4add(acc, red[threadIdx.x + f * G]);
   }
   if (!live) return;
+  float lmax = 0.f;
   if (it.flags & RGCN_ITEM_FINAL) {
     if (cnt) {  // mean: true division by max(1, segment size), as `sum / count` does
       const float c = cnt[it.dst];
       acc.x /= c; acc.y /= c; acc.z /= c; acc.w /= c;
     }
     *reinterpret_cast<float4*>(agg + (size_t)it.dst * d + c4) = acc;
+    lmax = f4amax(acc);
   } else {
     *reinterpret_cast<float4*>(partial + (size_t)it.dst * d + c4) = acc;
   }
+  if (amax_out) rgcn_amax_publish(amax_out, lmax, seen);
 }
 
 // fp16 feature table, fp32 accumulate (BASELINE.json configs[4]): the same walk with 8 halves
@@ -302,7 +308,8 @@ __global__ __launch_bounds__(kThreads) void k_aggregate_h(
 template <int G>
 __global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* __restrict__ items,
                                                               const float* __restrict__ cnt,
-                                                              float* __restrict__ agg, float* partial, int d) {
+                                                              float* __restrict__ agg, float* partial, int d,
+                                                              unsigned* __restrict__ amax_out) {
   constexpr int SLOTS = kThreads / G;
   __shared__ float4 red[kThreads];
   const rgcn_item it = items[blockIdx.x];
@@ -335,6 +342,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* _
         s.x /= c; s.y /= c; s.z /= c; s.w /= c;
       }
       *reinterpret_cast<float4*>(agg + (size_t)it.dst * d + c4) = s;
+      if (amax_out) rgcn_amax_publish(amax_out, f4amax(s));
     } else {
       *reinterpret_cast<float4*>(partial + (size_t)it.dst * d + c4) = s;
     }
@@ -343,7 +351,8 @@ __global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* _
 
 template <int G>
 void launch_level(const rgcn_csr* c, int level, bool weighted, const float* x, const float* cnt, float* agg,
-                  float* partial, int d, hipStream_t stream, const rgcn_slab_job* tail = nullptr) {
+                  float* partial, int d, hipStream_t stream, const rgcn_slab_job* tail = nullptr,
+                  unsigned* amax_out = nullptr) {
   const int64_t nitems = c->num_items[level];
   if (nitems == 0) return;
   const unsigned gy = (unsigned)ceil_div64(d, 4 * G);
@@ -353,13 +362,13 @@ void launch_level(const rgcn_csr* c, int level, bool weighted, const float* x, c
     dim3 grid(gather_blocks + (tail ? (unsigned)rgcn_slab_reduce_blocks(job) : 0u), gy);   // tail only with gy == 1
     if (weighted)
       k_aggregate<G, true><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, c->val, cnt, agg, partial, d,
-                                                          c->head_col, c->head_w, job, (int)gather_blocks);
+                                                          c->head_col, c->head_w, job, (int)gather_blocks, amax_out);
     else
       k_aggregate<G, false><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, nullptr, cnt, agg, partial, d,
-                                                           c->head_col, nullptr, job, (int)gather_blocks);
+                                                           c->head_col, nullptr, job, (int)gather_blocks, amax_out);
   } else {
     dim3 grid((unsigned)nitems, gy);
-    k_reduce_partials<G><<<grid, kThreads, 0, stream>>>(c->items[level], cnt, agg, partial, d);
+    k_reduce_partials<G><<<grid, kThreads, 0, stream>>>(c->items[level], cnt, agg, partial, d, amax_out);
   }
 }
 
@@ -379,7 +388,7 @@ void launch_level0_h(const rgcn_csr* c, bool weighted, const __half* x, const fl
 
 int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, const float* x, int64_t d,
                      float* agg, void* workspace, size_t workspace_bytes, void* stream_, bool half_in = false,
-                     const rgcn_slab_job* tail = nullptr) {
+                     const rgcn_slab_job* tail = nullptr, float* amax = nullptr) {
   if (!g || !agg || d <= 0 || (d & 3) || (half_in && (d & 7))) return RGCN_ERR_ARG;
   const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
   if (!c->rowptr) return RGCN_ERR_ARG;   // direction not built
@@ -392,6 +401,8 @@ int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, c
     return RGCN_ERR_WORKSPACE;
   hipStream_t stream = (hipStream_t)stream_;
   float* partial = (float*)workspace;
+  unsigned* amax_out = reinterpret_cast<unsigned*>(amax);
+  if (amax && half_in) return RGCN_ERR_UNSUPPORTED;            // the fp16-table gather feeds the fp16 transform: no scale needed
   const float* cnt = c->weighted ? nullptr : c->val;
   const bool weighted = c->weighted;
   const int q = (int)(d / 4);
@@ -420,13 +431,13 @@ int aggregate_levels(const rgcn_graph* g, int transposed, int first, int last, c
       else launch_level0_h<64>(c, weighted, xh, cnt, agg, partial, (int)d, stream);
       continue;
     }
-    if (q <= 1) launch_level<1>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
-    else if (q <= 2) launch_level<2>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
-    else if (q <= 4) launch_level<4>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
-    else if (q <= 8) launch_level<8>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
-    else if (q <= 16) launch_level<16>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
-    else if (q <= 32) launch_level<32>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
-    else launch_level<64>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0);
+    if (q <= 1) launch_level<1>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0, amax_out);
+    else if (q <= 2) launch_level<2>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0, amax_out);
+    else if (q <= 4) launch_level<4>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0, amax_out);
+    else if (q <= 8) launch_level<8>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0, amax_out);
+    else if (q <= 16) launch_level<16>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0, amax_out);
+    else if (q <= 32) launch_level<32>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0, amax_out);
+    else launch_level<64>(c, l, weighted, x, cnt, agg, partial, (int)d, stream, t0, amax_out);
   }
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
@@ -463,6 +474,22 @@ int rgcn_aggregate_and_reduce(const rgcn_graph* g, int transposed, const float* 
   return aggregate_levels(g, transposed, 0, c->num_levels, x, d, agg, workspace, workspace_bytes, stream, false, job);
 }
 
+int rgcn_aggregate_amax(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
+                        void* workspace, size_t workspace_bytes, const rgcn_slab_job* job, float* amax, void* stream) {
+  if (!g || !amax) return RGCN_ERR_ARG;
+  if (job && job->slab &&
+      (!job->grad_weight || job->splits <= 0 || job->Kc <= 0 || job->N <= 0 || (job->N & 3)))
+    return RGCN_ERR_ARG;
+  const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
+  if (job && job->slab && c->rowptr && c->n_key == 0) {      // nothing to gather: the reduction still has to run
+    k_slab_reduce<<<(unsigned)rgcn_slab_reduce_blocks(*job), 256, 0, (hipStream_t)stream>>>(*job);
+    RGCN_HIP_TRY(hipGetLastError());
+    return RGCN_OK;
+  }
+  return aggregate_levels(g, transposed, 0, c->num_levels, x, d, agg, workspace, workspace_bytes, stream, false, job,
+                          amax);
+}
+
 int rgcn_aggregate_f16(const rgcn_graph* g, int transposed, const void* x_f16, int64_t d, float* agg,
                        void* workspace, size_t workspace_bytes, void* stream) {
   if (!g) return RGCN_ERR_ARG;
@@ -471,8 +498,9 @@ int rgcn_aggregate_f16(const rgcn_graph* g, int transposed, const void* x_f16, i
 }
 
 int rgcn_aggregate_level(const rgcn_graph* g, int transposed, int level, const float* x, int64_t d, float* agg,
-                         void* workspace, size_t workspace_bytes, void* stream) {
-  return aggregate_levels(g, transposed, level, level + 1, x, d, agg, workspace, workspace_bytes, stream);
+                         void* workspace, size_t workspace_bytes, float* amax, void* stream) {
+  return aggregate_levels(g, transposed, level, level + 1, x, d, agg, workspace, workspace_bytes, stream, false,
+                          nullptr, amax);
 }
 
 }  // extern "C"

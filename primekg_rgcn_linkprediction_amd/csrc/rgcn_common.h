@@ -63,6 +63,9 @@ struct rgcn_csr {
   // disease row): the transforms skip the all-zero k/m-tiles these bits expose.  NULL if R > 32.
   uint32_t* tile_mask = nullptr;
   int64_t num_row_tiles = 0;
+  // max over segments of sum of |weights| (weighted mode; 1 in mean mode): |agg row| <= weight_bound * max |x|.
+  // The split-precision transforms scale the aggregate operand by this bound instead of scanning it.
+  float weight_bound = 1.f;
 };
 
 struct rgcn_graph {
@@ -71,3 +74,61 @@ struct rgcn_graph {
 };
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// "amax" buffers: max |tensor| as the split-precision transforms need it (rgcn_transform_split.hip).
+// A buffer is RGCN_AMAX_FLOATS floats, zeroed by the caller; its VALUE is the maximum over all entries.
+// Producers publish wave maxima into one of RGCN_AMAX_SLOTS slots, 128 bytes apart (own cache lines, so
+// the integer atomics of a launch spread over L2 channels instead of queueing on one address - 50k
+// same-address atomics cost a gather launch 10x its time), chosen by workgroup id, and only when the
+// wave's maximum exceeds what the slot already shows (a stale read is safe: slots only grow).  The bit
+// pattern of a non-negative float orders like an unsigned int and a maximum does not depend on arrival
+// order, so the value is run-to-run deterministic.
+// ---------------------------------------------------------------------------------------------
+constexpr int RGCN_AMAX_SLOTS = 64, RGCN_AMAX_STRIDE = 32;
+// Heads = the entries that are ever written: RGCN_AMAX_HEADS of them, RGCN_AMAX_HEAD_STRIDE floats apart.  The
+// scan kernel (rgcn_absmax) writes one partial maximum per workgroup into every head without atomics; the
+// publishing slots above are every fourth head.  A buffer's value is the maximum over its heads.
+constexpr int RGCN_AMAX_HEADS = 256, RGCN_AMAX_HEAD_STRIDE = 8;
+static_assert(RGCN_AMAX_SLOTS * RGCN_AMAX_STRIDE == RGCN_AMAX_FLOATS, "amax buffer layout (include/rgcn_hip.h)");
+static_assert(RGCN_AMAX_HEADS * RGCN_AMAX_HEAD_STRIDE == RGCN_AMAX_FLOATS && RGCN_AMAX_STRIDE % RGCN_AMAX_HEAD_STRIDE == 0,
+              "amax buffer layout");
+
+#if defined(__HIPCC__)
+extern "C" __device__ unsigned __ockl_wfred_max_u32(unsigned);
+// called by any subset of a wave's lanes (the reduction runs over the active ones)
+// `seen`: what the slot showed when the wave started (rgcn_amax_peek) - read early so that the tail of a
+// wave does not wait for a dependent load; a stale value only costs an atomic that changes nothing
+__device__ inline unsigned rgcn_amax_peek(const unsigned* __restrict__ amax) {
+  return amax ? amax[(blockIdx.x & (RGCN_AMAX_SLOTS - 1)) * RGCN_AMAX_STRIDE] : 0u;
+}
+__device__ inline void rgcn_amax_publish(unsigned* __restrict__ amax, float lane_max, unsigned seen = 0u) {
+  const unsigned m = __ockl_wfred_max_u32(__float_as_uint(lane_max));
+  if (m <= seen) return;
+  unsigned* slot = amax + (blockIdx.x & (RGCN_AMAX_SLOTS - 1)) * RGCN_AMAX_STRIDE;
+  const unsigned long long act = __ballot(1);
+  if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicMax(slot, m);
+}
+// the buffer's value, by every lane of a wave: four independent loads per lane (only the heads are ever written)
+__device__ inline float rgcn_amax_value(const float* __restrict__ amax, int lane) {
+  float v[RGCN_AMAX_HEADS / 64];
+#pragma unroll
+  for (int j = 0; j < RGCN_AMAX_HEADS / 64; ++j) v[j] = amax[(lane + 64 * j) * RGCN_AMAX_HEAD_STRIDE];
+  float m = v[0];
+#pragma unroll
+  for (int j = 1; j < RGCN_AMAX_HEADS / 64; ++j) m = fmaxf(m, v[j]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return m;
+}
+// max of `count` <= 256 contiguous partials, by every lane of a wave: four independent loads per lane
+__device__ inline float rgcn_partials_max(const float* __restrict__ p, int count, int lane) {
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (lane + 64 * j < count) ? p[lane + 64 * j] : 0.f;
+  float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return m;
+}
+#endif

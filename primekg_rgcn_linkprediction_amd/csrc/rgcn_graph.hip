@@ -8,6 +8,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <new>
 #include <vector>
 
@@ -289,6 +290,19 @@ int plan_structure(rgcn_csr* c, int64_t R, hipStream_t stream) {
     RGCN_HIP_TRY(hipMemcpy(c->tile_mask, mask.data(), mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
   TRY_PLAN(build_plan(rp, NR, c));
+  c->weight_bound = 1.f;
+  if (c->weighted && NR > 0 && rp[(size_t)NR] > 0) {      // one-time, on the host: max over segments of sum |w|
+    std::vector<float> w((size_t)rp[(size_t)NR]);
+    RGCN_HIP_TRY(hipMemcpyAsync(w.data(), c->val, w.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+    RGCN_HIP_TRY(hipStreamSynchronize(stream));
+    double best = 0.0;
+    for (int64_t s = 0; s < NR; ++s) {
+      double sum = 0.0;
+      for (int32_t e = rp[(size_t)s]; e < rp[(size_t)s + 1]; ++e) sum += std::fabs((double)w[(size_t)e]);
+      best = std::max(best, sum);
+    }
+    c->weight_bound = (float)(best * (1.0 + 1e-6)) + 1e-30f;
+  }
   const int64_t n0 = c->num_items[0];
   if (n0 > 0) {                                  // heads of the level-0 items (col / val are final by now)
     RGCN_HIP_TRY(hipMalloc((void**)&c->head_col, (size_t)n0 * RGCN_HEAD * sizeof(int32_t)));
@@ -505,6 +519,12 @@ void rgcn_graph_destroy(rgcn_graph* g) {
 int64_t rgcn_graph_num_edges(const rgcn_graph* g) { return g ? g->E : -1; }
 int64_t rgcn_graph_num_nodes(const rgcn_graph* g) { return g ? g->N : -1; }
 int64_t rgcn_graph_num_relations(const rgcn_graph* g) { return g ? g->R : -1; }
+float rgcn_graph_weight_bound(const rgcn_graph* g, int transposed) {
+  if (!g) return 0.f;
+  const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
+  return c->rowptr ? c->weight_bound : 0.f;
+}
+
 int rgcn_graph_num_levels(const rgcn_graph* g, int transposed) {
   return g ? g->dir[transposed ? 1 : 0].num_levels : -1;
 }

@@ -100,56 +100,49 @@ __global__ __launch_bounds__(kThreads) void k_absmax(const absmax_job J, float* 
   }
 }
 
-// max of `count` partials (count <= kMaxSlots), by every lane of a wave (no LDS)
-__device__ inline float fold_slots(const float* __restrict__ slots, int count, int lane) {
-  float m = 0.f;
-  for (int i = lane; i < count; i += 64) m = fmaxf(m, slots[i]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  return m;
-}
-
-// A tensor maximum as the kernels receive it: `slots` holds `count` non-negative partials.
+// A tensor maximum as the kernels receive it: an amax buffer (count == 0: its value is the maximum of
+// its slot heads) or `count` <= kMaxSlots contiguous partials of k_absmax.
 struct amax_ref {
   const float* slots;
   int count;
 };
+__device__ inline float amax_of(const amax_ref& r, int lane) {
+  return r.count == 0 ? rgcn_amax_value(r.slots, lane) : rgcn_partials_max(r.slots, r.count, lane);
+}
 
 // ---------------------------------------------------------------------------------------
-// B operand, split once per call:  Bt[n][k] = B[k][n] * 2^eb  ->  Bh[n*K + k] (hi), Bl[n*K + k] (lo)
-//   B_KN  (forward):     B[k][n] = k < K1 ? W[k*N + n] : Rt[(k-K1)*N + n]
-//   B_BLK (input grad):  B[k][n], k = r*dk + o:  W[(r*N + n)*dk + o];  k >= K1: Rt[n*dk + (k-K1)]
-// scale_out[0] = 2^-eb for the consumer's epilogue.
+// The weights of one layer, split ONCE per step for both transforms that multiply by them:
+//   forward image   Bt_f[n][k], n < d_out, k = r*d_in + i  (k >= R*d_in: root):   W[r][i][n] * 2^eb
+//   backward image  Bt_b[n][k], n < d_in,  k = r*d_out + o (k >= R*d_out: root):  W[r][n][o] * 2^eb
+// each as a hi and a lo fp16 image, k contiguous.  One scale 2^eb for all of [W ; root] (its maximum
+// comes as k_absmax partials); scale_out[0] = 2^-eb for the consumers' epilogues.
 // ---------------------------------------------------------------------------------------
-template <int BMODE>
 __global__ __launch_bounds__(kThreads) void k_pack_split(const float* __restrict__ W, const float* __restrict__ Rt,
-                                                         int K1, int K2, int N, int dk, amax_ref wmax, amax_ref rmax,
-                                                         __half* __restrict__ Bh, __half* __restrict__ Bl,
+                                                         int R, int d_in, int d_out, amax_ref wmax, amax_ref rmax,
+                                                         __half* __restrict__ Bh_f, __half* __restrict__ Bl_f,
+                                                         __half* __restrict__ Bh_b, __half* __restrict__ Bl_b,
                                                          float* __restrict__ scale_out) {
   const int lane = threadIdx.x & 63;
-  float m = fold_slots(wmax.slots, wmax.count, lane);
-  if (rmax.slots) m = fmaxf(m, fold_slots(rmax.slots, rmax.count, lane));
+  float m = amax_of(wmax, lane);
+  if (rmax.slots) m = fmaxf(m, amax_of(rmax, lane));
   const int eb = scale_exponent(m);
   const float sb = pow2f(eb);
   if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = pow2f(-eb);
-  const int K = K1 + K2;
-  const int64_t total = (int64_t)K * N;
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
-    int k, n;
-    float v;
-    if (BMODE == B_KN) {                       // n fastest: coalesced reads
-      k = (int)(i / N);
-      n = (int)(i % N);
-      v = k < K1 ? W[(size_t)k * N + n] : Rt[(size_t)(k - K1) * N + n];
-    } else {                                   // k fastest: coalesced reads and writes
-      n = (int)(i / K);
-      k = (int)(i % K);
-      v = k < K1 ? W[((size_t)(k / dk) * N + n) * dk + (k % dk)] : Rt[(size_t)n * dk + (k - K1)];
-    }
-    v *= sb;
+  const int blocks = R + (Rt ? 1 : 0);
+  const int Kf = blocks * d_in, Kb = blocks * d_out;
+  const int64_t total = (int64_t)blocks * d_in * d_out;
+  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
+    const int o = (int)(e % d_out);                       // o fastest: coalesced reads of W[r][i][:]
+    const int i = (int)((e / d_out) % d_in);
+    const int r = (int)(e / ((int64_t)d_out * d_in));
+    const float v = (r < R ? W[e] : Rt[(size_t)i * d_out + o]) * sb;
     const __half h = __float2half_rn(v);
-    Bh[(size_t)n * K + k] = h;
-    Bl[(size_t)n * K + k] = __float2half_rn(v - __half2float(h));
+    const __half l = __float2half_rn(v - __half2float(h));
+    const size_t f = (size_t)o * Kf + (size_t)r * d_in + i, bk = (size_t)i * Kb + (size_t)r * d_out + o;
+    Bh_f[f] = h;
+    Bl_f[f] = l;
+    Bh_b[bk] = h;
+    Bl_b[bk] = l;
   }
 }
 
@@ -165,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_split(const float* __restr
                                                             const __half* __restrict__ Bh,
                                                             const __half* __restrict__ Bl,
                                                             const float* __restrict__ b_inv_scale,
-                                                            amax_ref amax1, amax_ref amax2,
+                                                            amax_ref amax1, float a1_mul, amax_ref amax2,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ mask, float* __restrict__ C,
                                                             int M, int N, const uint32_t* __restrict__ tile_mask,
@@ -238,11 +231,15 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_split(const float* __restr
   if (kt_a < K) stage(kt_a, 0);
   if (kt_b < K) stage(kt_b, 1);
 
-  // scale of the A operand, from the maxima its producers left (behind the first DMA issue)
-  float am = fold_slots(amax1.slots, amax1.count, lane);
-  if (amax2.slots) am = fmaxf(am, fold_slots(amax2.slots, amax2.count, lane));
-  const int ea = scale_exponent(am);
-  const float sa = pow2f(ea);
+  const unsigned seen = rgcn_amax_peek(amax_out);
+  // scales of the two A operands (behind the first DMA issue).  A1 (the aggregate) is scaled by a BOUND,
+  // a1_mul * max |table it was gathered from| (a mean of rows cannot exceed the table's maximum; a weighted
+  // sum not the structure's largest sum of weights times it), A2 by its own maximum; the accumulator is
+  // carried over from the one scale to the other where the k loop passes from A1 to A2 (powers of two: exact).
+  const int ea1 = scale_exponent(amax_of(amax1, lane) * a1_mul);
+  const int ea2 = amax2.slots ? scale_exponent(amax_of(amax2, lane)) : ea1;
+  const float sa1 = pow2f(ea1), sa2 = pow2f(ea2);
+  bool in_a1 = true;
 
   // byte addresses inside one buffer for the two 16-k steps of a k-tile
   const int arow = wm * 32 + li;
@@ -277,8 +274,18 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_split(const float* __restr
     }
     kt_c = kt_b < K ? next_kt(kt_b) : K;         // the DMA issue covers the LDS latency of the reads above
     if (kt_c < K) stage(kt_c, (t + 2) % NBUF);
+    const bool tile_in_a1 = kt_a < K1;
     kt_a = kt_b;
     kt_b = kt_c;
+    if (in_a1 && !tile_in_a1) {                  // first k-tile of A2: re-express the sums so far in A2's scale
+      in_a1 = false;
+      const float down = pow2f(-ea1);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = acc[b][r] * down * sa2;
+    }
+    const float sa = tile_in_a1 ? sa1 : sa2;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       // step 0 may start once its own 2 + 2 TN reads are back (the last 2 + 2 TN issued are step 1's)
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_split(const float* __restr
   }
 
   // C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const float ia = pow2f(-ea), ib = b_inv_scale[0];            // two exact power-of-two factors
+  const float ia = pow2f(in_a1 ? -ea1 : -ea2), ib = b_inv_scale[0];   // two exact power-of-two factors
   float cmax = 0.f;
   if (m0 + BM <= M && n0 + BN <= N) {            // interior tile: straight-line stores (see k_gemm_nt_dma)
     float bv[TN];
@@ -364,16 +371,15 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_split(const float* __restr
       }
     }
   }
-  if (amax_out) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o));
-    if (lane == 0 && cmax > 0.f) atomicMax(amax_out, __float_as_uint(cmax));
-  }
+  if (amax_out) rgcn_amax_publish(amax_out, cmax, seen);
 }
 
-// one float = max |x| (atomic max on the bit pattern of non-negative floats: order-free, deterministic);
-// *out must be 0 before the launch (rgcn_absmax clears it)
-__global__ __launch_bounds__(kThreads) void k_absmax_one(const float* __restrict__ p, int64_t n, unsigned* __restrict__ out) {
+// max |x| into the amax buffer `out`, no atomics and no prior clearing: workgroup b of RGCN_AMAX_HEADS
+// writes its partial maximum to head b; it also ZEROES head b of `zero_count` further amax buffers that
+// start at `zero` (the buffers the kernels of this pass will publish into).
+__global__ __launch_bounds__(kThreads) void k_absmax_init(const float* __restrict__ p, int64_t n, float* __restrict__ out,
+                                                          float* __restrict__ zero, int zero_count) {
+  __shared__ float red[kThreads / 64];
   float m = 0.f;
   const int64_t n4 = n >> 2;
   const float4* p4 = reinterpret_cast<const float4*>(p);
@@ -384,7 +390,10 @@ __global__ __launch_bounds__(kThreads) void k_absmax_one(const float* __restrict
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(p[n4 * 4 + threadIdx.x]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x * RGCN_AMAX_HEAD_STRIDE] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if ((int)threadIdx.x < zero_count) zero[(size_t)threadIdx.x * RGCN_AMAX_FLOATS + blockIdx.x * RGCN_AMAX_HEAD_STRIDE] = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
                                                                 const float* __restrict__ A2, int K2,
                                                                 const float* __restrict__ G, int M, int N,
                                                                 int n_tiles, int rows_per_split,
-                                                                amax_ref amax1, amax_ref amax2, amax_ref gmax,
+                                                                amax_ref amax1, float a1_mul, amax_ref amax2, amax_ref gmax,
                                                                 float* __restrict__ slab,
                                                                 float* __restrict__ bias_part,
                                                                 const uint32_t* __restrict__ tile_mask, int kseg) {
@@ -475,10 +484,10 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
   if (mt_b < mend) stage(mt_b, 1);
   if (NBUF == 4 && mt_c < mend) stage(mt_c, 2);
 
-  // operand scales (behind the first DMA issue)
-  float am = fold_slots(amax1.slots, amax1.count, lane);
-  if (amax2.slots) am = fmaxf(am, fold_slots(amax2.slots, amax2.count, lane));
-  const int ea = scale_exponent(am), eg = scale_exponent(fold_slots(gmax.slots, gmax.count, lane));
+  // operand scales (behind the first DMA issue): this workgroup's kc tile lies in ONE of the two A operands -
+  // the aggregate (scaled by the bound a1_mul * max |its table|, see k_gemm_nt_split) or x (its own maximum)
+  const float am = (first || !amax2.slots) ? amax_of(amax1, lane) * a1_mul : amax_of(amax2, lane);
+  const int ea = scale_exponent(am), eg = scale_exponent(amax_of(gmax, lane));
   const float sa = pow2f(ea), sg = pow2f(eg);
 
   // this wave group's 16 rows of an m-tile: lane (li, lh) feeds rows 16 grp + 8 lh + j, j = 0..7
@@ -602,48 +611,76 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
 // ---------------------------------------------------------------------------------------
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-// workspace of one NT call: [ Bh ][ Bl ][ slots: kAbsmaxSegs * kMaxSlots floats ][ b_inv_scale ]
-size_t nt_workspace_bytes(int64_t K, int64_t N) {
-  return 2 * align256((size_t)K * N * sizeof(__half)) + kAbsmaxSegs * kMaxSlots * sizeof(float) + 256;
+// The split weights of one layer (rgcn_weights_split_pack):
+//   [ Bh_f ][ Bl_f ][ Bh_b ][ Bl_b ]  four fp16 images of (R+1)*d_in*d_out elements each (256-aligned)
+//   [ inv_scale: 64 floats ][ partial maxima of W and root: 2 * kMaxSlots floats ]
+struct PackedWeights {
+  __half *Bh_f, *Bl_f, *Bh_b, *Bl_b;
+  float *inv_scale, *partials;
+};
+size_t packed_bytes(int64_t R, int64_t d_in, int64_t d_out) {
+  return 4 * align256((size_t)(R + 1) * d_in * d_out * sizeof(__half)) + 256 + 2 * kMaxSlots * sizeof(float);
+}
+PackedWeights packed_view(void* base, int64_t R, int64_t d_in, int64_t d_out) {
+  const size_t img = align256((size_t)(R + 1) * d_in * d_out * sizeof(__half));
+  char* p = (char*)base;
+  PackedWeights v;
+  v.Bh_f = (__half*)p;
+  v.Bl_f = (__half*)(p + img);
+  v.Bh_b = (__half*)(p + 2 * img);
+  v.Bl_b = (__half*)(p + 3 * img);
+  v.inv_scale = (float*)(p + 4 * img);
+  v.partials = v.inv_scale + 64;
+  return v;
 }
 
-template <int BMODE>
-int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const float* W, const float* Rt, int dk,
-                    const float* bias, const float* mask, int epi, float* C, int M, int N, const uint32_t* tile_mask,
-                    int kseg, const float* a1_amax, const float* a2_amax, float* c_amax, void* workspace,
-                    size_t workspace_bytes, hipStream_t stream) {
+int pack_weights(const float* weight, const float* root, int64_t R, int64_t d_in, int64_t d_out, void* packed,
+                 hipStream_t stream) {
+  const PackedWeights v = packed_view(packed, R, d_in, d_out);
+  const int64_t wn = R * d_in * d_out, rn = root ? d_in * d_out : 0;
+  absmax_job J{};
+  J.p[0] = weight; J.n[0] = wn;
+  J.p[1] = root;   J.n[1] = rn;
+  const int blocks = (int)std::min<int64_t>(kMaxSlots, std::max<int64_t>(16, (wn + rn) / 8192));
+  k_absmax<<<blocks, kThreads, 0, stream>>>(J, v.partials);
+  const int pack_blocks = (int)std::min<int64_t>(512, ceil_div64(wn + rn, kThreads));
+  k_pack_split<<<pack_blocks, kThreads, 0, stream>>>(weight, root, (int)R, (int)d_in, (int)d_out,
+                                                     amax_ref{v.partials, blocks},
+                                                     amax_ref{root ? v.partials + kMaxSlots : nullptr, blocks}, v.Bh_f,
+                                                     v.Bl_f, v.Bh_b, v.Bl_b, v.inv_scale);
+  RGCN_HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+// workspace of one NT call: the split weights (when the caller brings none) + partial maxima of an A
+// operand nobody left a maximum for
+size_t nt_workspace_bytes(int64_t R, int64_t d_in, int64_t d_out) {
+  return packed_bytes(R, d_in, d_out) + 2 * kMaxSlots * sizeof(float);
+}
+
+int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __half* Bh, const __half* Bl,
+                    const float* b_inv, const float* bias, const float* mask, int epi, float* C, int M, int N,
+                    const uint32_t* tile_mask, int kseg, const float* a1_amax, float a1_mul, const float* a2_amax,
+                    float* c_amax, float* scan_slots, hipStream_t stream) {
   const int K = K1 + K2;
   if (K1 % BK || K2 % BK || K <= 0) return RGCN_ERR_UNSUPPORTED;
-  if (!workspace || workspace_bytes < nt_workspace_bytes(K, N)) return RGCN_ERR_WORKSPACE;
-  const size_t img = align256((size_t)K * N * sizeof(__half));
-  __half* Bh = (__half*)workspace;
-  __half* Bl = (__half*)((char*)workspace + img);
-  float* slots = (float*)((char*)workspace + 2 * img);
-  float* b_inv = slots + kAbsmaxSegs * kMaxSlots;
-
-  // maxima: the weights always; an A operand only when its producer handed none in
-  absmax_job J{};
-  J.p[0] = K1 ? W : nullptr;  J.n[0] = (int64_t)K1 * N;
-  J.p[1] = K2 ? Rt : nullptr; J.n[1] = (int64_t)K2 * N;
+  // maxima of the A operands: from their producers, or scanned here (one launch over what is missing)
   const bool scan1 = K1 && !a1_amax, scan2 = K2 && !a2_amax;
-  if (scan1) { J.p[2] = A1; J.n[2] = (int64_t)M * K1; }
-  if (scan2) { J.p[3] = A2; J.n[3] = (int64_t)M * K2; }
-  const int blocks = (scan1 || scan2) ? kMaxSlots : 16;
-  k_absmax<<<blocks, kThreads, 0, stream>>>(J, slots);
-  const amax_ref wref{K1 ? slots : nullptr, blocks}, rref{K2 ? slots + kMaxSlots : nullptr, blocks};
-  amax_ref r1 = !K1 ? amax_ref{nullptr, 0} : (scan1 ? amax_ref{slots + 2 * kMaxSlots, blocks} : amax_ref{a1_amax, 1});
-  amax_ref r2 = !K2 ? amax_ref{nullptr, 0} : (scan2 ? amax_ref{slots + 3 * kMaxSlots, blocks} : amax_ref{a2_amax, 1});
-  if (!r1.slots) { r1 = r2; r2 = amax_ref{nullptr, 0}; }       // the kernels read r1 unconditionally
-  const int pack_blocks = (int)std::min<int64_t>(512, ceil_div64((int64_t)K * N, kThreads));
-  if (wref.slots)
-    k_pack_split<BMODE><<<pack_blocks, kThreads, 0, stream>>>(W, Rt, K1, K2, N, dk, wref, rref, Bh, Bl, b_inv);
-  else
-    k_pack_split<BMODE><<<pack_blocks, kThreads, 0, stream>>>(W, Rt, K1, K2, N, dk, rref, amax_ref{nullptr, 0}, Bh, Bl, b_inv);
+  if (scan1 || scan2) {
+    absmax_job J{};
+    if (scan1) { J.p[0] = A1; J.n[0] = (int64_t)M * K1; }
+    if (scan2) { J.p[1] = A2; J.n[1] = (int64_t)M * K2; }
+    k_absmax<<<kMaxSlots, kThreads, 0, stream>>>(J, scan_slots);
+  }
+  amax_ref r1 = !K1 ? amax_ref{nullptr, 0} : (scan1 ? amax_ref{scan_slots, kMaxSlots} : amax_ref{a1_amax, 0});
+  amax_ref r2 = !K2 ? amax_ref{nullptr, 0} : (scan2 ? amax_ref{scan_slots + kMaxSlots, kMaxSlots} : amax_ref{a2_amax, 0});
+  if (scan1 || !(a1_mul > 0.f)) a1_mul = 1.f;                  // a scanned maximum is exact
+  if (!r1.slots) { r1 = r2; r2 = amax_ref{nullptr, 0}; a1_mul = 1.f; }   // the kernels read r1 unconditionally
   if (kseg <= 0 || kseg % BK != 0) tile_mask = nullptr;
   unsigned* amax_out = reinterpret_cast<unsigned*>(c_amax);
 #define RGCN_NT_SPLIT(TN_, EPI_)                                                                                   \
-  k_gemm_nt_split<TN_, EPI_><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, r2, bias, mask, C, M, \
-                                                            N, tile_mask, kseg, amax_out)
+  k_gemm_nt_split<TN_, EPI_><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, \
+                                                            C, M, N, tile_mask, kseg, amax_out)
   if (N <= 64) {
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
     if (epi == EPI_RELU) RGCN_NT_SPLIT(1, EPI_RELU);
@@ -694,52 +731,79 @@ size_t tn_workspace_bytes(int64_t N, int64_t R, int64_t d_in, int64_t d_out) {
 
 extern "C" {
 
-int rgcn_absmax(const float* x, int64_t n, float* out, void* stream_) {
-  if (n < 0 || !out || (n > 0 && !x)) return RGCN_ERR_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
-  RGCN_HIP_TRY(hipMemsetAsync(out, 0, sizeof(float), stream));
-  if (n == 0) return RGCN_OK;
-  const int blocks = (int)std::min<int64_t>(512, std::max<int64_t>(1, ceil_div64(n / 4, kThreads * 4)));
-  k_absmax_one<<<blocks, kThreads, 0, stream>>>(x, n, reinterpret_cast<unsigned*>(out));
+int rgcn_absmax(const float* x, int64_t n, float* out, float* zero_buffers, int zero_count, void* stream_) {
+  if (n < 0 || !out || (n > 0 && !x) || zero_count < 0 || zero_count > kThreads || (zero_count > 0 && !zero_buffers))
+    return RGCN_ERR_ARG;
+  k_absmax_init<<<RGCN_AMAX_HEADS, kThreads, 0, (hipStream_t)stream_>>>(x, n, out, zero_buffers, zero_count);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
 
+size_t rgcn_weights_split_bytes(int64_t R, int64_t d_in, int64_t d_out) {
+  if (R <= 0 || d_in <= 0 || d_out <= 0) return 0;
+  return packed_bytes(R, d_in, d_out);
+}
+
+int rgcn_weights_split_pack(const float* weight, const float* root, int64_t R, int64_t d_in, int64_t d_out,
+                            void* packed, size_t packed_bytes_, void* stream_) {
+  if (R <= 0 || d_in <= 0 || d_out <= 0 || !weight) return RGCN_ERR_ARG;
+  if ((R + 1) * d_in > (1 << 24) || (R + 1) * d_out > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
+  if (!packed || packed_bytes_ < packed_bytes(R, d_in, d_out)) return RGCN_ERR_WORKSPACE;
+  return pack_weights(weight, root, R, d_in, d_out, packed, (hipStream_t)stream_);
+}
+
 size_t rgcn_transform_split_workspace_bytes(int64_t R, int64_t d_in, int64_t d_out) {
   if (R <= 0 || d_in <= 0 || d_out <= 0) return 0;
-  return nt_workspace_bytes((R + 1) * d_in, d_out);           // fwd: K = (R+1) d_in, N = d_out; bwd_input: swapped
+  return nt_workspace_bytes(R, d_in, d_out);
 }
 
 int rgcn_transform_fwd_split(const float* agg, const float* x, const float* weight, const float* root,
-                             const float* bias, int relu, const uint32_t* tile_mask, int64_t N, int64_t R,
-                             int64_t d_in, int64_t d_out, const float* agg_amax, const float* x_amax,
-                             float* out, float* out_amax, void* workspace, size_t workspace_bytes, void* stream_) {
+                             const void* packed, const float* bias, int relu, const uint32_t* tile_mask, int64_t N,
+                             int64_t R, int64_t d_in, int64_t d_out, const float* agg_amax, float agg_amax_mul,
+                             const float* x_amax, float* out, float* out_amax, void* workspace,
+                             size_t workspace_bytes, void* stream_) {
   if (bad_dims(N, R, d_in, d_out) || !out) return RGCN_ERR_ARG;
   if (N == 0) return RGCN_OK;
   if (!agg || !x || !weight) return RGCN_ERR_ARG;
   if (d_in % BK) return RGCN_ERR_UNSUPPORTED;
   if (N > INT32_MAX / 2 || (R + 1) * d_in > (1 << 24) || d_out > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < nt_workspace_bytes(R, d_in, d_out)) return RGCN_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!packed) {                                            // nobody split the weights for this step yet
+    const int rc = pack_weights(weight, root, R, d_in, d_out, workspace, stream);
+    if (rc != RGCN_OK) return rc;
+    packed = workspace;
+  }
+  const PackedWeights v = packed_view(const_cast<void*>(packed), R, d_in, d_out);
+  float* scan = (float*)((char*)workspace + packed_bytes(R, d_in, d_out));
   const int K1 = (int)(R * d_in), K2 = root ? (int)d_in : 0;
-  return launch_nt_split<B_KN>(agg, K1, x, K2, weight, root, 0, bias, nullptr, relu ? EPI_RELU : EPI_NONE, out, (int)N,
-                               (int)d_out, tile_mask, (int)d_in, agg_amax, x_amax, out_amax, workspace, workspace_bytes,
-                               (hipStream_t)stream_);
+  return launch_nt_split(agg, K1, x, K2, v.Bh_f, v.Bl_f, v.inv_scale, bias, nullptr, relu ? EPI_RELU : EPI_NONE, out,
+                         (int)N, (int)d_out, tile_mask, (int)d_in, agg_amax, agg_amax_mul, x_amax, out_amax, scan, stream);
 }
 
 int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const float* weight, const float* root,
-                                   const float* relu_mask, const uint32_t* tile_mask, int64_t N, int64_t R,
-                                   int64_t d_in, int64_t d_out, const float* gagg_amax, const float* g_amax,
-                                   float* grad_x, float* grad_x_amax, void* workspace, size_t workspace_bytes,
-                                   void* stream_) {
+                                   const void* packed, const float* relu_mask, const uint32_t* tile_mask, int64_t N,
+                                   int64_t R, int64_t d_in, int64_t d_out, const float* gagg_amax,
+                                   float gagg_amax_mul, const float* g_amax, float* grad_x, float* grad_x_amax,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
   if (bad_dims(N, R, d_in, d_out) || !grad_x) return RGCN_ERR_ARG;
   if (N == 0) return RGCN_OK;
   if (!gagg || !g || !weight) return RGCN_ERR_ARG;
   if (d_out % BK) return RGCN_ERR_UNSUPPORTED;
   if (N > INT32_MAX / 2 || (R + 1) * d_out > (1 << 24) || d_in > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < nt_workspace_bytes(R, d_in, d_out)) return RGCN_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!packed) {
+    const int rc = pack_weights(weight, root, R, d_in, d_out, workspace, stream);
+    if (rc != RGCN_OK) return rc;
+    packed = workspace;
+  }
+  const PackedWeights v = packed_view(const_cast<void*>(packed), R, d_in, d_out);
+  float* scan = (float*)((char*)workspace + packed_bytes(R, d_in, d_out));
   const int K1 = (int)(R * d_out), K2 = root ? (int)d_out : 0;
-  // workspace is sized by rgcn_transform_split_workspace_bytes(R, d_in, d_out): K*N is the same product
-  return launch_nt_split<B_BLK>(gagg, K1, g, K2, weight, root, (int)d_out, nullptr, relu_mask,
-                                relu_mask ? EPI_MASK : EPI_NONE, grad_x, (int)N, (int)d_in, tile_mask, (int)d_out,
-                                gagg_amax, g_amax, grad_x_amax, workspace, workspace_bytes, (hipStream_t)stream_);
+  return launch_nt_split(gagg, K1, g, K2, v.Bh_b, v.Bl_b, v.inv_scale, nullptr, relu_mask,
+                         relu_mask ? EPI_MASK : EPI_NONE, grad_x, (int)N, (int)d_in, tile_mask, (int)d_out, gagg_amax,
+                         gagg_amax_mul, g_amax, grad_x_amax, scan, stream);
 }
 
 size_t rgcn_transform_bwd_params_split_workspace_bytes(int64_t N, int64_t R, int64_t d_in, int64_t d_out) {
@@ -749,8 +813,8 @@ size_t rgcn_transform_bwd_params_split_workspace_bytes(int64_t N, int64_t R, int
 
 int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, const float* g,
                                           const uint32_t* tile_mask, int64_t N, int64_t R, int64_t d_in,
-                                          int64_t d_out, const float* agg_amax, const float* x_amax,
-                                          const float* g_amax, float* grad_weight, float* grad_root,
+                                          int64_t d_out, const float* agg_amax, float agg_amax_mul,
+                                          const float* x_amax, const float* g_amax, float* grad_weight, float* grad_root,
                                           float* grad_bias, void* workspace, size_t workspace_bytes, void* stream_,
                                           rgcn_slab_job* job) {
   if (!job) return RGCN_ERR_ARG;
@@ -780,19 +844,20 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
   if (scan2) { J.p[1] = x; J.n[1] = N * (int64_t)K2; }
   if (scang) { J.p[2] = g; J.n[2] = N * d_out; }
   if (scan1 || scan2 || scang) k_absmax<<<kMaxSlots, kThreads, 0, stream>>>(J, slots);
-  const amax_ref r1 = scan1 ? amax_ref{slots, kMaxSlots} : amax_ref{agg_amax, 1};
-  const amax_ref r2 = !K2 ? amax_ref{nullptr, 0} : (scan2 ? amax_ref{slots + kMaxSlots, kMaxSlots} : amax_ref{x_amax, 1});
-  const amax_ref rg = scang ? amax_ref{slots + 2 * kMaxSlots, kMaxSlots} : amax_ref{g_amax, 1};
+  const amax_ref r1 = scan1 ? amax_ref{slots, kMaxSlots} : amax_ref{agg_amax, 0};
+  const amax_ref r2 = !K2 ? amax_ref{nullptr, 0} : (scan2 ? amax_ref{slots + kMaxSlots, kMaxSlots} : amax_ref{x_amax, 0});
+  const amax_ref rg = scang ? amax_ref{slots + 2 * kMaxSlots, kMaxSlots} : amax_ref{g_amax, 0};
+  const float a1_mul = (scan1 || !(agg_amax_mul > 0.f)) ? 1.f : agg_amax_mul;
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
   const uint32_t* tmask = (d_in % 64 == 0) ? tile_mask : nullptr;
   const bool one_per_cu = (int64_t)grid.x * grid.y <= 320;
   float* bp = grad_bias ? bias_part : nullptr;
   if (one_per_cu)
     k_gemm_tn_split<4><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                          p.rows_per_split, r1, r2, rg, slab, bp, tmask, (int)d_in);
+                                                          p.rows_per_split, r1, a1_mul, r2, rg, slab, bp, tmask, (int)d_in);
   else
     k_gemm_tn_split<3><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                          p.rows_per_split, r1, r2, rg, slab, bp, tmask, (int)d_in);
+                                                          p.rows_per_split, r1, a1_mul, r2, rg, slab, bp, tmask, (int)d_in);
   RGCN_HIP_TRY(hipGetLastError());
   job->slab = slab;
   job->bias_part = bias_part;

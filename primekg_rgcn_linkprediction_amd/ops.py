@@ -73,6 +73,103 @@ def _need_gpu(name: str, t: torch.Tensor, dtype: torch.dtype) -> None:
         raise ValueError(f"{name} must be contiguous")
 
 
+# Arithmetic of the three dense transforms (rows A6 / A7).  "split" (default): fp32 values carried as
+# fp16 hi/lo pairs on the fp16 matrix cores, fp32 accumulate (csrc/rgcn_transform_split.hip; ~2^-22 per
+# product, inside the north star's 1e-5 gate on every config); "fp32": v_mfma_f32_32x32x2_f32, bit for
+# bit an fmaf chain.  Shapes the split kernels do not tile run the fp32 kernels either way.
+GEMM_PRECISION = os.environ.get("RGCN_GEMM_PRECISION", "split")
+if GEMM_PRECISION not in ("split", "fp32"):
+    raise ValueError(f"RGCN_GEMM_PRECISION must be 'split' or 'fp32', got {GEMM_PRECISION!r}")
+
+
+def _use_split(precision: Optional[str], k_dim: int, multiple: int) -> bool:
+    mode = GEMM_PRECISION if precision is None else precision
+    if mode not in ("split", "fp32"):
+        raise ValueError(f"precision must be 'split' or 'fp32', got {mode!r}")
+    return mode == "split" and k_dim % multiple == 0
+
+
+# An "amax buffer" (include/rgcn_hip.h, RGCN_AMAX_FLOATS): AMAX_FLOATS floats; its VALUE, max |tensor|, is the
+# maximum over its 256 heads (every 8th entry; the rest is never touched).  Producing kernels publish wave maxima
+# into 64 of the heads with an atomic max on the bit pattern (spread so the atomics of a launch do not queue on
+# one address), so the heads must be zero before a producer runs; ``absmax`` clears buffers on the side.
+AMAX_FLOATS = 2048
+AMAX_HEAD_STRIDE = 8
+
+
+def amax_buffer(device, count: int = 1) -> torch.Tensor:
+    """``count`` zeroed amax buffers as one ``[count, AMAX_FLOATS]`` tensor (one fill launch)"""
+    return torch.zeros(count, AMAX_FLOATS, dtype=torch.float32, device=device)
+
+
+def amax_value(buf: torch.Tensor) -> torch.Tensor:
+    """the number an amax buffer stands for (a 0-dim device tensor)"""
+    return buf.view(-1)[::AMAX_HEAD_STRIDE].max()
+
+
+def _check_amax(name: str, t: Optional[torch.Tensor], device) -> None:
+    if t is None:
+        return
+    _need_gpu(name, t, torch.float32)
+    if t.numel() != AMAX_FLOATS or t.device != device:
+        raise ValueError(f"{name} must be an amax buffer ({AMAX_FLOATS} floats) on {device}")
+
+
+def absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None, clear: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``max |x|`` as an amax buffer (``rgcn_absmax``; ``amax_value`` reads it): the operand scale of the
+    split-precision transforms for a tensor no kernel of this library produced (the embedding table,
+    the incoming gradient).  One launch, no atomics; ``clear`` (``[k, AMAX_FLOATS]``, contiguous): amax
+    buffers whose heads the same launch zeroes - the ones the kernels of the coming pass publish into."""
+    _need_gpu("x", x, torch.float32)
+    lib = _lib.load()
+    with _on(x.device):
+        if out is None:
+            out = torch.empty(AMAX_FLOATS, dtype=torch.float32, device=x.device)
+        _check_amax("out", out, x.device)
+        count = 0
+        if clear is not None:
+            _need_gpu("clear", clear, torch.float32)
+            if clear.numel() % AMAX_FLOATS or clear.device != x.device:
+                raise ValueError("clear must hold whole amax buffers on x's device")
+            count = clear.numel() // AMAX_FLOATS
+        rc = lib.rgcn_absmax(_ptr(x), x.numel(), _ptr(out), _ptr(clear), count, _stream())
+    _lib.check(rc, "rgcn_absmax")
+    return out
+
+
+class SplitWeights:
+    """``[W ; root]`` of one layer split into fp16 hi / lo images for the split-precision transforms
+    (``rgcn_weights_split_pack``): made once per step by ``split_weights`` and handed to
+    ``transform_fwd`` / ``transform_bwd_input`` as ``packed=`` so that neither splits them again."""
+
+    def __init__(self, buf: torch.Tensor, weight: torch.Tensor, root: Optional[torch.Tensor]):
+        self.buf, self.shape, self.has_root = buf, tuple(weight.shape), root is not None
+
+    def matches(self, weight: torch.Tensor, root: Optional[torch.Tensor]) -> bool:
+        return tuple(weight.shape) == self.shape and (root is not None) == self.has_root and weight.device == self.buf.device
+
+
+def split_weights(weight: torch.Tensor, root: Optional[torch.Tensor]) -> Optional[SplitWeights]:
+    """-> ``SplitWeights`` (None in fp32 mode or for widths the split kernels do not tile)"""
+    _need_gpu("weight", weight, torch.float32)
+    if weight.dim() != 3:
+        raise ValueError("weight must be [R, d_in, d_out]")
+    r, d_in, d_out = weight.shape
+    if GEMM_PRECISION != "split" or d_in % 32 or d_out % 32:
+        return None
+    if root is not None:
+        _need_gpu("root", root, torch.float32)
+        if tuple(root.shape) != (d_in, d_out):
+            raise ValueError(f"root must be [{d_in}, {d_out}]")
+    lib = _lib.load()
+    with _on(weight.device):
+        nbytes = lib.rgcn_weights_split_bytes(r, d_in, d_out)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        rc = lib.rgcn_weights_split_pack(_ptr(weight), _ptr(root), r, d_in, d_out, _ptr(buf), nbytes, _stream())
+    _lib.check(rc, "rgcn_weights_split_pack")
+    return SplitWeights(buf, weight, root)
+
+
 def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     if nbytes <= 0:
         return None
@@ -231,6 +328,16 @@ class BucketedGraph:
     def num_levels(self, transposed: bool) -> int:
         return _lib.load().rgcn_graph_num_levels(self.handle, int(transposed))
 
+    def weight_bound(self, transposed: bool) -> float:
+        """``|aggregate(x) row| <= weight_bound * max |x|``: 1 for the mean structure, the largest
+        per-segment sum of edge weights for a weighted one (memoised; fixed for the life of the handle)"""
+        handle = self.handle
+        cache = self.__dict__.setdefault("_wbound", {})
+        key = bool(transposed and not self.bipartite)
+        if key not in cache:
+            cache[key] = float(_lib.load().rgcn_graph_weight_bound(handle, int(key)))
+        return cache[key]
+
     def arrays(self, transposed: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         """Copies of (rowptr int32[N*R+1], col int32[E], perm int64[E], val float32) on the
         device: val = cnt[N*R] (forward) or w_t[E] (transposed).  For parity tests."""
@@ -359,6 +466,28 @@ def clear_graph_cache() -> None:
 # bench.py sets this to a list to collect (weighted, d, edges, segments, start_event, end_event) per
 # level-0 gather launch; None (the default) means one C call per aggregate, no events.
 GATHER_EVENTS = None
+# likewise for the dense transforms: (kind, M, K, N, precision, start_event, end_event) per call - the
+# bracket covers everything the call launches (split precision: operand scan, weight split, GEMM)
+GEMM_EVENTS = None
+
+
+class _GemmBracket:
+    """HIP events around one transform call on the launch stream, only while bench.py collects them"""
+
+    def __init__(self, kind: str, m: int, k: int, n: int, precision: str):
+        self.info = (kind, m, k, n, precision)
+
+    def __enter__(self):
+        if GEMM_EVENTS is not None:
+            self.beg, self.end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.beg.record()
+        return self
+
+    def __exit__(self, *exc):
+        if GEMM_EVENTS is not None and exc[0] is None:
+            self.end.record()
+            GEMM_EVENTS.append(self.info + (self.beg, self.end))
+        return False
 
 
 class PendingParamGrads:
@@ -384,12 +513,14 @@ class PendingParamGrads:
 
 
 def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
-              tail: Optional[PendingParamGrads] = None) -> torch.Tensor:
+              tail: Optional[PendingParamGrads] = None, amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``[N, R*d]``: per-(dst, rel) mean of source rows (``transposed=False``) or the
     1/cnt-weighted sum over out-edges per (src, rel) (``transposed=True``).  For a shard
     (``BucketedGraph.from_shard``) x holds the gathered rows of all ranks and the result has
     the rank's own rows.  ``x`` may be float16 (BASELINE configs[4]: fp16 feature table, half
-    the bytes per gathered row); sums and the result are fp32 either way."""
+    the bytes per gathered row); sums and the result are fp32 either way.  ``amax_out`` (a ZEROED amax
+    buffer, fp32 table only): receives ``max |result|``, the scale the split-precision
+    transforms need for this operand."""
     half_in = isinstance(x, torch.Tensor) and x.dtype == torch.float16
     _need_gpu("x", x, torch.float16 if half_in else torch.float32)
     if graph.bipartite and transposed:
@@ -401,6 +532,9 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
     d = x.size(1)
     if d % (8 if half_in else 4):
         raise ValueError(f"feature dim {d} must be a multiple of {8 if half_in else 4}")
+    _check_amax("amax_out", amax_out, x.device)
+    if amax_out is not None and half_in:
+        raise ValueError("amax_out goes with the fp32 gather (the fp16 path's transform needs no scale)")
     lib = _lib.load()
     with _on(x.device):
         out = torch.empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
@@ -411,6 +545,12 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
         if half_in:
             rc = lib.rgcn_aggregate_f16(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
                                         _stream())
+        elif GATHER_EVENTS is None and amax_out is not None:
+            job = tail.job if (tail is not None and not tail.done) else None
+            rc = lib.rgcn_aggregate_amax(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
+                                         ctypes.byref(job) if job is not None else None, _ptr(amax_out), _stream())
+            if rc == 0 and job is not None:
+                tail._launched()
         elif GATHER_EVENTS is None and tail is not None and not tail.done:
             rc = lib.rgcn_aggregate_and_reduce(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
                                                ctypes.byref(tail.job), _stream())
@@ -428,7 +568,7 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
                     beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     beg.record()
                 rc = rc or lib.rgcn_aggregate_level(graph.handle, int(transposed), level, _ptr(x), d,
-                                                    _ptr(out), _ptr(ws), nbytes, _stream())
+                                                    _ptr(out), _ptr(ws), nbytes, _ptr(amax_out), _stream())
                 if level == 0:
                     end.record()
                     weighted = bool(transposed) or (graph.bipartite and graph.weighted_shard)
@@ -475,7 +615,9 @@ def _mask_for(graph: Optional[BucketedGraph], transposed: bool, n: int, r: int) 
 
 
 def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
-                  graph: Optional[BucketedGraph] = None, half: bool = False) -> torch.Tensor:
+                  graph: Optional[BucketedGraph] = None, half: bool = False, amax=None,
+                  amax_out: Optional[torch.Tensor] = None, precision: Optional[str] = None,
+                  packed: Optional[SplitWeights] = None, amax_mul: float = 1.0) -> torch.Tensor:
     """``sum_r agg[:, r] @ weight[r] + x @ root + bias`` as one fp32-MFMA GEMM; ``relu``
     fuses the activation that follows conv1 (``rgcn.py:124``) into the epilogue.  ``graph``
     (the structure ``agg`` was aggregated over) lets the kernel skip the k-tiles of relations
@@ -483,29 +625,63 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
 
     ``half=True`` (BASELINE configs[4]): operands rounded to fp16, fp32 accumulate, on the fp16
     matrix cores (``rgcn_transform_fwd_f16``); widths the kernel does not take (d_in % 32) run the
-    fp32 GEMM instead - more precise, never less."""
+    fp32 GEMM instead - more precise, never less.
+
+    Split precision (``GEMM_PRECISION``): ``amax = (agg_amax, x_amax)`` are amax buffers
+    (``absmax``, a previous transform's ``amax_out``, ``aggregate(amax_out=)``); ``agg`` is scaled by
+    the bound ``amax_mul * value(agg_amax)`` - pass the buffer of the table ``agg`` was gathered from
+    and the structure's ``weight_bound`` (a mean of rows cannot exceed the table's maximum: 1) - and
+    ``x`` by its own maximum; a missing buffer is scanned here (one more pass over that operand).
+    ``amax_out`` (a ZEROED amax buffer): receives ``max |out|``."""
     n, r, d_in, d_out = _check_layer(agg, x, weight, root, bias)
     lib = _lib.load()
+    _check_amax("amax_out", amax_out, x.device)
+    if not half and _use_split(precision, d_in, 32) and n > 0:
+        a1, a2 = amax if amax is not None else (None, None)
+        _check_amax("agg_amax", a1, x.device)
+        _check_amax("x_amax", a2, x.device)
+        if packed is not None and not packed.matches(weight, root):
+            raise ValueError("packed does not belong to these weights")
+        with _on(x.device):
+            out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
+            nbytes = lib.rgcn_transform_split_workspace_bytes(r, d_in, d_out)
+            ws = _workspace(nbytes, x.device)
+            with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "split"):
+                rc = lib.rgcn_transform_fwd_split(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root),
+                                                  _ptr(packed.buf) if packed is not None else None, _ptr(bias),
+                                                  int(relu), _mask_for(graph, False, n, r), n, r, d_in, d_out,
+                                                  _ptr(a1), float(amax_mul), _ptr(a2), _ptr(out), _ptr(amax_out),
+                                                  _ptr(ws), nbytes, _stream())
+        _lib.check(rc, "rgcn_transform_fwd_split")
+        return out
     if half and d_in % 32 == 0:
         with _on(x.device):
             out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
             nbytes = lib.rgcn_transform_fwd_f16_workspace_bytes(r, d_in, d_out)
             ws = _workspace(nbytes, x.device)
-            rc = lib.rgcn_transform_fwd_f16(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu),
-                                            _mask_for(graph, False, n, r), n, r, d_in, d_out, _ptr(out), _ptr(ws),
-                                            nbytes, _stream())
+            with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "f16"):
+                rc = lib.rgcn_transform_fwd_f16(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu),
+                                                _mask_for(graph, False, n, r), n, r, d_in, d_out, _ptr(out), _ptr(ws),
+                                                nbytes, _stream())
         _lib.check(rc, "rgcn_transform_fwd_f16")
+        if amax_out is not None:
+            absmax(out, amax_out)
         return out
     with _on(x.device):
         out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
-        rc = lib.rgcn_transform_fwd(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu),
-                                    _mask_for(graph, False, n, r), n, r, d_in, d_out, _ptr(out), _stream())
+        with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "fp32"):
+            rc = lib.rgcn_transform_fwd(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu),
+                                        _mask_for(graph, False, n, r), n, r, d_in, d_out, _ptr(out), _stream())
     _lib.check(rc, "rgcn_transform_fwd")
+    if amax_out is not None:
+        absmax(out, amax_out)
     return out
 
 
 def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
-                        graph: Optional[BucketedGraph] = None) -> torch.Tensor:
+                        graph: Optional[BucketedGraph] = None, amax=None, amax_out: Optional[torch.Tensor] = None,
+                        precision: Optional[str] = None, packed: Optional[SplitWeights] = None,
+                        amax_mul: float = 1.0) -> torch.Tensor:
     """``grad_x = sum_r gagg[:, r] @ weight[r]^T + g @ root^T``; with ``relu_mask`` (the
     layer's input, when that input is the output of a fused-ReLU layer) the result is
     additionally multiplied by ``relu_mask > 0``."""
@@ -523,18 +699,44 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
         if tuple(relu_mask.shape) != (n, d_in):
             raise ValueError(f"relu_mask must be [{n}, {d_in}]")
     lib = _lib.load()
+    _check_amax("amax_out", amax_out, g.device)
+    if d_in % 4 or d_out % 4:
+        raise ValueError("in/out channels must be multiples of 4")
+    if _use_split(precision, d_out, 32) and n > 0:
+        a1, a2 = amax if amax is not None else (None, None)
+        _check_amax("gagg_amax", a1, g.device)
+        _check_amax("g_amax", a2, g.device)
+        if packed is not None and not packed.matches(weight, root):
+            raise ValueError("packed does not belong to these weights")
+        with _on(g.device):
+            gx = torch.empty(n, d_in, dtype=torch.float32, device=g.device)
+            nbytes = lib.rgcn_transform_split_workspace_bytes(r, d_in, d_out)
+            ws = _workspace(nbytes, g.device)
+            with _GemmBracket("bwd_input", n, (r + (root is not None)) * d_out, d_in, "split"):
+                rc = lib.rgcn_transform_bwd_input_split(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root),
+                                                        _ptr(packed.buf) if packed is not None else None,
+                                                        _ptr(relu_mask), _mask_for(graph, True, n, r), n, r, d_in,
+                                                        d_out, _ptr(a1), float(amax_mul), _ptr(a2), _ptr(gx),
+                                                        _ptr(amax_out), _ptr(ws), nbytes, _stream())
+        _lib.check(rc, "rgcn_transform_bwd_input_split")
+        return gx
     with _on(g.device):
         gx = torch.empty(n, d_in, dtype=torch.float32, device=g.device)
-        rc = lib.rgcn_transform_bwd_input(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root), _ptr(relu_mask),
-                                          _mask_for(graph, True, n, r), n, r, d_in, d_out, _ptr(gx), _stream())
+        with _GemmBracket("bwd_input", n, (r + (root is not None)) * d_out, d_in, "fp32"):
+            rc = lib.rgcn_transform_bwd_input(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root), _ptr(relu_mask),
+                                              _mask_for(graph, True, n, r), n, r, d_in, d_out, _ptr(gx), _stream())
     _lib.check(rc, "rgcn_transform_bwd_input")
+    if amax_out is not None:
+        absmax(gx, amax_out)
     return gx
 
 
 def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, want_bias: bool = True,
-                         graph: Optional[BucketedGraph] = None, defer: bool = False):
+                         graph: Optional[BucketedGraph] = None, defer: bool = False, amax=None,
+                         precision: Optional[str] = None, amax_mul: float = 1.0):
     """``(grad_weight[R, d_in, d_out], grad_root | None, grad_bias | None)``; with ``defer=True`` a
-    ``PendingParamGrads`` whose reduction the caller attaches to the next gather (or finishes)."""
+    ``PendingParamGrads`` whose reduction the caller attaches to the next gather (or finishes).
+    Split precision: ``amax = (agg_amax, x_amax, g_amax)``, any of them None (scanned here)."""
     _need_gpu("x", x, torch.float32)
     _need_gpu("agg", agg, torch.float32)
     _need_gpu("g", g, torch.float32)
@@ -548,13 +750,33 @@ def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, 
         gw = torch.empty(r, d_in, d_out, dtype=torch.float32, device=x.device)
         groot = torch.empty(d_in, d_out, dtype=torch.float32, device=x.device) if want_root else None
         gbias = torch.empty(d_out, dtype=torch.float32, device=x.device) if want_bias else None
+        if _use_split(precision, d_in, 64) and n > 0:
+            a1, a2, a3 = amax if amax is not None else (None, None, None)
+            for nm, t in (("agg_amax", a1), ("x_amax", a2), ("g_amax", a3)):
+                _check_amax(nm, t, x.device)
+            nbytes = lib.rgcn_transform_bwd_params_split_workspace_bytes(n, r, d_in, d_out)
+            ws = _workspace(nbytes, x.device)
+            job = _lib.SlabJob()
+            with _GemmBracket("bwd_params", (r + want_root) * d_in, n, d_out, "split"):
+                rc = lib.rgcn_transform_bwd_params_split_begin(_ptr(agg), _ptr(x), _ptr(g),
+                                                               _mask_for(graph, False, n, r), n, r, d_in, d_out,
+                                                               _ptr(a1), float(amax_mul), _ptr(a2), _ptr(a3), _ptr(gw), _ptr(groot),
+                                                               _ptr(gbias), _ptr(ws), nbytes, _stream(),
+                                                               ctypes.byref(job))
+            _lib.check(rc, "rgcn_transform_bwd_params_split_begin")
+            pending = PendingParamGrads((gw, groot, gbias), job, ws)
+            if defer:
+                return pending
+            pending.finish()
+            return gw, groot, gbias
         nbytes = lib.rgcn_transform_bwd_params_workspace_bytes(n, r, d_in, d_out)
         ws = _workspace(nbytes, x.device)
         if defer:
             job = _lib.SlabJob()
-            rc = lib.rgcn_transform_bwd_params_begin(_ptr(agg), _ptr(x), _ptr(g), _mask_for(graph, False, n, r), n, r,
-                                                     d_in, d_out, _ptr(gw), _ptr(groot), _ptr(gbias), _ptr(ws), nbytes,
-                                                     _stream(), ctypes.byref(job))
+            with _GemmBracket("bwd_params", (r + want_root) * d_in, n, d_out, "fp32"):
+                rc = lib.rgcn_transform_bwd_params_begin(_ptr(agg), _ptr(x), _ptr(g), _mask_for(graph, False, n, r), n,
+                                                         r, d_in, d_out, _ptr(gw), _ptr(groot), _ptr(gbias), _ptr(ws),
+                                                         nbytes, _stream(), ctypes.byref(job))
             _lib.check(rc, "rgcn_transform_bwd_params_begin")
             return PendingParamGrads((gw, groot, gbias), job, ws)
         rc = lib.rgcn_transform_bwd_params(_ptr(agg), _ptr(x), _ptr(g), _mask_for(graph, False, n, r), n, r, d_in,

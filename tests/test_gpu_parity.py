@@ -234,9 +234,12 @@ def test_aggregate_is_deterministic_and_exact_on_ones():
 
 
 # ------------------------------------------------------------------ transform (A6) and its grads
+@pytest.mark.parametrize("precision", ["fp32", "split"])
 @pytest.mark.parametrize("n,r,d_in,d_out", [(100, 3, 64, 128), (257, 1, 8, 4), (1000, 3, 64, 64),
                                             (513, 16, 32, 64), (300, 3, 128, 256), (129, 2, 20, 36)])
-def test_transform_kernels(n, r, d_in, d_out):
+def test_transform_kernels(n, r, d_in, d_out, precision):
+    """the three dense kernels by themselves against float64, in both arithmetics: the fp32 MFMA and the
+    split-precision fp16 MFMA (shapes its tiling does not take run the fp32 kernels: never less precise)"""
     dev = need_gpu()
     gen = torch.Generator().manual_seed(n + d_in)
     agg = torch.randn(n, r * d_in, generator=gen)
@@ -245,26 +248,104 @@ def test_transform_kernels(n, r, d_in, d_out):
     root = torch.randn(d_in, d_out, generator=gen) * 0.1
     bias = torch.randn(d_out, generator=gen)
     g = torch.randn(n, d_out, generator=gen)
+    kw = dict(precision=precision)
     want = (agg.double() @ w.double().view(r * d_in, d_out) + x.double() @ root.double() + bias.double())
-    out = ops.transform_fwd(agg.to(dev), x.to(dev), w.to(dev), root.to(dev), bias.to(dev))
+    out = ops.transform_fwd(agg.to(dev), x.to(dev), w.to(dev), root.to(dev), bias.to(dev), **kw)
     assert rel_err(out, want) <= 2e-6
-    out_nr = ops.transform_fwd(agg.to(dev), x.to(dev), w.to(dev), None, None)
+    out_nr = ops.transform_fwd(agg.to(dev), x.to(dev), w.to(dev), None, None, **kw)
     assert rel_err(out_nr, agg.double() @ w.double().view(r * d_in, d_out)) <= 2e-6
     # grad wrt input: gagg [n, r*d_out] plays agg's role
     gagg = torch.randn(n, r * d_out, generator=gen)
     want_gx = sum(gagg.double()[:, k * d_out:(k + 1) * d_out] @ w.double()[k].t() for k in range(r)) \
         + g.double() @ root.double().t()
-    gx = ops.transform_bwd_input(gagg.to(dev), g.to(dev), w.to(dev), root.to(dev))
+    gx = ops.transform_bwd_input(gagg.to(dev), g.to(dev), w.to(dev), root.to(dev), **kw)
     assert rel_err(gx, want_gx) <= 2e-6
     # grads wrt parameters
-    gw, groot, gbias = ops.transform_bwd_params(agg.to(dev), x.to(dev), g.to(dev), r)
+    gw, groot, gbias = ops.transform_bwd_params(agg.to(dev), x.to(dev), g.to(dev), r, **kw)
     assert rel_err(gw, (agg.double().t() @ g.double()).view(r, d_in, d_out)) <= 5e-6
     assert rel_err(groot, x.double().t() @ g.double()) <= 5e-6
     assert rel_err(gbias, g.double().sum(0)) <= 5e-6
     gw2, groot2, gbias2 = ops.transform_bwd_params(agg.to(dev), x.to(dev), g.to(dev), r, want_root=False,
-                                                   want_bias=False)
+                                                   want_bias=False, **kw)
     # (without a root the operand widths can select the other slab kernel, whose row order differs)
     assert groot2 is None and gbias2 is None and rel_err(gw2, gw.cpu()) <= 1e-6
+
+
+@pytest.mark.parametrize("a_scale,b_scale,g_scale", [(1e-6, 1.0, 1e-7), (3e4, 1e-3, 1e5), (1.0, 1e-9, 1e-12),
+                                                     (1e-20, 1e10, 1e15)])
+def test_split_precision_scales_with_the_operands(a_scale, b_scale, g_scale):
+    """split precision = fp16 hi/lo pairs under ONE power-of-two scale per operand tensor: operands far
+    outside fp16's range (gradients of a mean loss ~1e-7, un-normalised features ~1e4) must come through
+    with the same RELATIVE accuracy, hub-sized outliers and exact zeros included; the scales arrive either
+    from the producers (amax=) or from the call's own scan - same bits."""
+    dev = need_gpu()
+    n, r, d_in, d_out = 777, 3, 64, 128
+    gen = torch.Generator().manual_seed(11)
+    agg = torch.randn(n, r * d_in, generator=gen) * a_scale
+    agg[5] *= 300.0                                   # one hub-sized row sets the scale; the rest sit 2^8 below it
+    agg[:, d_in:2 * d_in] *= (torch.rand(n, 1, generator=gen) < 0.5)
+    x = torch.randn(n, d_in, generator=gen) * a_scale
+    w = torch.randn(r, d_in, d_out, generator=gen) * b_scale
+    root = torch.randn(d_in, d_out, generator=gen) * b_scale
+    g = torch.randn(n, d_out, generator=gen) * g_scale
+    gagg = torch.randn(n, r * d_out, generator=gen) * g_scale
+    A, X, W, Rt, G, GA = (t.to(dev) for t in (agg, x, w, root, g, gagg))
+    want = agg.double() @ w.double().view(-1, d_out) + x.double() @ root.double()
+    out = ops.transform_fwd(A, X, W, Rt, None, precision="split")
+    assert rel_err(out, want) <= 2e-6
+    a_amax, x_amax, g_amax, ga_amax = ops.absmax(A), ops.absmax(X), ops.absmax(G), ops.absmax(GA)
+    assert ops.amax_value(a_amax).item() == agg.abs().max().item() and ops.amax_value(x_amax).item() == x.abs().max().item()
+    o_amax = ops.amax_buffer(dev)[0]
+    out2 = ops.transform_fwd(A, X, W, Rt, None, precision="split", amax=(a_amax, x_amax), amax_out=o_amax)
+    assert torch.equal(out, out2) and ops.amax_value(o_amax).item() == out.abs().max().item()
+    want_gx = sum(gagg.double()[:, k * d_out:(k + 1) * d_out] @ w.double()[k].t() for k in range(r)) \
+        + g.double() @ root.double().t()
+    gx = ops.transform_bwd_input(GA, G, W, Rt, precision="split", amax=(ga_amax, g_amax))
+    assert rel_err(gx, want_gx) <= 2e-6
+    assert torch.equal(gx, ops.transform_bwd_input(GA, G, W, Rt, precision="split"))
+    gw, groot, gbias = ops.transform_bwd_params(A, X, G, r, precision="split", amax=(a_amax, x_amax, g_amax))
+    assert rel_err(gw, (agg.double().t() @ g.double()).view(r, d_in, d_out)) <= 5e-6
+    assert rel_err(groot, x.double().t() @ g.double()) <= 5e-6
+    assert rel_err(gbias, g.double().sum(0)) <= 5e-6
+    gw_b = ops.transform_bwd_params(A, X, G, r, precision="split")[0]
+    assert torch.equal(gw, gw_b)
+    # weights split once (ops.split_weights) = the per-call split, bit for bit; absmax clears buffers on the side
+    pk = ops.split_weights(W, Rt)
+    assert torch.equal(out, ops.transform_fwd(A, X, W, Rt, None, precision="split", packed=pk))
+    assert torch.equal(gx, ops.transform_bwd_input(GA, G, W, Rt, precision="split", packed=pk))
+    with pytest.raises(ValueError):
+        ops.transform_fwd(A, X, W, None, None, precision="split", packed=pk)
+    junk = torch.full((3, ops.AMAX_FLOATS), 7.0, device=dev)
+    ops.absmax(X, junk[0], clear=junk[1:])
+    assert ops.amax_value(junk[0]).item() == x.abs().max().item() and ops.amax_value(junk[1:]).item() == 0.0
+    # all-zero operands: scale 1, exact zeros out
+    z = ops.transform_fwd(torch.zeros_like(A), torch.zeros_like(X), W, Rt, None, precision="split")
+    assert float(z.abs().max()) == 0.0
+
+
+def test_gather_leaves_the_exact_maximum():
+    """aggregate(amax_out=): max |agg| (hub tails reduced in the upper levels included), both directions"""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=200000, seed=4)
+    g = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
+    x = torch.randn(n, 64, generator=torch.Generator().manual_seed(1)).to(dev) * 3e-4
+    for transposed in (False, True):
+        slot = ops.amax_buffer(dev)[0]
+        agg = ops.aggregate(g, x, transposed, amax_out=slot)
+        assert torch.equal(agg, ops.aggregate(g, x, transposed))
+        assert ops.amax_value(slot).item() == agg.abs().max().item() > 0
+    with pytest.raises(ValueError):
+        ops.aggregate(g, x.half(), amax_out=ops.amax_buffer(dev)[0])
+    # the bound the encoder uses instead (no pass over the aggregate, no atomics in the gather):
+    # |agg| <= weight_bound * max |x|, weight_bound = largest per-segment sum of edge weights (1 for the mean)
+    assert g.weight_bound(False) == 1.0
+    rowptr_t, _, _, w_t = (t.cpu() for t in g.arrays(True))
+    seg = torch.repeat_interleave(torch.arange(n * r), (rowptr_t[1:] - rowptr_t[:-1]).long())
+    sums = torch.zeros(n * r, dtype=torch.float64).index_add_(0, seg, w_t.double())
+    assert sums.max().item() <= g.weight_bound(True) <= sums.max().item() * (1 + 1e-5) + 1e-30
+    gagg = ops.aggregate(g, x, True)
+    assert gagg.abs().max().item() <= g.weight_bound(True) * x.abs().max().item()
+    assert ops.aggregate(g, x, False).abs().max().item() <= x.abs().max().item() * (1 + 1e-6)
 
 
 # ------------------------------------------------------------------ the layer against the goldens
@@ -464,16 +545,16 @@ def _encoder_vs_oracle(dev, ei, et, n, r, dims, num_bases=None, seed=0, fwd_atol
     for c in convs:
         c.bias.data.uniform_(-0.1, 0.1)
     cot = torch.randn(n, dims[2])
-    # oracle #1: fp32 loop path + autograd
     ref_p = [{k: v.detach().clone().requires_grad_(True) for k, v in c.named_parameters()} for c in convs]
-    e_ref = emb.clone().requires_grad_(True)
-    out_ref = O.encoder_ref(e_ref, ref_p[0], ref_p[1], ei, et)
-    (out_ref * cot).sum().backward()
     # HIP
     convs = [c.to(dev) for c in convs]
     eid, etd = ei.to(dev), et.to(dev)
     with torch.no_grad():
         mask = (convs[0](emb.to(dev), eid, etd, activation="relu") > 0).cpu()
+    # oracle #1: fp32 loop path + autograd (the device's ReLU decisions, like oracle #3 below)
+    e_ref = emb.clone().requires_grad_(True)
+    out_ref = O.encoder_ref(e_ref, ref_p[0], ref_p[1], ei, et, relu_mask=mask)
+    (out_ref * cot).sum().backward()
     # oracle #3: float64, explicit backward, the device's ReLU decisions
     p64 = [{k: v.detach() for k, v in rp.items()} for rp in ref_p]
     f64 = O.encoder_explicit_f64(emb, p64[0], p64[1], ei, et, cot, relu_mask=mask)
@@ -852,7 +933,7 @@ def test_c_abi_error_codes_with_real_handles():
     assert lib.rgcn_aggregate(g.handle, 0, P(x), 6, P(agg), P(ws), need, stream) == _lib.RGCN_ERR_ARG
     assert lib.rgcn_aggregate(g.handle, 0, None, d, P(agg), P(ws), need, stream) == _lib.RGCN_ERR_ARG
     assert lib.rgcn_aggregate_f16(g.handle, 0, P(x), 68, P(agg), P(ws), need * 2, stream) == _lib.RGCN_ERR_ARG   # d % 8
-    assert lib.rgcn_aggregate_level(g.handle, 0, 7, P(x), d, P(agg), P(ws), need, stream) == _lib.RGCN_ERR_ARG
+    assert lib.rgcn_aggregate_level(g.handle, 0, 7, P(x), d, P(agg), P(ws), need, None, stream) == _lib.RGCN_ERR_ARG
     assert lib.rgcn_aggregate(g.handle, 0, P(x), d, P(agg), P(ws), need, stream) == _lib.RGCN_OK
     torch.cuda.synchronize()
     assert_fwd(agg.view(50, -1), O.mean_aggregate_ref(x.cpu(), ei, torch.zeros(500, dtype=torch.int64), 2).view(50, -1))
