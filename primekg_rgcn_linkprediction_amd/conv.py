@@ -80,6 +80,10 @@ class _Scales:
         return self._buf[self._next - 1]
 
 
+import os as _os
+_TRANSFORM_FIRST_RATIO = float(_os.environ.get("RGCN_TRANSFORM_FIRST_RATIO", "4"))   # A/B switch, see _input_grad
+
+
 def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Optional[Tensor],
                 tail: Optional["ops.PendingParamGrads"] = None, g_amax: Optional[Tensor] = None,
                 scales: Optional[_Scales] = None, packed: Optional["ops.SplitWeights"] = None) -> Tensor:
@@ -95,7 +99,7 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
     ``T`` costs what the narrower gather saves (54 us either way), so that layer keeps the default."""
     r, d_in, d_out = weight.shape
     merged = (graph.merged_transposed()
-              if (d_out >= 4 * d_in and root is not None and not graph.bipartite) else None)
+              if (d_out >= _TRANSFORM_FIRST_RATIO * d_in and root is not None and not graph.bipartite) else None)
     # `tail`: the pending slab reduction of this layer's parameter gradients rides in the gather launch
     if merged is None:
         gagg = ops.aggregate(graph, g, transposed=True, tail=tail)       # autograd of A3 + A4 (fp32 grads)

@@ -23,6 +23,9 @@
 // k-tile, counted vmcnt, relation-occupancy skipping of all-zero k-tiles.  The A operand stays fp32
 // in memory and in LDS; a lane splits the 8 consecutive k it owns in registers.  The (small) B
 // operand is split once per call by k_pack_split into two k-contiguous fp16 images Bh / Bl [n][K].
+#include <algorithm>
+#include <cstdlib>
+
 #include <hip/hip_fp16.h>
 
 #include "rgcn_common.h"
@@ -114,35 +117,70 @@ __device__ inline float amax_of(const amax_ref& r, int lane) {
 // The weights of one layer, split ONCE per step for both transforms that multiply by them:
 //   forward image   Bt_f[n][k], n < d_out, k = r*d_in + i  (k >= R*d_in: root):   W[r][i][n] * 2^eb
 //   backward image  Bt_b[n][k], n < d_in,  k = r*d_out + o (k >= R*d_out: root):  W[r][n][o] * 2^eb
-// each as a hi and a lo fp16 image, k contiguous.  One scale 2^eb for all of [W ; root] (its maximum
-// comes as k_absmax partials); scale_out[0] = 2^-eb for the consumers' epilogues.
+// each as a hi and a lo fp16 image, k contiguous.  One scale 2^eb for all of [W ; root]: every workgroup
+// scans the (small, L2-resident) weights for their maximum itself - a second launch for it would cost more
+// than the redundant reads; scale_out[0] = 2^-eb for the consumers' epilogues.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_pack_split(const float* __restrict__ W, const float* __restrict__ Rt,
-                                                         int R, int d_in, int d_out, amax_ref wmax, amax_ref rmax,
-                                                         __half* __restrict__ Bh_f, __half* __restrict__ Bl_f,
-                                                         __half* __restrict__ Bh_b, __half* __restrict__ Bl_b,
-                                                         float* __restrict__ scale_out) {
+constexpr int kPackThreads = 1024;
+__global__ __launch_bounds__(kPackThreads) void k_pack_split(const float* __restrict__ W, const float* __restrict__ Rt,
+                                                             int R, int d_in, int d_out,
+                                                             __half* __restrict__ Bh_f, __half* __restrict__ Bl_f,
+                                                             __half* __restrict__ Bh_b, __half* __restrict__ Bl_b,
+                                                             float* __restrict__ scale_out) {
+  __shared__ float red[kPackThreads / 64];
   const int lane = threadIdx.x & 63;
-  float m = amax_of(wmax, lane);
-  if (rmax.slots) m = fmaxf(m, amax_of(rmax, lane));
+  const int64_t wn4 = (int64_t)R * d_in * d_out / 4, rn4 = Rt ? (int64_t)d_in * d_out / 4 : 0;   // d_out % 4 == 0
+  float m = 0.f;
+  auto scan = [&](const float* __restrict__ p, int64_t n4) {     // 8 independent loads per thread and round
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 8 * kPackThreads) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = i0 + (int64_t)u * kPackThreads;
+        v[u] = i < n4 ? p4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
+  };
+  scan(W, wn4);
+  if (Rt) scan(Rt, rn4);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = red[lane & (kPackThreads / 64 - 1)];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   const int eb = scale_exponent(m);
   const float sb = pow2f(eb);
   if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = pow2f(-eb);
   const int blocks = R + (Rt ? 1 : 0);
   const int Kf = blocks * d_in, Kb = blocks * d_out;
   const int64_t total = (int64_t)blocks * d_in * d_out;
-  for (int64_t e = (int64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kThreads) {
-    const int o = (int)(e % d_out);                       // o fastest: coalesced reads of W[r][i][:]
+  // two passes so that the STORES of each image are contiguous (2-byte stores a whole row apart cost this
+  // launch twice its time); the strided side is a 4-byte read of L2-resident weights
+  for (int64_t e = (int64_t)blockIdx.x * kPackThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kPackThreads) {
+    const int o = (int)(e % d_out);                       // o fastest: the backward image's k
     const int i = (int)((e / d_out) % d_in);
     const int r = (int)(e / ((int64_t)d_out * d_in));
     const float v = (r < R ? W[e] : Rt[(size_t)i * d_out + o]) * sb;
     const __half h = __float2half_rn(v);
-    const __half l = __float2half_rn(v - __half2float(h));
-    const size_t f = (size_t)o * Kf + (size_t)r * d_in + i, bk = (size_t)i * Kb + (size_t)r * d_out + o;
-    Bh_f[f] = h;
-    Bl_f[f] = l;
+    const size_t bk = (size_t)i * Kb + (size_t)r * d_out + o;
     Bh_b[bk] = h;
-    Bl_b[bk] = l;
+    Bl_b[bk] = __float2half_rn(v - __half2float(h));
+  }
+  for (int64_t e = (int64_t)blockIdx.x * kPackThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kPackThreads) {
+    const int i = (int)(e % d_in);                        // i fastest: the forward image's k
+    const int r = (int)((e / d_in) % blocks);
+    const int o = (int)(e / ((int64_t)d_in * blocks));
+    const float v = (r < R ? W[((size_t)r * d_in + i) * d_out + o] : Rt[(size_t)i * d_out + o]) * sb;
+    const __half h = __float2half_rn(v);
+    const size_t f = (size_t)o * Kf + (size_t)r * d_in + i;
+    Bh_f[f] = h;
+    Bl_f[f] = __float2half_rn(v - __half2float(h));
   }
 }
 
@@ -152,8 +190,12 @@ __global__ __launch_bounds__(kThreads) void k_pack_split(const float* __restrict
 // max |C| over this launch (atomic max on the bit pattern of non-negative floats: order-free, so
 // deterministic) - the scale the NEXT transform needs for this tensor.
 // ---------------------------------------------------------------------------------------
-template <int TN, int EPI>
-__global__ __launch_bounds__(kThreads) void k_gemm_nt_split(const float* __restrict__ A1, int K1,
+// WM = wave rows (32 output rows each) of the workgroup: 2 -> 64 x 64 TN tile, 256 threads, ring of 3, two
+// workgroups per CU; 4 -> 128 x 128 tile, 512 threads, ring of 4 (128 KB), one workgroup per CU.  These
+// transforms run at the rate their LDS-DMA bytes in flight allow (about 96 KB per CU either way), and B -
+// the same 256 KB for every workgroup - is two thirds of the 64-row tile's traffic: 128 rows halve it.
+template <int WM, int TN, int EPI>
+__global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restrict__ A1, int K1,
                                                             const float* __restrict__ A2, int K2,
                                                             const __half* __restrict__ Bh,
                                                             const __half* __restrict__ Bl,
@@ -163,11 +205,12 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_split(const float* __restr
                                                             const float* __restrict__ mask, float* __restrict__ C,
                                                             int M, int N, const uint32_t* __restrict__ tile_mask,
                                                             int kseg, unsigned* __restrict__ amax_out) {
-  constexpr int BM = 64, BN = 64 * TN, NBUF = 3;
+  constexpr int BM = 32 * WM, BN = 64 * TN, NBUF = WM == 2 ? 3 : 4, D = NBUF - 1;   // D k-tiles in flight
   constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + 2 * B_BYTES;
-  constexpr int A_PW = BM / 32;                  // A DMA instructions per wave and k-tile (8 rows of 128 B each)
-  constexpr int B_PW = BN / 64;                  // B DMA instructions per wave, k-tile and part (16 rows of 64 B each)
+  constexpr int A_PW = 2;                        // A DMA instructions per wave and k-tile (8 rows of 128 B each)
+  constexpr int B_PW = BN / (32 * WM);           // B DMA instructions per wave, k-tile and part (16 rows of 64 B each)
   constexpr int P = A_PW + 2 * B_PW;
+  static_assert(B_PW >= 1 && A_PW * 8 * 2 * WM == BM, "tile / wave layout");
   __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF_BYTES];   // the ONLY LDS object
 
   const int K = K1 + K2;
@@ -219,7 +262,10 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_split(const float* __restr
   unsigned rel_mask = 0xffffffffu;
   if (tile_mask) {
     const int t32 = m0 >> 5;
-    rel_mask = tile_mask[t32] | ((t32 + 1) * 32 < M ? tile_mask[t32 + 1] : 0u);
+    rel_mask = 0u;
+#pragma unroll
+    for (int q = 0; q < WM; ++q)
+      if ((t32 + q) * 32 < M) rel_mask |= tile_mask[t32 + q];
     rel_mask = __builtin_amdgcn_readfirstlane(rel_mask);
   }
   auto next_kt = [&](int kt) {                   // next k-tile whose relation some row of this tile has
@@ -227,9 +273,13 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_split(const float* __restr
     while (kt < K1 && !((rel_mask >> (kt / kseg)) & 1u)) kt = (kt / kseg + 1) * kseg;
     return min(kt, K);
   };
-  int kt_a = next_kt(-BK), kt_b = next_kt(kt_a), kt_c = K;
-  if (kt_a < K) stage(kt_a, 0);
-  if (kt_b < K) stage(kt_b, 1);
+  int ktq[D];                                    // the k-tile being multiplied and the D - 1 staged behind it
+  ktq[0] = next_kt(-BK);
+#pragma unroll
+  for (int j = 1; j < D; ++j) ktq[j] = ktq[j - 1] < K ? next_kt(ktq[j - 1]) : K;
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+    if (ktq[j] < K) stage(ktq[j], j);
 
   const unsigned seen = rgcn_amax_peek(amax_out);
   // scales of the two A operands (behind the first DMA issue).  A1 (the aggregate) is scaled by a BOUND,
@@ -256,8 +306,11 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_split(const float* __restr
     }
   }
 
-  for (int t = 0; kt_a < K; ++t) {
-    if (kt_b < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+  for (int t = 0; ktq[0] < K; ++t) {
+    // k-tile ktq[0] has landed for this wave (all but the DMAs of the tiles staged behind it are done), then for
+    // every wave; the barrier also says all waves are done reading the buffer the stage() below refills
+    if (D == 3 && ktq[D - 1] < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    else if (ktq[1] < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const unsigned buf = (unsigned)((t % NBUF) * BUF_BYTES);
@@ -272,11 +325,12 @@ __global__ __launch_bounds__(kThreads) void k_gemm_nt_split(const float* __restr
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl[s][b]) : "v"(b_addr[b][s] + buf), "n"(B_BYTES));
       }
     }
-    kt_c = kt_b < K ? next_kt(kt_b) : K;         // the DMA issue covers the LDS latency of the reads above
-    if (kt_c < K) stage(kt_c, (t + 2) % NBUF);
-    const bool tile_in_a1 = kt_a < K1;
-    kt_a = kt_b;
-    kt_b = kt_c;
+    const int kt_new = ktq[D - 1] < K ? next_kt(ktq[D - 1]) : K;   // the DMA issue covers the LDS latency of the reads above
+    if (kt_new < K) stage(kt_new, (t + D) % NBUF);
+    const bool tile_in_a1 = ktq[0] < K1;
+#pragma unroll
+    for (int j = 0; j + 1 < D; ++j) ktq[j] = ktq[j + 1];
+    ktq[D - 1] = kt_new;
     if (in_a1 && !tile_in_a1) {                  // first k-tile of A2: re-express the sums so far in A2's scale
       in_a1 = false;
       const float down = pow2f(-ea1);
@@ -398,14 +452,19 @@ __global__ __launch_bounds__(kThreads) void k_absmax_init(const float* __restric
 
 // ---------------------------------------------------------------------------------------
 // slab[s][kc][n] = sum over the node rows of split s of [A1 | A2][m][kc] * G[m][n], split precision.
-// Same tiling, ring, placement and relation-occupancy skipping as k_gemm_tn_dma<2, NBUF>
-// (rgcn_transform.hip): 64 kc x 128 n per workgroup, 32-row m-tiles global -> LDS by LDS-DMA (fp32),
-// eight waves in two groups that take rows 0-15 / 16-31 of every m-tile (one 16-deep MFMA step each).
-// The reduction index m is the slow index of both operands in memory, so a lane collects the 8 rows
-// it feeds to an MFMA with 8 ds_read_b32 (lanes along the contiguous dimension: conflict free) and
-// splits them in registers.  Slab values are unscaled here; their fixed-order sum is k_slab_reduce.
+// 128 kc x 128 n per 512-thread workgroup (eight waves, 4 kc x 2 n, a 32 x 64 block each), 32-row m-tiles
+// global -> LDS by LDS-DMA (fp32) through a ring of four buffers (three m-tiles = 96 KB in flight per CU:
+// this kernel streams both operands once and runs at the rate its bytes in flight allow), a split's tiles
+// placed on one XCD, relation-occupancy skipping of all-zero m-tiles.  Against the 64 kc tile of
+// k_gemm_tn_dma the G rows are re-read half as often (4 kc tiles at C2's K = 512, not 8).
+// The reduction index m is the slow index of both operands in memory, so a lane collects the 8 rows it
+// feeds to an MFMA with 8 ds_read_b32 (lanes along the contiguous dimension: conflict free) and splits
+// them in registers.  Every 64-column half of a kc tile lies in one A operand (K1 % 64 == 0), every wave's
+// 32 columns in one operand and one relation.  Slab values are unscaled here; their fixed-order sum is
+// k_slab_reduce.  The column sums of G (grad_bias partials) ride with the LAST kc tile (tile 0 without a
+// root), which therefore never skips an m-tile.
 // ---------------------------------------------------------------------------------------
-template <int NBUF>
+constexpr int TN_TKC = 128;
 __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __restrict__ A1, int K1,
                                                                 const float* __restrict__ A2, int K2,
                                                                 const float* __restrict__ G, int M, int N,
@@ -414,10 +473,10 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
                                                                 float* __restrict__ slab,
                                                                 float* __restrict__ bias_part,
                                                                 const uint32_t* __restrict__ tile_mask, int kseg) {
-  constexpr int TKC = 64, A_FLOATS = 32 * TKC, G_FLOATS = 32 * 128, BUF_FLOATS = A_FLOATS + G_FLOATS;
+  constexpr int TKC = TN_TKC, NBUF = 4, A_FLOATS = 32 * TKC, G_FLOATS = 32 * 128, BUF_FLOATS = A_FLOATS + G_FLOATS;
   constexpr int NT = 2 * kThreads;
-  constexpr int A_PW = 1, G_PW = 2, P = A_PW + G_PW;            // LDS-DMA instructions per wave and m-tile
-  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF_FLOATS];   // the ONLY LDS object
+  constexpr int A_PW = 2, G_PW = 2, P = A_PW + G_PW;            // LDS-DMA instructions per wave and m-tile (2 rows each)
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF_FLOATS];   // the ONLY LDS object (128 KB)
   const int Kc = K1 + K2;
   int bx = blockIdx.x, split = blockIdx.y;                     // a split's tiles on one XCD (see k_gemm_tn_dma)
   {
@@ -429,21 +488,24 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
       split = (q / gx) * 8 + (lin & 7);
     }
   }
-  const int kc0 = (bx / n_tiles) * TKC, n0 = (bx % n_tiles) * 128;
+  const int kc_tile = bx / n_tiles, kc_tiles = (int)gridDim.x / n_tiles;
+  const int kc0 = kc_tile * TKC, n0 = (bx % n_tiles) * 128;
   const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, w4 = wave & 3;
-  const int wk = w4 >> 1, wn = w4 & 1;
+  const int wk = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
-  const bool bias_block = (bias_part != nullptr) && (kc0 == (K2 > 0 ? K1 : 0));
+  const bool bias_block = (bias_part != nullptr) && (kc_tile == (K2 > 0 ? kc_tiles - 1 : 0));
   const bool do_bias = bias_block && (tid < 128);
-  const bool sparse = tile_mask != nullptr && kc0 < K1 && !bias_block;
-  const int rel = sparse ? kc0 / kseg : 0;
+  // m-tiles in which no row has ANY of this kc tile's relations are exact zeros in A1: skipped
+  unsigned rel_bits = 0u;
+  if (tile_mask != nullptr && !bias_block && kc0 + TKC <= K1)
+    for (int c = kc0; c < kc0 + TKC; c += kseg) rel_bits |= 1u << (c / kseg);
+  const bool sparse = rel_bits != 0u;
   auto next_mt = [&](int mt) {
     mt += 32;
-    while (sparse && mt < mend && !((tile_mask[mt >> 5] >> rel) & 1u)) mt += 32;
+    while (sparse && mt < mend && !(tile_mask[mt >> 5] & rel_bits)) mt += 32;
     return min(mt, mend + 31);
   };
 
@@ -454,49 +516,51 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
   float bsum = 0.f;
 
-  const bool first = kc0 < K1;
-  const float* abase = first ? A1 + kc0 : A2 + (kc0 - K1);
-  const int lda = first ? K1 : K2;
-  const int a_row = lane >> 4, a_col = (lane & 15) * 4;
-  const int g_row = lane >> 5, g_col = (lane & 31) * 4;
-  const bool g_ok = n0 + g_col < N;
+  // A and G: 32 lanes per row (2 rows per wave instruction); this lane's 4 columns of the kc tile lie in one operand
+  const int d_row = lane >> 5, d_col = (lane & 31) * 4;
+  const int acol = min(kc0 + d_col, Kc - 4);                   // columns past Kc re-read valid ones; never stored
+  const bool a_first = acol < K1;
+  const float* a_src = a_first ? A1 + acol : A2 + (acol - K1);
+  const int lda = a_first ? K1 : K2;
+  const bool g_ok = n0 + d_col < N;
 
   auto stage = [&](int mt, int buf) {
     float* sA = lds + buf * BUF_FLOATS;
     float* sG = sA + A_FLOATS;
 #pragma unroll
     for (int j = 0; j < A_PW; ++j) {
-      const int r0 = (wave * A_PW + j) * 4;
-      const int m = min(mt + r0 + a_row, M - 1);               // tail rows are zeroed in LDS below
-      glds16(abase + (size_t)m * lda + a_col, sA + r0 * TKC);
+      const int r0 = (wave * A_PW + j) * 2;
+      const int m = min(mt + r0 + d_row, M - 1);               // tail rows are zeroed in LDS below
+      glds16(a_src + (size_t)m * lda, sA + r0 * TKC);
     }
 #pragma unroll
     for (int j = 0; j < G_PW; ++j) {
       const int r0 = (wave * G_PW + j) * 2;
-      const int m = min(mt + r0 + g_row, M - 1);
-      if (g_ok) glds16(G + (size_t)m * N + n0 + g_col, sG + r0 * 128);
+      const int m = min(mt + r0 + d_row, M - 1);
+      if (g_ok) glds16(G + (size_t)m * N + n0 + d_col, sG + r0 * 128);
     }
   };
 
-  int mt_a = next_mt(mbeg - 32), mt_b = mt_a < mend ? next_mt(mt_a) : mend,
-      mt_c = (NBUF == 4 && mt_b < mend) ? next_mt(mt_b) : mend, mt_d = mend;
+  int mt_a = next_mt(mbeg - 32), mt_b = mt_a < mend ? next_mt(mt_a) : mend, mt_c = mt_b < mend ? next_mt(mt_b) : mend,
+      mt_d = mend;
   if (mt_a < mend) stage(mt_a, 0);
   if (mt_b < mend) stage(mt_b, 1);
-  if (NBUF == 4 && mt_c < mend) stage(mt_c, 2);
+  if (mt_c < mend) stage(mt_c, 2);
 
-  // operand scales (behind the first DMA issue): this workgroup's kc tile lies in ONE of the two A operands -
+  // operand scales (behind the first DMA issue): this WAVE's 32 kc columns lie in ONE of the two A operands -
   // the aggregate (scaled by the bound a1_mul * max |its table|, see k_gemm_nt_split) or x (its own maximum)
-  const float am = (first || !amax2.slots) ? amax_of(amax1, lane) * a1_mul : amax_of(amax2, lane);
+  const bool w_first = kc0 + wk * 32 < K1 || !amax2.slots;
+  const float am = w_first ? amax_of(amax1, lane) * a1_mul : amax_of(amax2, lane);
   const int ea = scale_exponent(am), eg = scale_exponent(amax_of(gmax, lane));
   const float sa = pow2f(ea), sg = pow2f(eg);
 
-  // this wave group's 16 rows of an m-tile: lane (li, lh) feeds rows 16 grp + 8 lh + j, j = 0..7
-  const unsigned a_addr = (unsigned)((16 * grp + 8 * lh) * TKC + wk * 32 + li) * 4u;
-  const unsigned g_addr = (unsigned)(A_FLOATS + (16 * grp + 8 * lh) * 128 + wn * 64 + li) * 4u;
+  // lane (li, lh) feeds rows 16 s + 8 lh + j (j = 0..7) of the m-tile to the MFMAs of 16-row step s
+  const unsigned a_addr = (unsigned)(8 * lh * TKC + wk * 32 + li) * 4u;
+  const unsigned g_addr = (unsigned)(A_FLOATS + 8 * lh * 128 + wn * 64 + li) * 4u;
 
   for (int t = 0; mt_a < mend; ++t) {
     const int mt = mt_a;
-    if (NBUF == 4 && mt_c < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    if (mt_c < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
     else if (mt_b < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -511,25 +575,22 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
       __builtin_amdgcn_s_barrier();
     }
     const unsigned buf_bytes = (unsigned)((t % NBUF) * BUF_FLOATS) * 4u;
-    float fa[8], fg[2][8];
+    float fa[2][8], fg[2][2][8];               // [16-row step][..]
+    auto read_step = [&](int s) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[j]) : "v"(a_addr + buf_bytes), "n"(j * TKC * 4));
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fg[0][j]) : "v"(g_addr + buf_bytes), "n"(j * 128 * 4));
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fg[1][j]) : "v"(g_addr + buf_bytes), "n"(j * 128 * 4 + 32 * 4));
-    }
-    if (NBUF == 4) {
-      mt_d = mt_c < mend ? next_mt(mt_c) : mend;
-      if (mt_d < mend) stage(mt_d, (t + 3) % NBUF);
-      mt_a = mt_b;
-      mt_b = mt_c;
-      mt_c = mt_d;
-    } else {
-      mt_d = mt_b < mend ? next_mt(mt_b) : mend;
-      if (mt_d < mend) stage(mt_d, (t + 2) % NBUF);
-      mt_a = mt_b;
-      mt_b = mt_d;
-    }
+      for (int j = 0; j < 8; ++j) {
+        const unsigned ao = (unsigned)((16 * s + j) * TKC * 4), go = (unsigned)((16 * s + j) * 128 * 4);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(fa[s][j]) : "v"(a_addr + buf_bytes + ao));
+        asm volatile("ds_read_b32 %0, %1" : "=v"(fg[s][0][j]) : "v"(g_addr + buf_bytes + go));
+        asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(fg[s][1][j]) : "v"(g_addr + buf_bytes + go));
+      }
+    };
+    read_step(0);
+    mt_d = mt_c < mend ? next_mt(mt_c) : mend;   // the DMA issue covers the LDS latency of the reads above
+    if (mt_d < mend) stage(mt_d, (t + 3) % NBUF);
+    mt_a = mt_b;
+    mt_b = mt_c;
+    mt_c = mt_d;
     if (do_bias) {                             // column sums of G, fp32, rows in order (as k_gemm_tn_dma)
       const unsigned baddr = (unsigned)((sG - lds) + tid) * 4u;
 #pragma unroll
@@ -547,51 +608,41 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
         asm volatile("" ::: "memory");
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), "+v"(fa[7]));
-    asm volatile("" : "+v"(fg[0][0]), "+v"(fg[0][1]), "+v"(fg[0][2]), "+v"(fg[0][3]), "+v"(fg[0][4]), "+v"(fg[0][5]),
-                      "+v"(fg[0][6]), "+v"(fg[0][7]));
-    asm volatile("" : "+v"(fg[1][0]), "+v"(fg[1][1]), "+v"(fg[1][2]), "+v"(fg[1][3]), "+v"(fg[1][4]), "+v"(fg[1][5]),
-                      "+v"(fg[1][6]), "+v"(fg[1][7]));
-    half8 ah, al, gh[2], gl[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = fa[j] * sa;
-      const _Float16 h = (_Float16)v;
-      ah[j] = h;
-      al[j] = (_Float16)(v - (float)h);
+    for (int s = 0; s < 2; ++s) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (s == 0) read_step(1);                  // the next step's operands travel behind this step's conversion and MFMAs
+      asm volatile("" : "+v"(fa[s][0]), "+v"(fa[s][1]), "+v"(fa[s][2]), "+v"(fa[s][3]), "+v"(fa[s][4]), "+v"(fa[s][5]),
+                        "+v"(fa[s][6]), "+v"(fa[s][7]));
+      asm volatile("" : "+v"(fg[s][0][0]), "+v"(fg[s][0][1]), "+v"(fg[s][0][2]), "+v"(fg[s][0][3]), "+v"(fg[s][0][4]),
+                        "+v"(fg[s][0][5]), "+v"(fg[s][0][6]), "+v"(fg[s][0][7]));
+      asm volatile("" : "+v"(fg[s][1][0]), "+v"(fg[s][1][1]), "+v"(fg[s][1][2]), "+v"(fg[s][1][3]), "+v"(fg[s][1][4]),
+                        "+v"(fg[s][1][5]), "+v"(fg[s][1][6]), "+v"(fg[s][1][7]));
+      half8 ah, al, gh[2], gl[2];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = fa[s][j] * sa;
+        const _Float16 h = (_Float16)v;
+        ah[j] = h;
+        al[j] = (_Float16)(v - (float)h);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const float u = fg[s][b][j] * sg;
+          const _Float16 hg = (_Float16)u;
+          gh[b][j] = hg;
+          gl[b][j] = (_Float16)(u - (float)hg);
+        }
+      }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const float u = fg[b][j] * sg;
-        const _Float16 hg = (_Float16)u;
-        gh[b][j] = hg;
-        gl[b][j] = (_Float16)(u - (float)hg);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh[b], acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl[b], acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh[b], acc[b], 0, 0, 0);
       }
-    }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh[b], acc[b], 0, 0, 0);
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl[b], acc[b], 0, 0, 0);
-      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh[b], acc[b], 0, 0, 0);
     }
   }
 
-  // the second wave group hands its accumulators over through LDS; the first adds them (fixed order)
-  __builtin_amdgcn_s_barrier();
-  float* xch = lds;
-  if (grp == 1) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xch[((w4 * 2 + b) * 16 + r) * 64 + lane] = acc[b][r];
-  }
-  __syncthreads();
-  if (grp == 1) return;
   const float ia = pow2f(-ea), ig = pow2f(-eg);
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = (acc[b][r] + xch[((w4 * 2 + b) * 16 + r) * 64 + lane]) * ia * ig;
   float* out = slab + (size_t)split * Kc * N;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
@@ -600,7 +651,7 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kc = kc0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (kc < Kc) out[(size_t)kc * N + nn] = acc[b][r];
+      if (kc < Kc) out[(size_t)kc * N + nn] = acc[b][r] * ia * ig;
     }
   }
   if (do_bias && n0 + tid < N) bias_part[(size_t)split * N + n0 + tid] = bsum;
@@ -638,18 +689,19 @@ int pack_weights(const float* weight, const float* root, int64_t R, int64_t d_in
                  hipStream_t stream) {
   const PackedWeights v = packed_view(packed, R, d_in, d_out);
   const int64_t wn = R * d_in * d_out, rn = root ? d_in * d_out : 0;
-  absmax_job J{};
-  J.p[0] = weight; J.n[0] = wn;
-  J.p[1] = root;   J.n[1] = rn;
-  const int blocks = (int)std::min<int64_t>(kMaxSlots, std::max<int64_t>(16, (wn + rn) / 8192));
-  k_absmax<<<blocks, kThreads, 0, stream>>>(J, v.partials);
-  const int pack_blocks = (int)std::min<int64_t>(512, ceil_div64(wn + rn, kThreads));
-  k_pack_split<<<pack_blocks, kThreads, 0, stream>>>(weight, root, (int)R, (int)d_in, (int)d_out,
-                                                     amax_ref{v.partials, blocks},
-                                                     amax_ref{root ? v.partials + kMaxSlots : nullptr, blocks}, v.Bh_f,
-                                                     v.Bl_f, v.Bh_b, v.Bl_b, v.inv_scale);
+  const int pack_blocks = (int)std::min<int64_t>(64, ceil_div64(wn + rn, kPackThreads));
+  k_pack_split<<<pack_blocks, kPackThreads, 0, stream>>>(weight, root, (int)R, (int)d_in, (int)d_out, v.Bh_f, v.Bl_f,
+                                                         v.Bh_b, v.Bl_b, v.inv_scale);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
+}
+
+int nt_rows() {                       // RGCN_NT_ROWS=128: the 128-row tile for N > 64 (A/B runs; measured no faster at C2)
+  static const int v = [] {
+    const char* e = getenv("RGCN_NT_ROWS");
+    return (e && atoi(e) == 128) ? 128 : 64;
+  }();
+  return v;
 }
 
 // workspace of one NT call: the split weights (when the caller brings none) + partial maxima of an A
@@ -678,19 +730,24 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
   if (!r1.slots) { r1 = r2; r2 = amax_ref{nullptr, 0}; a1_mul = 1.f; }   // the kernels read r1 unconditionally
   if (kseg <= 0 || kseg % BK != 0) tile_mask = nullptr;
   unsigned* amax_out = reinterpret_cast<unsigned*>(c_amax);
-#define RGCN_NT_SPLIT(TN_, EPI_)                                                                                   \
-  k_gemm_nt_split<TN_, EPI_><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, \
+#define RGCN_NT_SPLIT(WM_, TN_, EPI_)                                                                                   \
+  k_gemm_nt_split<WM_, TN_, EPI_><<<grid, 128 * WM_, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, \
                                                             C, M, N, tile_mask, kseg, amax_out)
   if (N <= 64) {
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
-    if (epi == EPI_RELU) RGCN_NT_SPLIT(1, EPI_RELU);
-    else if (epi == EPI_MASK) RGCN_NT_SPLIT(1, EPI_MASK);
-    else RGCN_NT_SPLIT(1, EPI_NONE);
-  } else {
+    if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 1, EPI_RELU);
+    else if (epi == EPI_MASK) RGCN_NT_SPLIT(2, 1, EPI_MASK);
+    else RGCN_NT_SPLIT(2, 1, EPI_NONE);
+  } else if (nt_rows() == 64) {
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 128));
-    if (epi == EPI_RELU) RGCN_NT_SPLIT(2, EPI_RELU);
-    else if (epi == EPI_MASK) RGCN_NT_SPLIT(2, EPI_MASK);
-    else RGCN_NT_SPLIT(2, EPI_NONE);
+    if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 2, EPI_RELU);
+    else if (epi == EPI_MASK) RGCN_NT_SPLIT(2, 2, EPI_MASK);
+    else RGCN_NT_SPLIT(2, 2, EPI_NONE);
+  } else {
+    dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)ceil_div64(N, 128));
+    if (epi == EPI_RELU) RGCN_NT_SPLIT(4, 2, EPI_RELU);
+    else if (epi == EPI_MASK) RGCN_NT_SPLIT(4, 2, EPI_MASK);
+    else RGCN_NT_SPLIT(4, 2, EPI_NONE);
   }
 #undef RGCN_NT_SPLIT
   RGCN_HIP_TRY(hipGetLastError());
@@ -703,14 +760,13 @@ bool bad_dims(int64_t n, int64_t r, int64_t di, int64_t dout) {
 
 struct TnPlan { int kc_tiles, n_tiles, splits, rows_per_split; };
 
-// same split of the node rows as plan_splits (rgcn_transform.hip): one workgroup per CU at C2's size,
-// two once every workgroup still has >= 2,048 rows to stream
+// one workgroup per CU (the 128 KB ring leaves no room for a second): as many row splits as that gives
 TnPlan tn_plan(int64_t M, int64_t Kc, int64_t N) {
   TnPlan p;
-  p.kc_tiles = (int)ceil_div64(Kc, 64);
+  p.kc_tiles = (int)ceil_div64(Kc, TN_TKC);
   p.n_tiles = (int)ceil_div64(N, 128);
   const int tiles = p.kc_tiles * p.n_tiles;
-  const int target = M / std::max(1, 512 / tiles) >= 2048 ? 512 : 256;
+  const int target = 256;
   int64_t s = std::max<int64_t>(1, target / tiles);
   s = std::min<int64_t>(s, std::max<int64_t>(1, ceil_div64(M, 128)));
   int64_t rps = ceil_div64(ceil_div64(M, s), 32) * 32;
@@ -827,7 +883,7 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
   hipStream_t stream = (hipStream_t)stream_;
   const int K1 = (int)(R * d_in), K2 = grad_root ? (int)d_in : 0, Kc = K1 + K2;
   TnPlan p = tn_plan(N, (R + 1) * d_in, d_out);
-  p.kc_tiles = (int)ceil_div64(Kc, 64);
+  p.kc_tiles = (int)ceil_div64(Kc, TN_TKC);
   float* slab = (float*)workspace;
   float* bias_part = slab + (size_t)p.splits * (R + 1) * d_in * d_out;
   float* slots = (float*)((char*)workspace +
@@ -850,14 +906,9 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
   const float a1_mul = (scan1 || !(agg_amax_mul > 0.f)) ? 1.f : agg_amax_mul;
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
   const uint32_t* tmask = (d_in % 64 == 0) ? tile_mask : nullptr;
-  const bool one_per_cu = (int64_t)grid.x * grid.y <= 320;
   float* bp = grad_bias ? bias_part : nullptr;
-  if (one_per_cu)
-    k_gemm_tn_split<4><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                          p.rows_per_split, r1, a1_mul, r2, rg, slab, bp, tmask, (int)d_in);
-  else
-    k_gemm_tn_split<3><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                          p.rows_per_split, r1, a1_mul, r2, rg, slab, bp, tmask, (int)d_in);
+  k_gemm_tn_split<<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles, p.rows_per_split,
+                                                     r1, a1_mul, r2, rg, slab, bp, tmask, (int)d_in);
   RGCN_HIP_TRY(hipGetLastError());
   job->slab = slab;
   job->bias_part = bias_part;
