@@ -302,31 +302,48 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
  * is the fused gather form, and (head_emb, NULL), (tail_emb, NULL), (rel_rows, NULL) is
  * LinkPredictor.forward on already-gathered rows (e.g. after relation dropout).
  * ---------------------------------------------------------------------------------- */
-int distmult_fwd(const float* h, const int64_t* h_idx, const float* t, const int64_t* t_idx,
-                 const float* r, const int64_t* r_idx, int64_t batch, int64_t d, float* scores,
-                 void* stream);
+int distmult_fwd(const float* h, const int64_t* h_idx, int64_t h_rows, const float* t, const int64_t* t_idx,
+                 int64_t t_rows, const float* r, const int64_t* r_idx, int64_t r_rows, int64_t batch, int64_t d,
+                 float* scores, void* stream);
+/* *_rows: number of rows of each operand matrix.  An index outside [0, rows) (torch indexing would raise a
+ * device-side assert, src/models/rgcn.py:325-326) is never dereferenced: it is clamped to row 0 and a sticky
+ * per-device flag is raised, which rgcn_index_error_fetch reads (synchronising `stream`) and clears. */
+int rgcn_index_error_fetch(int* host_flag, void* stream);
 
-/* Backward: grad_h[hi(b), :] += gs[b] * r * t, etc.  Rows reached through an index vector
- * are accumulated with fp32 atomics into buffers the caller has zeroed (duplicates in
- * head/tail are legal); a NULL index writes row b directly.  Any grad pointer may be NULL. */
-int distmult_bwd(const float* grad_scores, const float* h, const int64_t* h_idx, const float* t,
-                 const int64_t* t_idx, const float* r, const int64_t* r_idx, int64_t batch,
-                 int64_t d, float* grad_h, float* grad_t, float* grad_r, void* stream);
+/* Backward, DETERMINISTIC: grad_h[hi(b), :] = sum over the samples b' with hi(b') == hi(b) of gs[b'] * r * t,
+ * etc.  Duplicates in head / tail / relation ids are legal and frequent; no float atomics are used - every row
+ * is summed by one wave in sample order (embedding rows: the row's first occurrence adds all of them; the
+ * relation table: a fixed two-level tree over 256-sample segments), so two runs give the same bits.
+ * Rows reached through an index vector are WRITTEN (the caller zeroes the rows nobody touches); a NULL index
+ * writes row b directly.  grad_h == grad_t (head and tail gathered from one table) is one key space.  Any
+ * grad pointer may be NULL.  workspace: distmult_bwd_workspace_bytes(batch, d, r_idx ? r_rows : 0). */
+size_t distmult_bwd_workspace_bytes(int64_t batch, int64_t d, int64_t r_rows);
+int distmult_bwd(const float* grad_scores, const float* h, const int64_t* h_idx, int64_t h_rows, const float* t,
+                 const int64_t* t_idx, int64_t t_rows, const float* r, const int64_t* r_idx, int64_t r_rows,
+                 int64_t batch, int64_t d, float* grad_h, float* grad_t, float* grad_r, void* workspace,
+                 size_t workspace_bytes, void* stream);
 
 /* The head fused with the training loss (SURVEY section 8f "next" row 1; reference
  * `self.criterion = nn.BCEWithLogitsLoss()` src/train.py:139 applied to the scores at
  * train.py:300): scores[b] as above and loss[b] = binary_cross_entropy_with_logits(scores[b],
  * labels[b]) per sample (the caller takes the mean).  labels: float[batch] in {0, 1}. */
-int distmult_bce_fwd(const float* h, const int64_t* h_idx, const float* t, const int64_t* t_idx,
-                     const float* r, const int64_t* r_idx, const float* labels, int64_t batch,
-                     int64_t d, float* scores, float* loss, void* stream);
-/* Its backward in one launch: grad_scores[b] = grad_mean_loss[0] * (sigmoid(scores[b]) -
- * labels[b]) / batch (autograd of mean(loss)), fed straight into the accumulation of
- * distmult_bwd.  grad_mean_loss is a DEVICE pointer to one float (no host sync). */
-int distmult_bce_bwd(const float* grad_mean_loss, const float* scores, const float* labels,
-                     const float* h, const int64_t* h_idx, const float* t, const int64_t* t_idx,
-                     const float* r, const int64_t* r_idx, int64_t batch, int64_t d, float* grad_h,
-                     float* grad_t, float* grad_r, void* stream);
+int distmult_bce_fwd(const float* h, const int64_t* h_idx, int64_t h_rows, const float* t, const int64_t* t_idx,
+                     int64_t t_rows, const float* r, const int64_t* r_idx, int64_t r_rows, const float* labels,
+                     int64_t batch, int64_t d, float* scores, float* loss, void* stream);
+/* Its backward: grad_scores[b] = grad_mean_loss[0] * (sigmoid(scores[b]) - labels[b]) / batch (autograd of
+ * mean(loss)) formed inside the first kernel of distmult_bwd's deterministic accumulation.  grad_mean_loss is a
+ * DEVICE pointer to one float (no host sync).  Workspace as distmult_bwd. */
+int distmult_bce_bwd(const float* grad_mean_loss, const float* scores, const float* labels, const float* h,
+                     const int64_t* h_idx, int64_t h_rows, const float* t, const int64_t* t_idx, int64_t t_rows,
+                     const float* r, const int64_t* r_idx, int64_t r_rows, int64_t batch, int64_t d, float* grad_h,
+                     float* grad_t, float* grad_r, void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[num_rows, d] = sum over b of rows[b, :] into row idx[b], deterministic (the two-level tree above by
+ * itself): autograd of `table[idx]` for a table of few rows - LinkPredictor's relation embeddings when their
+ * gathered rows go through dropout (src/models/rgcn.py:207-208). */
+size_t rgcn_segment_sum_workspace_bytes(int64_t batch, int64_t d, int64_t num_rows);
+int rgcn_segment_sum(const float* rows, const int64_t* idx, int64_t batch, int64_t d, int64_t num_rows, float* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* Mini-batch assembly on the device (SURVEY section 8f "next" row 1): the batch slice of the
  * shuffled train columns (src/train.py:223-245), NegativeSampler.sample (train.py:59-97) and the

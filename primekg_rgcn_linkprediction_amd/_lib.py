@@ -78,15 +78,20 @@ PROTOTYPES = {
     "rgcn_transform_bwd_params_split_workspace_bytes": (c_size_t, [_I64, _I64, _I64, _I64]),
     "rgcn_transform_bwd_params_split_begin": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P, _P,
                                                       _P, _P, _P, c_size_t, _P, POINTER(SlabJob)]),
-    "distmult_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "distmult_fwd": (c_int, [_P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P]),
+    "rgcn_index_error_fetch": (c_int, [POINTER(c_int), _P]),
+    "distmult_bwd_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),
+    "rgcn_segment_sum_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),
+    "rgcn_segment_sum": (c_int, [_P, _P, _I64, _I64, _I64, _P, _P, c_size_t, _P]),
     "distmult_rank_tails": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P]),
-    "distmult_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "distmult_bwd": (c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, c_size_t, _P]),
     "rgcn_adam_workspace_bytes": (c_size_t, [c_int, _P]),
     "rgcn_adam_clip_step": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int,
                                     c_float, _P, _P, c_size_t, _P]),
     "rgcn_sample_batch": (c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
-    "distmult_bce_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
-    "distmult_bce_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "distmult_bce_fwd": (c_int, [_P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _P, _P, _P]),
+    "distmult_bce_bwd": (c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P,
+                                 c_size_t, _P]),
 }
 
 _lib = None

@@ -20,11 +20,27 @@ __device__ inline float bce_with_logits(float x, float y) {
   return (1.f - y) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));
 }
 
+// Sticky per-device flag: some kernel of this library met an index outside its table.  Indices are
+// clamped before they are used (nothing is ever dereferenced out of bounds) and the flag is raised;
+// rgcn_index_error_fetch reads and clears it (the reference's torch indexing raises a device-side assert
+// in the same situation, asynchronously; an error CODE would need a host sync per call).
+__device__ int g_index_error = 0;
+
+__device__ inline int64_t checked_row(const int64_t* __restrict__ idx, int64_t b, int64_t rows) {
+  int64_t v = idx ? idx[b] : b;
+  if ((uint64_t)v >= (uint64_t)rows) {
+    g_index_error = 1;
+    v = 0;
+  }
+  return v;
+}
+
 template <int G, bool BCE = false>
 __global__ __launch_bounds__(kThreads) void k_distmult_fwd(const float* __restrict__ h, const int64_t* __restrict__ hi,
-                                                           const float* __restrict__ t, const int64_t* __restrict__ ti,
+                                                           int64_t h_rows, const float* __restrict__ t,
+                                                           const int64_t* __restrict__ ti, int64_t t_rows,
                                                            const float* __restrict__ r, const int64_t* __restrict__ ri,
-                                                           int64_t B, int d, float* __restrict__ scores,
+                                                           int64_t r_rows, int64_t B, int d, float* __restrict__ scores,
                                                            const float* __restrict__ labels = nullptr,
                                                            float* __restrict__ loss = nullptr) {
   const int64_t b = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
@@ -32,9 +48,9 @@ __global__ __launch_bounds__(kThreads) void k_distmult_fwd(const float* __restri
   const bool live = b < B;
   float s = 0.f;
   if (live) {
-    const float* hp = h + (size_t)(hi ? hi[b] : b) * d;
-    const float* tp = t + (size_t)(ti ? ti[b] : b) * d;
-    const float* rp = r + (size_t)(ri ? ri[b] : b) * d;
+    const float* hp = h + (size_t)checked_row(hi, b, h_rows) * d;
+    const float* tp = t + (size_t)checked_row(ti, b, t_rows) * d;
+    const float* rp = r + (size_t)checked_row(ri, b, r_rows) * d;
     for (int c = gl * 4; c < d; c += G * 4) {
       const float4 a = ld4(hp + c), m = ld4(rp + c), z = ld4(tp + c);
       s += a.x * m.x * z.x;
@@ -51,35 +67,156 @@ __global__ __launch_bounds__(kThreads) void k_distmult_fwd(const float* __restri
   }
 }
 
-__device__ inline void emit4(float* dst, bool atomic, float4 v) {
-  if (atomic) {
-    atomicAdd(dst + 0, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
-  } else {
-    *reinterpret_cast<float4*>(dst) = v;
-  }
-}
-
-// BCE: gs is ONE float, the gradient arriving at the mean loss; the per-sample score gradient
-// gs * (sigmoid(score) - label) / B (autograd of the mean of bce_with_logits) is formed here.
+// ---------------------------------------------------------------------------------------
+// Backward, deterministic (no float atomics): duplicates in head / tail / relation ids are legal and
+// frequent (a hub is the head or tail of dozens of a 2,048-sample batch; 3 relation rows take them all).
+//   1. k_distmult_contrib: per sample the three gradient rows g*r*t, g*h*r, g*h*t - into the caller's
+//      buffer for an operand without an index (row b is its own), otherwise into workspace rows, and the
+//      sample's row ids as int32 keys.
+//   2. k_scatter_rows: one wave per slot (a head or tail occurrence).  It scans all keys (staged in LDS,
+//      64 per step, one ballot each); a slot that finds an equal key BEFORE itself retires; the first
+//      occurrence of a row adds the workspace rows of all its occurrences in slot order, eight loads in
+//      flight, and writes the row once.  Head and tail slots of one table (grad_h == grad_t) are one key
+//      space.  The caller zeroes the rows nobody touches.
+//   3. k_segment_partials / k_segment_combine: the relation table (few rows, hundreds of occurrences
+//      each) as a fixed two-level tree: one wave per (row, 256-sample segment) adds its occurrences in
+//      order, one wave per row adds the segments in order.
+// Every sum has a fixed order: two runs give the same bits.
+// ---------------------------------------------------------------------------------------
 template <int G, bool BCE = false>
-__global__ __launch_bounds__(kThreads) void k_distmult_bwd(const float* __restrict__ gs, const float* __restrict__ h,
-                                                           const int64_t* __restrict__ hi, const float* __restrict__ t,
-                                                           const int64_t* __restrict__ ti, const float* __restrict__ r,
-                                                           const int64_t* __restrict__ ri, int64_t B, int d,
-                                                           float* gh, float* gt, float* gr,
-                                                           const float* __restrict__ scores = nullptr,
-                                                           const float* __restrict__ labels = nullptr) {
+__global__ __launch_bounds__(kThreads) void k_distmult_contrib(
+    const float* __restrict__ gs, const float* __restrict__ h, const int64_t* __restrict__ hi, int64_t h_rows,
+    const float* __restrict__ t, const int64_t* __restrict__ ti, int64_t t_rows, const float* __restrict__ r,
+    const int64_t* __restrict__ ri, int64_t r_rows, int64_t B, int d, float* __restrict__ out_h,
+    float* __restrict__ out_t, float* __restrict__ out_r, int32_t* __restrict__ key_h, int32_t* __restrict__ key_t,
+    int32_t* __restrict__ key_r, const float* __restrict__ scores = nullptr, const float* __restrict__ labels = nullptr) {
   const int64_t b = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   const int gl = threadIdx.x % G;
   if (b >= B) return;
-  const size_t ho = (size_t)(hi ? hi[b] : b) * d, to = (size_t)(ti ? ti[b] : b) * d,
-               ro = (size_t)(ri ? ri[b] : b) * d;
+  const int64_t hr = checked_row(hi, b, h_rows), tr = checked_row(ti, b, t_rows), rr = checked_row(ri, b, r_rows);
+  if (gl == 0) {
+    if (key_h) key_h[b] = (int32_t)hr;
+    if (key_t) key_t[b] = (int32_t)tr;
+    if (key_r) key_r[b] = (int32_t)rr;
+  }
+  const size_t ho = (size_t)hr * d, to = (size_t)tr * d, ro = (size_t)rr * d, bo = (size_t)b * d;
   const float g = BCE ? gs[0] * (1.f / (1.f + expf(-scores[b])) - labels[b]) / (float)B : gs[b];
   for (int c = gl * 4; c < d; c += G * 4) {
     const float4 a = ld4(h + ho + c), m = ld4(r + ro + c), z = ld4(t + to + c);
-    if (gh) emit4(gh + ho + c, hi != nullptr, make_float4(g * m.x * z.x, g * m.y * z.y, g * m.z * z.z, g * m.w * z.w));
-    if (gt) emit4(gt + to + c, ti != nullptr, make_float4(g * a.x * m.x, g * a.y * m.y, g * a.z * m.z, g * a.w * m.w));
-    if (gr) emit4(gr + ro + c, ri != nullptr, make_float4(g * a.x * z.x, g * a.y * z.y, g * a.z * z.z, g * a.w * z.w));
+    if (out_h) *reinterpret_cast<float4*>(out_h + bo + c) = make_float4(g * m.x * z.x, g * m.y * z.y, g * m.z * z.z, g * m.w * z.w);
+    if (out_t) *reinterpret_cast<float4*>(out_t + bo + c) = make_float4(g * a.x * m.x, g * a.y * m.y, g * a.z * m.z, g * a.w * m.w);
+    if (out_r) *reinterpret_cast<float4*>(out_r + bo + c) = make_float4(g * a.x * z.x, g * a.y * z.y, g * a.z * z.z, g * a.w * z.w);
+  }
+}
+
+// ordered iteration over the positions p in [lo, hi) with keys[p] == my (keys in LDS or global), wave-uniform
+struct MatchIter {
+  const int32_t* keys;
+  int my, pos, hi;            // pos: next chunk start (multiple of 64)
+  unsigned long long mask;    // unvisited matches of the current chunk
+  int base;                   // its start
+  __device__ inline void start(const int32_t* k, int my_, int lo, int hi_, int lane) {
+    keys = k; my = my_; hi = hi_; pos = lo & ~63; mask = 0ull;
+    fetch(lane);
+    if (lo & 63) mask &= ~((1ull << (lo & 63)) - 1ull);
+  }
+  __device__ inline void fetch(int lane) {       // load the chunk at pos, advance
+    base = pos;
+    const int p = pos + lane;
+    mask = __ballot(p < hi && keys[p] == my);
+    pos += 64;
+  }
+  __device__ inline int next(int lane) {         // next match or -1
+    while (mask == 0ull) {
+      if (pos >= hi) return -1;
+      fetch(lane);
+    }
+    const int bit = __ffsll((long long)mask) - 1;
+    mask &= mask - 1ull;
+    return base + bit;
+  }
+};
+
+// the rows of the matches the iterator yields, added in order, eight loads in flight
+__device__ inline float4 ordered_row_sum(MatchIter& it, const float* __restrict__ rows, int d, int c0, int lane) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  while (true) {
+    int p[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] = it.next(lane);
+    if (p[0] < 0) break;
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      v[u] = p[u] >= 0 ? ld4(rows + (size_t)p[u] * d + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+    }
+    if (p[7] < 0) break;
+  }
+  return acc;
+}
+
+constexpr int kScatterWaves = 4;                 // waves (slots) per workgroup
+constexpr int kKeysInLds = 16384;                // key count up to which the keys are staged in LDS
+
+// rows[S, d] (workspace), keys[S] -> out[key] = sum of the rows with that key, in slot order; one wave per slot
+__global__ __launch_bounds__(64 * kScatterWaves) void k_scatter_rows(const int32_t* __restrict__ keys, int S,
+                                                                       const float* __restrict__ rows, int d,
+                                                                       float* __restrict__ out) {
+  __shared__ int32_t skeys[kKeysInLds];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool in_lds = S <= kKeysInLds;
+  if (in_lds) {
+    for (int i = threadIdx.x; i < S; i += 64 * kScatterWaves) skeys[i] = keys[i];
+    __syncthreads();
+  }
+  const int32_t* k = in_lds ? skeys : keys;
+  const int s = blockIdx.x * kScatterWaves + wave;
+  if (s >= S) return;
+  const int my = k[s];
+  for (int c = 0; c < s; c += 64) {              // an earlier occurrence owns the row
+    const int p = c + lane;
+    if (__ballot(p < s && k[p] == my)) return;
+  }
+  for (int c0 = lane * 4; c0 < ((d + 255) & ~255); c0 += 256) {   // (d <= 256: one pass; wider rows rescan the matches)
+    MatchIter it;
+    it.start(k, my, s, S, lane);
+    const int cc = min(c0, d - 4);               // lanes past the row end follow the (wave-uniform) iteration
+    const float4 acc = ordered_row_sum(it, rows, d, cc, lane);
+    if (c0 < d) *reinterpret_cast<float4*>(out + (size_t)my * d + c0) = acc;
+  }
+}
+
+constexpr int kSegment = 256;                    // samples per segment of the relation-table tree
+
+// partial[(seg * R + row), :] = sum of rows[b] over b in segment seg with keys[b] == row, in order
+__global__ __launch_bounds__(64) void k_segment_partials(const int32_t* __restrict__ keys, int B,
+                                                         const float* __restrict__ rows, int d, int R,
+                                                         float* __restrict__ partial) {
+  const int lane = threadIdx.x, row = blockIdx.x, seg = blockIdx.y;
+  const int lo = seg * kSegment, hi = min(B, lo + kSegment);
+  for (int c0 = lane * 4; c0 < ((d + 255) & ~255); c0 += 256) {
+    MatchIter it;
+    it.start(keys, row, lo, hi, lane);
+    const int cc = min(c0, d - 4);
+    const float4 acc = ordered_row_sum(it, rows, d, cc, lane);
+    if (c0 < d) *reinterpret_cast<float4*>(partial + ((size_t)seg * R + row) * d + c0) = acc;
+  }
+}
+
+// out[row, :] = sum over segments, in order
+__global__ __launch_bounds__(64) void k_segment_combine(const float* __restrict__ partial, int nseg, int R, int d,
+                                                        float* __restrict__ out) {
+  const int lane = threadIdx.x, row = blockIdx.x;
+  for (int c0 = lane * 4; c0 < d; c0 += 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nseg; ++s) {
+      const float4 v = ld4(partial + ((size_t)s * R + row) * d + c0);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)row * d + c0) = acc;
   }
 }
 
@@ -104,62 +241,153 @@ int pick_group(int64_t d) {
 
 extern "C" {
 
-int distmult_fwd(const float* h, const int64_t* h_idx, const float* t, const int64_t* t_idx, const float* r,
-                 const int64_t* r_idx, int64_t batch, int64_t d, float* scores, void* stream_) {
-  if (batch < 0 || d <= 0 || (d & 3)) return RGCN_ERR_ARG;
+int rgcn_index_error_fetch(int* host_flag, void* stream_) {
+  if (!host_flag) return RGCN_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  int zero = 0;
+  RGCN_HIP_TRY(hipStreamSynchronize(stream));
+  RGCN_HIP_TRY(hipMemcpyFromSymbol(host_flag, HIP_SYMBOL(g_index_error), sizeof(int)));
+  RGCN_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_index_error), &zero, sizeof(int)));
+  return RGCN_OK;
+}
+
+int distmult_fwd(const float* h, const int64_t* h_idx, int64_t h_rows, const float* t, const int64_t* t_idx,
+                 int64_t t_rows, const float* r, const int64_t* r_idx, int64_t r_rows, int64_t batch, int64_t d,
+                 float* scores, void* stream_) {
+  if (batch < 0 || d <= 0 || (d & 3) || h_rows < 0 || t_rows < 0 || r_rows < 0) return RGCN_ERR_ARG;
   if (batch == 0) return RGCN_OK;
   if (!h || !t || !r || !scores) return RGCN_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const int g = pick_group(d);
   const unsigned grid = (unsigned)ceil_div64(batch, kThreads / g);
-  DISPATCH_G(g, (k_distmult_fwd<G><<<grid, kThreads, 0, stream>>>(h, h_idx, t, t_idx, r, r_idx, batch, (int)d, scores)));
+  DISPATCH_G(g, (k_distmult_fwd<G><<<grid, kThreads, 0, stream>>>(h, h_idx, h_rows, t, t_idx, t_rows, r, r_idx, r_rows,
+                                                                    batch, (int)d, scores)));
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
 
-int distmult_bwd(const float* grad_scores, const float* h, const int64_t* h_idx, const float* t,
-                 const int64_t* t_idx, const float* r, const int64_t* r_idx, int64_t batch, int64_t d,
-                 float* grad_h, float* grad_t, float* grad_r, void* stream_) {
-  if (batch < 0 || d <= 0 || (d & 3)) return RGCN_ERR_ARG;
-  if (batch == 0) return RGCN_OK;
-  if (!grad_scores || !h || !t || !r) return RGCN_ERR_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
-  const int g = pick_group(d);
-  const unsigned grid = (unsigned)ceil_div64(batch, kThreads / g);
-  DISPATCH_G(g, (k_distmult_bwd<G><<<grid, kThreads, 0, stream>>>(grad_scores, h, h_idx, t, t_idx, r, r_idx, batch,
-                                                                    (int)d, grad_h, grad_t, grad_r)));
-  RGCN_HIP_TRY(hipGetLastError());
-  return RGCN_OK;
-}
-
-int distmult_bce_fwd(const float* h, const int64_t* h_idx, const float* t, const int64_t* t_idx, const float* r,
-                     const int64_t* r_idx, const float* labels, int64_t batch, int64_t d, float* scores, float* loss,
-                     void* stream_) {
-  if (batch < 0 || d <= 0 || (d & 3)) return RGCN_ERR_ARG;
+int distmult_bce_fwd(const float* h, const int64_t* h_idx, int64_t h_rows, const float* t, const int64_t* t_idx,
+                     int64_t t_rows, const float* r, const int64_t* r_idx, int64_t r_rows, const float* labels,
+                     int64_t batch, int64_t d, float* scores, float* loss, void* stream_) {
+  if (batch < 0 || d <= 0 || (d & 3) || h_rows < 0 || t_rows < 0 || r_rows < 0) return RGCN_ERR_ARG;
   if (batch == 0) return RGCN_OK;
   if (!h || !t || !r || !labels || !scores || !loss) return RGCN_ERR_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const int g = pick_group(d);
   const unsigned grid = (unsigned)ceil_div64(batch, kThreads / g);
-  DISPATCH_G(g, (k_distmult_fwd<G, true><<<grid, kThreads, 0, stream>>>(h, h_idx, t, t_idx, r, r_idx, batch, (int)d,
-                                                                         scores, labels, loss)));
+  DISPATCH_G(g, (k_distmult_fwd<G, true><<<grid, kThreads, 0, stream>>>(h, h_idx, h_rows, t, t_idx, t_rows, r, r_idx,
+                                                                         r_rows, batch, (int)d, scores, labels, loss)));
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
 
-int distmult_bce_bwd(const float* grad_mean_loss, const float* scores, const float* labels, const float* h,
-                     const int64_t* h_idx, const float* t, const int64_t* t_idx, const float* r,
-                     const int64_t* r_idx, int64_t batch, int64_t d, float* grad_h, float* grad_t, float* grad_r,
-                     void* stream_) {
-  if (batch < 0 || d <= 0 || (d & 3)) return RGCN_ERR_ARG;
+size_t distmult_bwd_workspace_bytes(int64_t batch, int64_t d, int64_t r_rows) {
+  if (batch <= 0 || d <= 0) return 0;
+  const int64_t nseg = ceil_div64(batch, kSegment);
+  return ((size_t)3 * batch * d + (size_t)nseg * (r_rows > 0 ? r_rows : 0) * d) * sizeof(float) +
+         (size_t)3 * batch * sizeof(int32_t) + 256;
+}
+
+}  // extern "C"
+
+namespace {
+
+// the shared body of distmult_bwd / distmult_bce_bwd
+template <bool BCE>
+int bwd_impl(const float* gs, const float* scores, const float* labels, const float* h, const int64_t* h_idx,
+             int64_t h_rows, const float* t, const int64_t* t_idx, int64_t t_rows, const float* r, const int64_t* r_idx,
+             int64_t r_rows, int64_t batch, int64_t d, float* grad_h, float* grad_t, float* grad_r, void* workspace,
+             size_t workspace_bytes, hipStream_t stream) {
+  if (batch < 0 || d <= 0 || (d & 3) || h_rows < 0 || t_rows < 0 || r_rows < 0) return RGCN_ERR_ARG;
   if (batch == 0) return RGCN_OK;
-  if (!grad_mean_loss || !scores || !labels || !h || !t || !r) return RGCN_ERR_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
+  if (!gs || !h || !t || !r) return RGCN_ERR_ARG;
+  if (batch > INT32_MAX / 4 || h_rows > INT32_MAX || t_rows > INT32_MAX || r_rows > INT32_MAX) return RGCN_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < distmult_bwd_workspace_bytes(batch, d, r_idx ? r_rows : 0)) return RGCN_ERR_WORKSPACE;
+  float* ws = (float*)workspace;
+  const size_t bd = (size_t)batch * d;
+  float *ch = ws, *ct = ws + bd, *cr = ws + 2 * bd;
+  const int64_t nseg = ceil_div64(batch, kSegment);
+  float* partial = ws + 3 * bd;
+  int32_t* keys = (int32_t*)(partial + (size_t)nseg * (r_idx ? r_rows : 0) * d);
+  int32_t *kh = keys, *kt = keys + batch, *kr = keys + 2 * batch;
+  // an operand without an index: row b is its own, written straight to the caller's buffer
+  float* out_h = grad_h ? (h_idx ? ch : grad_h) : nullptr;
+  float* out_t = grad_t ? (t_idx ? ct : grad_t) : nullptr;
+  float* out_r = grad_r ? (r_idx ? cr : grad_r) : nullptr;
   const int g = pick_group(d);
   const unsigned grid = (unsigned)ceil_div64(batch, kThreads / g);
-  DISPATCH_G(g, (k_distmult_bwd<G, true><<<grid, kThreads, 0, stream>>>(grad_mean_loss, h, h_idx, t, t_idx, r, r_idx,
-                                                                         batch, (int)d, grad_h, grad_t, grad_r, scores,
-                                                                         labels)));
+  DISPATCH_G(g, (k_distmult_contrib<G, BCE><<<grid, kThreads, 0, stream>>>(
+                    gs, h, h_idx, h_rows, t, t_idx, t_rows, r, r_idx, r_rows, batch, (int)d, out_h, out_t, out_r,
+                    (grad_h && h_idx) ? kh : nullptr, (grad_t && t_idx) ? kt : nullptr, (grad_r && r_idx) ? kr : nullptr,
+                    scores, labels)));
+  const bool sh = grad_h && h_idx, st = grad_t && t_idx;
+  if (sh && st && grad_h == grad_t) {            // one table, one key space: head slots then tail slots
+    const int S = (int)(2 * batch);
+    k_scatter_rows<<<(unsigned)ceil_div64(S, kScatterWaves), 64 * kScatterWaves, 0, stream>>>(kh, S, ch, (int)d, grad_h);
+  } else {
+    const int S = (int)batch;
+    const unsigned sg = (unsigned)ceil_div64(S, kScatterWaves);
+    if (sh) k_scatter_rows<<<sg, 64 * kScatterWaves, 0, stream>>>(kh, S, ch, (int)d, grad_h);
+    if (st) k_scatter_rows<<<sg, 64 * kScatterWaves, 0, stream>>>(kt, S, ct, (int)d, grad_t);
+  }
+  if (grad_r && r_idx && r_rows > 0) {
+    dim3 pg((unsigned)r_rows, (unsigned)nseg);
+    k_segment_partials<<<pg, 64, 0, stream>>>(kr, (int)batch, cr, (int)d, (int)r_rows, partial);
+    k_segment_combine<<<(unsigned)r_rows, 64, 0, stream>>>(partial, (int)nseg, (int)r_rows, (int)d, grad_r);
+  }
+  RGCN_HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+__global__ void k_keys32(const int64_t* __restrict__ idx, int64_t B, int64_t rows, int32_t* __restrict__ keys) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) keys[b] = (int32_t)checked_row(idx, b, rows);
+}
+
+}  // namespace
+
+extern "C" {
+
+int distmult_bwd(const float* grad_scores, const float* h, const int64_t* h_idx, int64_t h_rows, const float* t,
+                 const int64_t* t_idx, int64_t t_rows, const float* r, const int64_t* r_idx, int64_t r_rows,
+                 int64_t batch, int64_t d, float* grad_h, float* grad_t, float* grad_r, void* workspace,
+                 size_t workspace_bytes, void* stream_) {
+  return bwd_impl<false>(grad_scores, nullptr, nullptr, h, h_idx, h_rows, t, t_idx, t_rows, r, r_idx, r_rows, batch, d,
+                         grad_h, grad_t, grad_r, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+int distmult_bce_bwd(const float* grad_mean_loss, const float* scores, const float* labels, const float* h,
+                     const int64_t* h_idx, int64_t h_rows, const float* t, const int64_t* t_idx, int64_t t_rows,
+                     const float* r, const int64_t* r_idx, int64_t r_rows, int64_t batch, int64_t d, float* grad_h,
+                     float* grad_t, float* grad_r, void* workspace, size_t workspace_bytes, void* stream_) {
+  if (batch > 0 && (!scores || !labels)) return RGCN_ERR_ARG;
+  return bwd_impl<true>(grad_mean_loss, scores, labels, h, h_idx, h_rows, t, t_idx, t_rows, r, r_idx, r_rows, batch, d,
+                        grad_h, grad_t, grad_r, workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+size_t rgcn_segment_sum_workspace_bytes(int64_t batch, int64_t d, int64_t num_rows) {
+  if (batch <= 0 || d <= 0 || num_rows <= 0) return 0;
+  return (size_t)ceil_div64(batch, kSegment) * num_rows * d * sizeof(float) + (size_t)batch * sizeof(int32_t) + 256;
+}
+
+int rgcn_segment_sum(const float* rows, const int64_t* idx, int64_t batch, int64_t d, int64_t num_rows, float* out,
+                     void* workspace, size_t workspace_bytes, void* stream_) {
+  if (batch < 0 || d <= 0 || (d & 3) || num_rows <= 0 || !out) return RGCN_ERR_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (batch == 0) {
+    RGCN_HIP_TRY(hipMemsetAsync(out, 0, (size_t)num_rows * d * sizeof(float), stream));
+    return RGCN_OK;
+  }
+  if (!rows || !idx) return RGCN_ERR_ARG;
+  if (batch > INT32_MAX / 4 || num_rows > INT32_MAX) return RGCN_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < rgcn_segment_sum_workspace_bytes(batch, d, num_rows)) return RGCN_ERR_WORKSPACE;
+  const int64_t nseg = ceil_div64(batch, kSegment);
+  float* partial = (float*)workspace;
+  int32_t* keys = (int32_t*)(partial + (size_t)nseg * num_rows * d);
+  k_keys32<<<(unsigned)ceil_div64(batch, 256), 256, 0, stream>>>(idx, batch, num_rows, keys);
+  dim3 pg((unsigned)num_rows, (unsigned)nseg);
+  k_segment_partials<<<pg, 64, 0, stream>>>(keys, (int)batch, rows, (int)d, (int)num_rows, partial);
+  k_segment_combine<<<(unsigned)num_rows, 64, 0, stream>>>(partial, (int)nseg, (int)num_rows, (int)d, out);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

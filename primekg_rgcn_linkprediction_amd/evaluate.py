@@ -95,19 +95,33 @@ class ModelEvaluator:
     def evaluate(self, num_neg_samples: int = 1, k_values: List[int] = (10, 50)) -> Dict:
         scores, labels = self.compute_scores_and_labels(num_neg_samples)
         self.scores, self.labels = scores, labels          # kept for plotting code, as the reference does
-        return {"classification": self.compute_classification_metrics(scores, labels),
-                "ranking": self.compute_ranking_metrics(k_values),
-                "test_edges": self.num_test_edges, "num_nodes": self.num_nodes}
+        metrics = {"classification": self.compute_classification_metrics(scores, labels),
+                   "ranking": self.compute_ranking_metrics(k_values),
+                   "test_edges": self.num_test_edges, "num_nodes": self.num_nodes}
+        from . import ops
+        ops.check_indices(self.device)                     # an id outside the embedding table anywhere above: IndexError
+        return metrics
 
 
 # ------------------------------------------------------------------------------------------
 # checkpoint / data / results files / CLI
 # ------------------------------------------------------------------------------------------
-def load_model(model_path: str, device: torch.device) -> Tuple[DrugDiseaseModel, Dict]:
+def load_model(model_path: str, device: torch.device, trust_pickle: bool = False) -> Tuple[DrugDiseaseModel, Dict]:
     """-> (model in eval mode on ``device``, model_info).  A training checkpoint pickles its
-    argparse ``Namespace`` (``train.py:431-442``), so - like the reference - this needs
-    ``weights_only=False``: load only checkpoints you wrote yourself."""
-    checkpoint = torch.load(model_path, map_location="cpu", weights_only=False)
+    argparse ``Namespace`` next to the tensors (``train.py:431-442``; the reference therefore loads with
+    ``weights_only=False``, ``evaluate.py:672``).  Here the file is read with the restricted unpickler
+    (``weights_only=True``) that is allowed exactly one extra class, ``argparse.Namespace`` - nothing in the
+    file can execute.  ``trust_pickle=True`` (CLI ``--trust_checkpoint``) falls back to the unrestricted
+    loader for checkpoints that hold other objects: only for files you wrote yourself."""
+    import argparse
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            checkpoint = torch.load(model_path, map_location="cpu", weights_only=True)
+    except Exception as exc:
+        if not trust_pickle:
+            raise RuntimeError(f"{model_path} holds objects the restricted loader refuses ({exc}); re-run with "
+                               f"--trust_checkpoint if (and only if) you wrote this file yourself") from exc
+        checkpoint = torch.load(model_path, map_location="cpu", weights_only=False)
     args = checkpoint.get("args")
     if args is None:
         raise ValueError("Checkpoint does not contain 'args'. Cannot reconstruct model architecture.")
@@ -166,6 +180,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--num_neg_samples", type=int, default=1)
     p.add_argument("--k_values", type=int, nargs="+", default=[10, 50])
     p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--trust_checkpoint", action="store_true",
+                   help="allow the unrestricted pickle loader for --model_path (only for files you wrote yourself)")
     return p
 
 
@@ -173,7 +189,7 @@ def main(argv=None) -> Dict:
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(name)s - %(levelname)s - %(message)s")
     args = build_parser().parse_args(argv)
     device = torch.device(args.device)
-    model, info = load_model(args.model_path, device)
+    model, info = load_model(args.model_path, device, trust_pickle=args.trust_checkpoint)
     test_data, full_graph = load_test_data(args.data_dir)
     evaluator = ModelEvaluator(model, test_data, full_graph, device, batch_size=args.batch_size)
     metrics = evaluator.evaluate(num_neg_samples=args.num_neg_samples, k_values=args.k_values)

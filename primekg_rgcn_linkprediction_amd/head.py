@@ -64,8 +64,8 @@ class _DistMultFunction(torch.autograd.Function):
 class _RelationRows(torch.autograd.Function):
     """``table[idx]`` for the [R, d] relation table.  Thousands of samples share R rows, which
     is the worst case for an atomic / sort based embedding backward (160 us per step measured
-    with ``nn.Embedding``); here the table gradient is the small dense product
-    ``one_hot(idx)^T @ g`` -- deterministic, a few microseconds."""
+    with ``nn.Embedding``); here the table gradient is a fixed two-level tree over 256-sample
+    segments (``ops.segment_sum``) -- deterministic, a few microseconds."""
 
     @staticmethod
     def forward(ctx, table: Tensor, idx: Tensor) -> Tensor:
@@ -76,9 +76,7 @@ class _RelationRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g: Tensor):
         (idx,) = ctx.saved_tensors
-        one_hot = torch.zeros(ctx.rows, idx.numel(), device=g.device, dtype=g.dtype)
-        one_hot.scatter_(0, idx.unsqueeze(0), 1.0)
-        return one_hot @ g, None
+        return ops.segment_sum(g.contiguous(), idx.contiguous(), ctx.rows), None
 
 
 class _DistMultBCEFunction(torch.autograd.Function):

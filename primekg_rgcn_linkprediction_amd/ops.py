@@ -812,10 +812,43 @@ def distmult_fwd(h, h_idx, t, t_idx, r, r_idx, batch: int) -> torch.Tensor:
     lib = _lib.load()
     with _on(h.device):
         scores = torch.empty(batch, dtype=torch.float32, device=h.device)
-        rc = lib.distmult_fwd(_ptr(h), _ptr(h_idx), _ptr(t), _ptr(t_idx), _ptr(r), _ptr(r_idx), batch, d,
-                              _ptr(scores), _stream())
+        rc = lib.distmult_fwd(_ptr(h), _ptr(h_idx), h.size(0), _ptr(t), _ptr(t_idx), t.size(0), _ptr(r), _ptr(r_idx),
+                              r.size(0), batch, d, _ptr(scores), _stream())
     _lib.check(rc, "distmult_fwd")
     return scores
+
+
+def check_indices(device=None) -> None:
+    """Raise ``IndexError`` if any kernel since the last call met a head / tail / relation id outside its
+    table (``rgcn_index_error_fetch``).  Such ids are never dereferenced - they are clamped to row 0 and a
+    sticky device flag is raised - so, like torch's device-side assert on a bad index, the error surfaces
+    at the next check (this call synchronises): the trainer and the evaluator check once per epoch / run."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    flag = ctypes.c_int(0)
+    with _on(device):
+        rc = _lib.load().rgcn_index_error_fetch(ctypes.byref(flag), _stream())
+    _lib.check(rc, "rgcn_index_error_fetch")
+    if flag.value:
+        raise IndexError("a head / tail / relation index was outside its embedding table "
+                         "(clamped to row 0 on the device; results of that step are invalid)")
+
+
+def segment_sum(rows: torch.Tensor, idx: torch.Tensor, num_rows: int) -> torch.Tensor:
+    """``zeros(num_rows, d).index_add_(0, idx, rows)`` with a fixed summation order (deterministic; no
+    atomics): autograd of ``table[idx]`` for a table of few rows (``rgcn_segment_sum``)."""
+    _need_gpu("rows", rows, torch.float32)
+    _need_gpu("idx", idx, torch.int64)
+    if rows.dim() != 2 or idx.shape != (rows.size(0),) or rows.size(1) % 4:
+        raise ValueError("rows must be [B, d] (d % 4 == 0) and idx [B]")
+    lib = _lib.load()
+    b, d = rows.shape
+    with _on(rows.device):
+        out = torch.empty(num_rows, d, dtype=torch.float32, device=rows.device)
+        nbytes = lib.rgcn_segment_sum_workspace_bytes(b, d, num_rows)
+        ws = _workspace(nbytes, rows.device)
+        rc = lib.rgcn_segment_sum(_ptr(rows), _ptr(idx), b, d, int(num_rows), _ptr(out), _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "rgcn_segment_sum")
+    return out
 
 
 def adam_clip_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr: float, beta1: float, beta2: float, eps: float,
@@ -914,36 +947,46 @@ def distmult_bce_fwd(h, h_idx, t, t_idx, r, r_idx, labels, batch: int):
     with _on(h.device):
         scores = torch.empty(batch, dtype=torch.float32, device=h.device)
         loss = torch.empty(batch, dtype=torch.float32, device=h.device)
-        rc = lib.distmult_bce_fwd(_ptr(h), _ptr(h_idx), _ptr(t), _ptr(t_idx), _ptr(r), _ptr(r_idx), _ptr(labels),
-                                  batch, d, _ptr(scores), _ptr(loss), _stream())
+        rc = lib.distmult_bce_fwd(_ptr(h), _ptr(h_idx), h.size(0), _ptr(t), _ptr(t_idx), t.size(0), _ptr(r), _ptr(r_idx),
+                                  r.size(0), _ptr(labels), batch, d, _ptr(scores), _ptr(loss), _stream())
     _lib.check(rc, "distmult_bce_fwd")
     return scores, loss
+
+
+def _bwd_workspace(lib, batch: int, d: int, r, r_idx, device):
+    nbytes = lib.distmult_bwd_workspace_bytes(batch, d, r.size(0) if r_idx is not None else 0)
+    return _workspace(nbytes, device), nbytes
 
 
 def distmult_bce_bwd(grad_mean_loss, scores, labels, h, h_idx, t, t_idx, r, r_idx, batch: int,
                      grad_h, grad_t, grad_r) -> None:
     """Backward of ``mean(bce_with_logits(distmult(...), labels))``; ``grad_mean_loss`` is a
-    one-element device tensor.  Accumulates like ``distmult_bwd``."""
+    one-element device tensor.  Writes like ``distmult_bwd``."""
     _need_gpu("grad_mean_loss", grad_mean_loss, torch.float32)
     if grad_mean_loss.numel() != 1:
         raise ValueError("grad_mean_loss must hold one float")
     d = h.size(1)
     lib = _lib.load()
     with _on(h.device):
-        rc = lib.distmult_bce_bwd(_ptr(grad_mean_loss), _ptr(scores), _ptr(labels), _ptr(h), _ptr(h_idx), _ptr(t),
-                                  _ptr(t_idx), _ptr(r), _ptr(r_idx), batch, d, _ptr(grad_h), _ptr(grad_t),
-                                  _ptr(grad_r), _stream())
+        ws, nbytes = _bwd_workspace(lib, batch, d, r, r_idx, h.device)
+        rc = lib.distmult_bce_bwd(_ptr(grad_mean_loss), _ptr(scores), _ptr(labels), _ptr(h), _ptr(h_idx), h.size(0),
+                                  _ptr(t), _ptr(t_idx), t.size(0), _ptr(r), _ptr(r_idx), r.size(0), batch, d,
+                                  _ptr(grad_h), _ptr(grad_t), _ptr(grad_r), _ptr(ws), nbytes, _stream())
     _lib.check(rc, "distmult_bce_bwd")
 
 
 def distmult_bwd(gs, h, h_idx, t, t_idx, r, r_idx, batch: int, grad_h, grad_t, grad_r) -> None:
-    """Accumulates into caller-provided (zeroed where indexed) gradient buffers."""
+    """Deterministic backward (no float atomics; two runs give the same bits): rows reached through an
+    index vector are WRITTEN with the ordered sum of their samples' contributions - the caller provides
+    buffers that are zero in the rows nobody touches; ``grad_h is grad_t`` (one table) is one key space."""
     _need_gpu("grad_scores", gs, torch.float32)
     d = h.size(1)
     lib = _lib.load()
     with _on(h.device):
-        rc = lib.distmult_bwd(_ptr(gs), _ptr(h), _ptr(h_idx), _ptr(t), _ptr(t_idx), _ptr(r), _ptr(r_idx),
-                              batch, d, _ptr(grad_h), _ptr(grad_t), _ptr(grad_r), _stream())
+        ws, nbytes = _bwd_workspace(lib, batch, d, r, r_idx, h.device)
+        rc = lib.distmult_bwd(_ptr(gs), _ptr(h), _ptr(h_idx), h.size(0), _ptr(t), _ptr(t_idx), t.size(0), _ptr(r),
+                              _ptr(r_idx), r.size(0), batch, d, _ptr(grad_h), _ptr(grad_t), _ptr(grad_r), _ptr(ws),
+                              nbytes, _stream())
     _lib.check(rc, "distmult_bwd")
 
 

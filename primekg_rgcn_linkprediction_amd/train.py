@@ -34,6 +34,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import ops
 from .model import DrugDiseaseModel
 
 logger = logging.getLogger("primekg_rgcn_linkprediction_amd.train")
@@ -239,7 +240,9 @@ class Trainer:
             seen += (hi - lo) * (1 + self.neg_sampler.num_neg_samples)
             if on_step is not None:
                 on_step(*out)
-        return (self._loss_sum / max(seen, 1)).item(), self._correct.item() / max(seen, 1)
+        result = (self._loss_sum / max(seen, 1)).item(), self._correct.item() / max(seen, 1)
+        ops.check_indices(self.device)       # an id outside the embedding table anywhere in the epoch: IndexError, here
+        return result
 
     @torch.no_grad()
     def validate(self):
@@ -254,7 +257,9 @@ class Trainer:
             loss_sum += self.criterion(scores, labels).double() * labels.numel()
             correct += ((scores > 0) == (labels > 0.5)).sum()
             seen += labels.numel()
-        return (loss_sum / max(seen, 1)).item(), correct.item() / max(seen, 1)
+        result = (loss_sum / max(seen, 1)).item(), correct.item() / max(seen, 1)
+        ops.check_indices(self.device)
+        return result
 
     # -- checkpoints (same keys as train.py:431-442) --------------------------------------
     def save_checkpoint(self, epoch: int, is_best: bool = False, is_final: bool = False,

@@ -121,3 +121,4 @@ def test_evaluate_cli_round_trip(tmp_path):
     assert saved["model_info"]["num_parameters"] == 2078208 and saved["metrics"]["test_edges"] == te["edge_index"].size(1)
     text = (tmp_path / "results" / "metrics_summary.txt").read_text()
     assert "EVALUATION RESULTS SUMMARY" in text and "Ranking Metrics:" in text and "hits@100" in text
+

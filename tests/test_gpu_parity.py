@@ -517,6 +517,67 @@ def test_distmult_duplicate_rows_and_dropout_path():
     assert distmult(e2[:0], None, e2[:0], None, e2[:0], None).shape == (0,)
 
 
+def test_distmult_backward_is_deterministic_with_heavy_duplicates():
+    """no float atomics in the head's backward: hub rows (one row the head of a third of the batch), head and tail
+    from ONE table (one key space) or from two, relation table rows taking every sample - two runs give the
+    same bits, and the sums equal the oracle's."""
+    dev = need_gpu()
+    gen = torch.Generator().manual_seed(9)
+    b, d = 2048, 128
+    emb, emb2 = torch.randn(300, d, generator=gen), torch.randn(40, d, generator=gen)
+    rel = torch.randn(3, d, generator=gen)
+    hi = torch.randint(0, 300, (b,), generator=gen)
+    hi[torch.rand(b, generator=gen) < 0.33] = 7                     # a hub
+    ti = torch.randint(0, 40, (b,), generator=gen)
+    ri = torch.randint(0, 3, (b,), generator=gen)
+    cot = torch.randn(b, generator=gen)
+    for shared in (True, False):
+        table_t = emb if shared else emb2
+        tix = ti if not shared else torch.randint(0, 300, (b,), generator=gen)
+        e1, t1, r1 = emb.clone().requires_grad_(True), table_t.clone().requires_grad_(True), rel.clone().requires_grad_(True)
+        (O.distmult_ref(e1[hi], (e1 if shared else t1)[tix], r1[ri]) * cot).sum().backward()
+        runs = []
+        for _ in range(2):
+            e2, r2 = emb.to(dev).requires_grad_(True), rel.to(dev).requires_grad_(True)
+            t2 = e2 if shared else table_t.to(dev).requires_grad_(True)
+            sc = distmult(e2, hi.to(dev), t2, tix.to(dev), r2, ri.to(dev))
+            (sc * cot.to(dev)).sum().backward()
+            runs.append((e2.grad.clone(), None if shared else t2.grad.clone(), r2.grad.clone()))
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][2], runs[1][2])
+        assert_grad(runs[0][0], e1.grad, 1e-5)
+        assert_grad(runs[0][2], r1.grad, 1e-5)
+        if not shared:
+            assert torch.equal(runs[0][1], runs[1][1])
+            assert_grad(runs[0][1], t1.grad, 1e-5)
+    # the relation-table tree by itself, odd sizes
+    rows, idx = torch.randn(1000, 36, generator=gen), torch.randint(0, 5, (1000,), generator=gen)
+    got = ops.segment_sum(rows.to(dev), idx.to(dev), 7)
+    want = torch.zeros(7, 36).index_add_(0, idx, rows)
+    assert_grad(got, want, 1e-6) and float(got[5:].abs().max()) == 0.0
+    assert torch.equal(got, ops.segment_sum(rows.to(dev), idx.to(dev), 7))
+    ops.check_indices(dev)                                            # nothing above was out of range
+
+
+def test_out_of_range_head_ids_raise_at_the_next_check_and_never_fault():
+    """torch indexing raises (device-side assert) on a bad index; here the kernels clamp it, keep running and
+    raise a sticky flag that `ops.check_indices` turns into IndexError (no out-of-bounds access)."""
+    dev = need_gpu()
+    emb, rel = torch.randn(10, 8, device=dev, requires_grad=True), torch.randn(3, 8, device=dev)
+    ok = torch.tensor([1, 2, 3], device=dev)
+    ops.check_indices(dev)
+    for bad in (torch.tensor([1, 10, 3], device=dev), torch.tensor([1, -1, 3], device=dev)):
+        sc = distmult(emb, bad, emb, ok, rel, torch.tensor([0, 1, 2], device=dev))
+        sc.sum().backward()
+        torch.cuda.synchronize()
+        with pytest.raises(IndexError):
+            ops.check_indices(dev)
+        ops.check_indices(dev)                                        # the flag was cleared
+    sc = distmult(emb, ok, emb, ok, rel, torch.tensor([0, 3, 2], device=dev))   # relation id == R
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        ops.check_indices(dev)
+
+
 # ------------------------------------------------------------------ BASELINE configs
 PARITY_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r02.json")
 
@@ -526,7 +587,7 @@ def _record(tag, **numbers):
     try:
         os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
         log = json.load(open(PARITY_LOG)) if os.path.exists(PARITY_LOG) else {}
-        log[tag] = {k: float(v) for k, v in numbers.items()}
+        log[tag] = {k: float(v.detach()) if isinstance(v, torch.Tensor) else float(v) for k, v in numbers.items()}
         json.dump(log, open(PARITY_LOG, "w"), indent=1, sort_keys=True)
     except OSError:
         pass

@@ -45,8 +45,8 @@ def test_null_handle_and_bad_args_return_codes_without_a_gpu():
     assert lib.rgcn_graph_num_edges(None) == -1
     assert lib.rgcn_aggregate_workspace_bytes(None, 0, 64) == 0
     assert lib.rgcn_aggregate(None, 0, None, 64, None, None, 0, None) == _lib.RGCN_ERR_ARG
-    assert lib.distmult_fwd(None, None, None, None, None, None, 4, 6, None, None) == _lib.RGCN_ERR_ARG
-    assert lib.distmult_fwd(None, None, None, None, None, None, 0, 8, None, None) == _lib.RGCN_OK
+    assert lib.distmult_fwd(None, None, 1, None, None, 1, None, None, 1, 4, 6, None, None) == _lib.RGCN_ERR_ARG
+    assert lib.distmult_fwd(None, None, 1, None, None, 1, None, None, 1, 0, 8, None, None) == _lib.RGCN_OK
     assert lib.rgcn_transform_bwd_params_workspace_bytes(30926, 3, 128, 128) > 0
     # every entry point rejects bad sizes / null pointers before it touches the device
     import ctypes
@@ -65,10 +65,10 @@ def test_null_handle_and_bad_args_return_codes_without_a_gpu():
     assert lib.rgcn_transform_fwd(None, None, None, None, None, 0, None, 10, 3, 8, 8, None, None) == A   # null operands
     assert lib.rgcn_transform_bwd_input(None, None, None, None, None, None, 10, 0, 8, 8, None, None) == A
     assert lib.rgcn_transform_bwd_params(None, None, None, None, 10, 3, 8, 8, None, None, None, None, 0, None) == A
-    assert lib.distmult_bwd(None, None, None, None, None, None, None, 4, 8, None, None, None, None) == E
-    assert lib.distmult_bce_fwd(None, None, None, None, None, None, None, 4, 8, None, None, None) == E
-    assert lib.distmult_bce_bwd(None, None, None, None, None, None, None, None, None, 4, 8, None, None, None, None) == E
-    assert lib.distmult_bce_fwd(None, None, None, None, None, None, None, 0, 8, None, None, None) == _lib.RGCN_OK
+    assert lib.distmult_bwd(None, None, None, 1, None, None, 1, None, None, 1, 4, 8, None, None, None, None, 0, None) == E
+    assert lib.distmult_bce_fwd(None, None, 1, None, None, 1, None, None, 1, None, 4, 8, None, None, None) == E
+    assert lib.distmult_bce_bwd(None, None, None, None, None, 1, None, None, 1, None, None, 1, 4, 8, None, None, None, None, 0, None) == E
+    assert lib.distmult_bce_fwd(None, None, 1, None, None, 1, None, None, 1, None, 0, 8, None, None, None) == _lib.RGCN_OK
     assert lib.distmult_rank_tails(None, None, None, None, 4, 100, 48, None, None) != _lib.RGCN_OK       # d % 32
     assert lib.rgcn_sample_batch(None, None, 10, None, None, 4, 1, 0, None, None, None, None, None, None) == E
     assert lib.rgcn_sample_batch(None, None, 10, None, None, 4, 1, 100, None, None, None, None, None, None) == E
@@ -230,3 +230,30 @@ def test_header_is_plain_c_and_links_against_the_library(tmp_path):
     env = dict(os.environ, LD_LIBRARY_PATH=hip_dir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=env).stdout.split(maxsplit=2)
     assert out[0] == out[1] == str(_lib.ABI_VERSION) and "outside" in out[2]
+
+
+class _NotATensor:                                     # something the restricted unpickler must refuse
+    pass
+
+
+def test_load_model_uses_the_restricted_unpickler(tmp_path):
+    """checkpoints written by the trainer hold tensors, plain containers and ONE argparse.Namespace
+    (train.py:431-442): `load_model` reads them with weights_only=True + that one allowed class; a file
+    holding any other object is refused unless the caller opts in (no arbitrary unpickling)."""
+    import argparse
+    from primekg_rgcn_linkprediction_amd import DrugDiseaseModel, evaluate as E
+    torch.manual_seed(0)
+    model = DrugDiseaseModel(num_nodes=50, num_relations=3, embedding_dim=16, hidden_dim=32)
+    args = argparse.Namespace(embedding_dim=16, hidden_dim=32, dropout=0.5, decoder_dropout=0.1, num_bases=None)
+    good = {"epoch": 3, "model_state_dict": model.state_dict(), "optimizer_state_dict": {"state": {}, "param_groups": []},
+            "best_val_loss": 0.25, "best_val_acc": 0.9, "train_losses": [0.7, 0.5], "args": args}
+    torch.save(good, tmp_path / "good.pt")
+    loaded, info = E.load_model(str(tmp_path / "good.pt"), torch.device("cpu"))
+    assert info["epoch"] == 3 and info["num_nodes"] == 50 and info["best_val_loss"] == 0.25
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, loaded.state_dict()[k])
+    torch.save(dict(good, extra=_NotATensor()), tmp_path / "bad.pt")
+    with pytest.raises(RuntimeError, match="restricted loader refuses"):
+        E.load_model(str(tmp_path / "bad.pt"), torch.device("cpu"))
+    loaded2, _ = E.load_model(str(tmp_path / "bad.pt"), torch.device("cpu"), trust_pickle=True)
+    assert torch.equal(loaded2.state_dict()["encoder.conv1.weight"], model.state_dict()["encoder.conv1.weight"])

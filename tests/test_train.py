@@ -140,6 +140,26 @@ def test_trainer_steps_match_oracle_on_the_same_batches(tmp_path, hip_graph, tor
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hip_graph", [False, True])
+def test_training_steps_are_bitwise_reproducible(tmp_path, hip_graph):
+    """same seed -> the same bits after six full training steps with the reference's dropouts (0.5 / 0.1):
+    the layer has no atomics, the head's backward sums every row in a fixed order, clip + Adam reduce in a
+    fixed order, the device sampler is counter based."""
+    dev = need_gpu()
+    tr, va, full, _ = T.synthetic_data(num_edges=30000, seed=2)
+    states = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        args = _args(batch_size=1024, output_dir=str(tmp_path), device="cuda", no_hip_graph=not hip_graph)
+        trainer = T.Trainer(T.create_model(tr["num_nodes"], 3, args), tr, va, full, dev, args)
+        loss, _ = trainer.train_epoch(max_steps=6)
+        states.append(({k: v.clone() for k, v in trainer.model.state_dict().items()}, loss))
+    assert states[0][1] == states[1][1]
+    for k, v in states[0][0].items():
+        assert torch.equal(v, states[1][0][k]), k
+
+
+@pytest.mark.gpu
 def test_short_run_learns_and_checkpoints(tmp_path):
     dev = need_gpu()
     torch.manual_seed(1)
