@@ -238,7 +238,11 @@ def main():
         cot = enc.shard_rows(cot_cpu).to(dev)
         step = lambda: enc.step(cot)                                     # noqa: E731
         exchange = "RCCL over xGMI" if backend == "nccl" else f"{backend} (host-staged rehearsal, NOT RCCL)"
-        parallelism = f"node-partitioned x{world} (edge-balanced ranges), exchange per layer and direction: {exchange}"
+        summ = enc.exchange_summary()
+        how = ("halo all-to-all-v of the rows a rank's edges read" if summ["scheme"] == "pull" else
+               "partial sums from the source owner: reduce-scatter forward, halo all-to-all-v backward")
+        parallelism = (f"node-partitioned x{world} (degree-balanced deal), scheme '{summ['scheme']}': {how}, per layer "
+                       f"and direction, over {exchange}")
 
     def sync():
         if dist is not None:
@@ -347,6 +351,8 @@ def main():
                                             if ops.GEMM_PRECISION == "split" else "fp32 MFMA")},
         "bucket_ms": bucket_ms,
     }
+    if world > 1:
+        result["exchange_rank0"] = summ          # rows received per exchange as a fraction of the rows rank 0 does not own
 
     if events:
         # per instantiation of the gather kernel: average duration from the live HIP events

@@ -3,30 +3,36 @@
 direction.  The reference has no distributed code at all; this is the
 multi-GPU form BASELINE.json's north star asks for, built for MI355X's point-to-point xGMI.
 
-Scheme ("owner computes", SURVEY.md section 8e "alternative worth measuring" - chosen over
-the partial-sum all-reduce form because it keeps BOTH halves of the layer sharded):
+Partition: nodes are dealt to the P ranks greedily in descending degree (least-loaded rank first,
+at most cap = ceil(N/P) row slots each): near-equal shares of edge endpoints (PrimeKG ids are
+type-sorted and genes carry ~88 % of the endpoints, so contiguous ranges would be badly skewed,
+and its hubs defeat a plain round-robin deal).  Built once on rank 0 and broadcast.
 
-* nodes are dealt to the P ranks greedily in descending degree (least-loaded rank first,
-  at most cap = ceil(N/P) row slots each): near-equal shares of edge endpoints (PrimeKG ids
-  are type-sorted and genes carry ~88 % of the endpoints, so contiguous ranges would be
-  badly skewed, and its hubs defeat a plain round-robin deal);
-* rank p holds the in-edges of its rows (forward structure, mean mode) and the out-edges of
-  its rows (transposed structure, weights 1/cnt[dst, rel] from the GLOBAL counts);
-* forward of a layer : all-gather x [P*cap, d_in]  -> gather+mean over own (dst, rel)
-  segments -> MFMA transform of own rows only;
-* backward           : all-gather g [P*cap, d_out] -> weighted gather over own (src, rel)
-  segments -> input-grad transform of own rows; parameter grads are partial sums over own
-  rows -> ONE flat all-reduce per layer (<= 0.4 MB).
+Two exchange schemes, switchable (``scheme=`` / ``RGCN_DIST_SCHEME``), same results:
 
-No row of the output is ever a cross-rank partial sum, so activations and input gradients
-are bit-identical to the single-GPU run (same per-segment summation order, same k-ordered
-MFMA chains); only the parameter gradients see a different (rank-ordered) summation.
-The all-reduce form of the north star would make every rank run the dense transform over all
-N rows (or ship R*d_in-wide partial aggregates): it shards only the gather.
+``"pull"`` (default; SURVEY.md section 8e "alternative worth measuring") - owner computes:
+  rank p holds the in-edges of its rows (forward structure, mean mode) and the out-edges of its
+  rows (transposed structure, weights 1/cnt[dst, rel] from the GLOBAL counts).
+  forward of a layer : HALO exchange of x - every rank receives exactly the rows its edges read
+                       from every peer (one all-to-all-v; the lists are fixed with the graph) ->
+                       gather+mean over own (dst, rel) segments -> transform of own rows only;
+  backward           : halo exchange of g -> weighted gather over own (src, rel) segments ->
+                       input-grad transform of own rows.
+  No row of the output is ever a cross-rank partial sum, so activations and input gradients are
+  bit-identical to the single-GPU run in fp32 arithmetic (same per-segment summation order, same
+  k-ordered MFMA chains); BOTH halves of the layer are sharded.
+``"push"`` (the north star's form) - source owner computes partial sums:
+  rank q holds the edges whose SOURCE it owns, bucketed by (dst, rel) over all N rows, weights
+  1/cnt; forward: partial aggregates of all rows from own x -> transform (linear, so partial
+  outputs add) -> REDUCE-SCATTER of the [P*cap, d_out] partial outputs -> the owner adds
+  x root + bias; backward: ALL-GATHER of g (the other half of the all-reduce) -> the same
+  transposed gather as "pull".  Shards the gather only: every rank transforms all N rows.
 
-xGMI is point to point (7 links per GPU): an all-gather of equal slabs drives all seven
-links at once, which is why rows are padded to equal ``cap`` slabs instead of using
-variable-size ranges.
+Parameter gradients are partial sums over a rank's rows -> ONE flat all-reduce per layer
+(<= 0.4 MB), overlapped with the gather that follows.
+
+xGMI is point to point (7 links per GPU): an all-to-all / all-gather / reduce-scatter of slabs
+drives all seven links at once.
 
 The compute backend is injectable so that the N > 1 logic is covered by world_size-2 gloo
 tests on CPU (tests/ supply an oracle-backed backend); the product backend is the HIP
@@ -35,11 +41,14 @@ library and there is no CPU fallback here.
 from __future__ import annotations
 
 import heapq
+import os
 from typing import List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 from torch import Tensor
+
+SCHEMES = ("pull", "push")
 
 
 class HipBackend:
@@ -56,44 +65,128 @@ class HipBackend:
     def aggregate(self, shard, x):
         return self.ops.aggregate(shard, x)
 
-    # `shard` = the structure the aggregate operand was built over (its relation-occupancy mask
-    # lets the kernels skip all-zero tiles); backends without that notion ignore it
-    def transform_fwd(self, agg, x, weight, root, bias, relu=False, shard=None):
-        return self.ops.transform_fwd(agg, x, weight, root, bias, relu, shard)
+    def _amax(self, table, shard):
+        """operand scales of the split-precision transforms: the aggregate is bounded by
+        (largest per-segment weight sum) * max |table it was gathered from|; the rank's own rows are
+        part of that table, so its maximum serves both operands - one launch, no collective"""
+        if table is None or self.ops.GEMM_PRECISION != "split":
+            return None, 1.0
+        t = self.ops.absmax(table)
+        return (t, t), (shard.weight_bound(False) if shard is not None else 1.0)
 
-    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None, shard=None):
-        return self.ops.transform_bwd_input(gagg, g, weight, root, relu_mask, shard)
+    # `shard` = the structure the aggregate operand was built over (its relation-occupancy mask
+    # lets the kernels skip all-zero tiles), `table` = the rows it was gathered from; backends
+    # without these notions ignore them
+    def transform_fwd(self, agg, x, weight, root, bias, relu=False, shard=None, table=None):
+        amax, mul = self._amax(table, shard)
+        return self.ops.transform_fwd(agg, x, weight, root, bias, relu, shard, amax=amax, amax_mul=mul)
+
+    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None, shard=None, table=None):
+        amax, mul = self._amax(table, shard)
+        return self.ops.transform_bwd_input(gagg, g, weight, root, relu_mask, shard, amax=amax, amax_mul=mul)
 
     def transform_bwd_params(self, agg, x, g, num_relations, want_root, want_bias, shard=None):
         return self.ops.transform_bwd_params(agg, x, g, num_relations, want_root, want_bias, shard)
 
 
+# ------------------------------------------------------------------------------------------
+# partition
+# ------------------------------------------------------------------------------------------
 class NodePartition:
-    """Deterministic assignment node -> (rank, slot), identical on every rank."""
+    """Deterministic assignment node -> (rank, slot).  ``NodePartition(...)`` computes it locally;
+    ``NodePartition.shared(...)`` computes it on rank 0 and broadcasts (every rank of a job then
+    holds the identical tensors without each running the serial part)."""
 
-    def __init__(self, edge_index: Tensor, num_nodes: int, world: int):
+    EXACT_HEAD = 65536      # nodes (heaviest first) dealt by the exact heap; the light tail is dealt in bulk
+
+    def __init__(self, edge_index: Tensor, num_nodes: int, world: int, exact_head: Optional[int] = None):
         ei = edge_index.cpu()
         deg = torch.bincount(ei[0], minlength=num_nodes) + torch.bincount(ei[1], minlength=num_nodes)
-        order = torch.argsort(deg, descending=True, stable=True)        # heavy nodes first
         self.world, self.num_nodes = world, num_nodes
         self.cap = (num_nodes + world - 1) // world
-        # longest-processing-time greedy under a capacity of `cap` rows per rank: each node, in
-        # descending degree, goes to the least-loaded rank that still has a free slot
-        # (ties -> lowest rank).  A Zipf tail (top node ~4 % of all endpoints) defeats a plain
-        # round-robin deal; this keeps max/mean edge load within a few percent.
+        rank_of, slot_of = self._deal(deg, world, self.cap, self.EXACT_HEAD if exact_head is None else exact_head)
+        self._finish(rank_of, slot_of)
+
+    @classmethod
+    def shared(cls, edge_index: Tensor, num_nodes: int, group=None, device=None) -> "NodePartition":
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if rank == 0:
+            part = cls(edge_index, num_nodes, world)
+            payload = torch.stack([part.rank_of, part.slot_of])
+        else:
+            part = cls.__new__(cls)
+            part.world, part.num_nodes, part.cap = world, num_nodes, (num_nodes + world - 1) // world
+            payload = torch.empty(2, num_nodes, dtype=torch.int64)
+        if world > 1:
+            on_dev = dist.get_backend(group) == "nccl"
+            buf = payload.to(device) if on_dev else payload
+            dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            payload = buf.cpu()
+        if rank != 0:
+            part._finish(payload[0].clone(), payload[1].clone())
+        return part
+
+    def _finish(self, rank_of: Tensor, slot_of: Tensor) -> None:
+        self.rank_of, self.slot_of = rank_of, slot_of
+        self.pid = rank_of * self.cap + slot_of                         # row in the gathered layout
+        self.counts = torch.bincount(rank_of, minlength=self.world)
+
+    @staticmethod
+    def _deal(deg: Tensor, world: int, cap: int, exact_head: int):
+        """Longest-processing-time greedy under a capacity of `cap` rows per rank: each node, in
+        descending degree, goes to the least-loaded rank that still has a free slot (ties -> lowest
+        rank).  A Zipf tail (top node ~4 % of all endpoints) defeats a plain round-robin deal; this keeps
+        max/mean edge load within a few percent.  The heap loop is inherently serial, so only the
+        `exact_head` heaviest nodes take it (all of PrimeKG); the light tail - loads are within one
+        head-sized degree of each other by then - is dealt in bulk: rounds over the ranks in ascending
+        load order, each rank taking one node per round until its slots are full."""
+        n = deg.numel()
+        order = torch.argsort(deg, descending=True, stable=True)        # heavy nodes first
+        head = min(n, max(0, exact_head))
         heap = [(0, k) for k in range(world)]
         fill = [0] * world
-        rank_l, slot_l = [0] * num_nodes, [0] * num_nodes
-        deg_l = deg[order].tolist()
-        for node, d in zip(order.tolist(), deg_l):
-            load, k = heapq.heappop(heap)
-            rank_l[node], slot_l[node] = k, fill[k]
+        load = [0] * world
+        rank_l, slot_l = [0] * head, [0] * head
+        for i, d in enumerate(deg[order[:head]].tolist()):
+            ld, k = heapq.heappop(heap)
+            rank_l[i], slot_l[i] = k, fill[k]
             fill[k] += 1
-            if fill[k] < self.cap:
-                heapq.heappush(heap, (load + d, k))
-        self.rank_of = torch.tensor(rank_l, dtype=torch.int64)
-        self.slot_of = torch.tensor(slot_l, dtype=torch.int64)
-        self.pid = self.rank_of * self.cap + self.slot_of               # row in the gathered layout
+            load[k] = ld + d
+            if fill[k] < cap:
+                heapq.heappush(heap, (ld + d, k))
+        rank_of = torch.empty(n, dtype=torch.int64)
+        slot_of = torch.empty(n, dtype=torch.int64)
+        rank_of[order[:head]] = torch.tensor(rank_l, dtype=torch.int64)
+        slot_of[order[:head]] = torch.tensor(slot_l, dtype=torch.int64)
+        tail = n - head
+        if tail > 0:
+            fill_t = torch.tensor(fill, dtype=torch.int64)
+            # final row counts: as even as the capacity allows (the first n - (cap-1)*world ranks get cap)
+            base = n // world
+            final = torch.full((world,), base, dtype=torch.int64)
+            final[: n - base * world] += 1
+            quota = (final - fill_t).clamp(min=0)
+            short = tail - int(quota.sum())                              # head dealt unevenly: hand the rest to
+            k = 0                                                        # the ranks with free slots, lightest first
+            by_load = sorted(range(world), key=lambda r: (load[r], r))
+            while short != 0:
+                r = by_load[k % world]
+                if short > 0 and fill_t[r] + quota[r] < cap:
+                    quota[r] += 1
+                    short -= 1
+                elif short < 0 and quota[r] > 0:
+                    quota[r] -= 1
+                    short += 1
+                k += 1
+            pos_in_order = torch.empty(world, dtype=torch.int64)
+            pos_in_order[torch.tensor(by_load)] = torch.arange(world)
+            rk = torch.repeat_interleave(torch.arange(world), quota)                    # owner of each tail slot
+            start = torch.cumsum(quota, 0) - quota
+            rnd = torch.arange(tail) - torch.repeat_interleave(start, quota)           # its round
+            seq = torch.argsort(rnd * world + pos_in_order[rk], stable=True)            # rounds, ranks by ascending load
+            rank_of[order[head:]] = rk[seq]
+            slot_of[order[head:]] = (fill_t[rk] + rnd)[seq]
+        return rank_of, slot_of
 
     def nodes_of(self, rank: int) -> Tensor:
         """node ids owned by ``rank`` in slot order"""
@@ -112,32 +205,135 @@ class NodePartition:
         return gathered[self.pid.to(gathered.device)]
 
 
+# ------------------------------------------------------------------------------------------
+# what one rank holds of the static graph
+# ------------------------------------------------------------------------------------------
+class HaloPlan:
+    """The fixed all-to-all-v of one direction: which own rows go to which peer, and where the rows
+    received from each peer sit in this rank's local row table ``[own rows (cap) | halo rows]``.
+    ``reader`` / ``read`` : per edge, the node whose owner gathers and the node whose row it reads.
+    Every rank holds the whole (static) edge list, so both sides of every pair are computed locally -
+    no handshake; sender and receiver order a pair's rows by the owner's slot."""
+
+    def __init__(self, reader: Tensor, read: Tensor, part: NodePartition, rank: int, device):
+        world, n = part.world, part.num_nodes
+        r_reader, r_read = part.rank_of[reader], part.rank_of[read]
+        cross = r_reader != r_read
+        # rows this rank receives: the distinct nodes its own readers read from other ranks
+        mine = cross & (r_reader == rank)
+        remote = torch.unique(read[mine])
+        remote = remote[torch.argsort(part.pid[remote])]                 # by owner, then by the owner's slot
+        self.halo_nodes, self.num_halo = remote, int(remote.numel())
+        self.recv_splits = torch.bincount(part.rank_of[remote], minlength=world).tolist()
+        # rows this rank sends: its own nodes that readers of other ranks read, per reading rank
+        theirs = cross & (r_read == rank)
+        pair = torch.unique(r_reader[theirs] * n + read[theirs])         # (reading rank, own node), distinct
+        to_rank, node = pair // n, pair % n
+        order = torch.argsort(to_rank * (part.cap + 1) + part.slot_of[node])
+        self.send_splits = torch.bincount(to_rank, minlength=world).tolist()
+        self.send_slots = part.slot_of[node][order].to(device)
+        self.num_send = int(pair.numel())
+
+    def local_index(self, part: NodePartition, rank: int, nodes: Tensor) -> Tensor:
+        """node id -> row of the local table (own slot, or cap + position among the halo rows)"""
+        lut = torch.full((part.num_nodes,), -1, dtype=torch.int64)
+        own = torch.nonzero(part.rank_of == rank).flatten()
+        lut[own] = part.slot_of[own]
+        lut[self.halo_nodes] = part.cap + torch.arange(self.num_halo)
+        out = lut[nodes]
+        if out.numel() and int(out.min()) < 0:
+            raise RuntimeError("halo plan does not cover an edge endpoint")
+        return out
+
+    def emulate(self, own: Tensor, full: Tensor) -> Tensor:
+        """the local table a real exchange would produce, built from the full [N, d] tensor (single-process
+        checks of a shard: tests)"""
+        return torch.cat([own, full[self.halo_nodes.to(full.device)]])
+
+
 class RankShard:
-    """What one rank holds of the static graph: both bucketed structures of its rows."""
+    """What one rank holds of the static graph: the bucketed structures of its rows, in the rank's LOCAL
+    row space ``[own rows (cap) | halo rows]``, and the two halo plans."""
 
     def __init__(self, part: NodePartition, edge_index: Tensor, edge_type: Tensor, num_relations: int,
-                 rank: int, device, backend):
+                 rank: int, device, backend, scheme: str = "pull"):
+        if scheme not in SCHEMES:
+            raise ValueError(f"scheme must be one of {SCHEMES}, got {scheme!r}")
         ei, et = edge_index.cpu(), edge_type.cpu()
         n, r = part.num_nodes, num_relations
         src, dst = ei[0], ei[1]
         cnt = torch.bincount(dst * r + et, minlength=n * r).clamp(min=1).to(torch.float32)
-        self.part, self.rank, self.num_relations = part, rank, r
+        self.part, self.rank, self.num_relations, self.scheme = part, rank, r, scheme
         self.cap, self.rows_all = part.cap, part.cap * part.world
+        self.num_own = int(part.counts[rank])
         m_in = part.rank_of[dst] == rank             # in-edges of own rows, column order kept
-        self.g_in = backend.make_shard(part.slot_of[dst[m_in]].to(device), part.pid[src[m_in]].to(device),
-                                       et[m_in].to(device), self.cap, self.rows_all, r)
         m_out = part.rank_of[src] == rank            # out-edges of own rows
-        w = (1.0 / cnt[dst[m_out] * r + et[m_out]]).to(torch.float32)
-        self.g_out = backend.make_shard(part.slot_of[src[m_out]].to(device), part.pid[dst[m_out]].to(device),
-                                        et[m_out].to(device), self.cap, self.rows_all, r, w.to(device))
         self.num_in_edges, self.num_out_edges = int(m_in.sum()), int(m_out.sum())
+        w_out = (1.0 / cnt[dst[m_out] * r + et[m_out]]).to(torch.float32)
+        # backward of both schemes: out-edges of own rows over the local table [own | halo of g]
+        self.halo_out = HaloPlan(src, dst, part, rank, device)          # a node's owner reads g of its out-neighbours
+        self.g_out = backend.make_shard(part.slot_of[src[m_out]].to(device),
+                                        self.halo_out.local_index(part, rank, dst[m_out]).to(device),
+                                        et[m_out].to(device), self.cap, self.cap + self.halo_out.num_halo, r,
+                                        w_out.to(device))
+        if scheme == "pull":                         # forward: in-edges of own rows over [own | halo of x]
+            self.halo_in = HaloPlan(dst, src, part, rank, device)       # a node's owner reads x of its in-neighbours
+            self.g_in = backend.make_shard(part.slot_of[dst[m_in]].to(device),
+                                           self.halo_in.local_index(part, rank, src[m_in]).to(device),
+                                           et[m_in].to(device), self.cap, self.cap + self.halo_in.num_halo, r)
+            self.g_push = None
+        else:                                        # forward: partial sums of ALL rows from own sources
+            self.halo_in = None
+            self.g_in = None
+            self.g_push = backend.make_shard(part.pid[dst[m_out]].to(device), part.slot_of[src[m_out]].to(device),
+                                             et[m_out].to(device), self.rows_all, self.cap, r, w_out.to(device))
+        remote_rows = n - self.num_own
+        self.halo_fraction_in = (self.halo_in.num_halo / max(remote_rows, 1)) if self.halo_in else None
+        self.halo_fraction_out = self.halo_out.num_halo / max(remote_rows, 1)
+
+
+# ------------------------------------------------------------------------------------------
+# exchanges
+# ------------------------------------------------------------------------------------------
+def _host_staged(t: Tensor, group) -> bool:
+    # test rigs only (several ranks sharing one GPU, where RCCL refuses to run): gloo has no device
+    # collectives, so the exchange is staged through the host
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+class _Halo:
+    """Exchange of the rows a rank's edges read: issue it, launch the work that only needs this rank's
+    rows, then ``.table()`` = ``[own rows | received rows]`` when the gather needs it."""
+
+    def __init__(self, own: Tensor, plan: HaloPlan, group):
+        self.work = None
+        d = own.size(1)
+        self.tbl = own.new_empty(own.size(0) + plan.num_halo, d)
+        self.tbl[: own.size(0)].copy_(own)
+        send = own.index_select(0, plan.send_slots) if plan.num_send else own.new_empty(0, d)
+        recv = self.tbl[own.size(0):]
+        if dist.get_world_size(group) == 1:
+            return
+        if _host_staged(own, group):
+            send_h = send.detach().cpu()
+            recv_h = send_h.new_empty(plan.num_halo, d)
+            dist.all_to_all_single(recv_h, send_h, plan.recv_splits, plan.send_splits, group=group)
+            recv.copy_(recv_h)
+            return
+        self.work = dist.all_to_all_single(recv, send.contiguous(), plan.recv_splits, plan.send_splits, group=group,
+                                           async_op=True)
+        self._keep = send                        # alive until the collective has consumed it
+
+    def table(self) -> Tensor:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.tbl
 
 
 def _all_gather_rows(own: Tensor, world: int, group) -> Tensor:
     shape = (own.size(0) * world,) + tuple(own.shape[1:])
-    if own.is_cuda and dist.get_backend(group) == "gloo":
-        # test rigs only (several ranks sharing one GPU, where RCCL refuses to run): gloo has no
-        # device all-gather, so the exchange is staged through the host
+    if _host_staged(own, group):
         host = own.detach().contiguous().cpu()
         out_h = host.new_empty(shape)
         dist.all_gather_into_tensor(out_h, host, group=group)
@@ -147,29 +343,29 @@ def _all_gather_rows(own: Tensor, world: int, group) -> Tensor:
     return out
 
 
-class _Gather:
-    """An all-gather of row slabs that may still be in flight: issue it, launch the work that
-    only needs this rank's rows, then ``.result()`` when the gathered rows are needed."""
-
-    def __init__(self, own: Tensor, world: int, group):
-        self.work = None
-        if own.is_cuda and dist.get_backend(group) == "gloo":
-            self.out = _all_gather_rows(own, world, group)          # host-staged test path: synchronous
-            return
-        self.out = own.new_empty((own.size(0) * world,) + tuple(own.shape[1:]))
-        self.work = dist.all_gather_into_tensor(self.out, own.contiguous(), group=group, async_op=True)
-
-    def result(self) -> Tensor:
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
-        return self.out
+def _reduce_scatter_rows(full: Tensor, world: int, group) -> Tensor:
+    """[P*cap, d] partial rows of every rank -> [cap, d] sums of this rank's rows"""
+    cap = full.size(0) // world
+    if _host_staged(full, group) or dist.get_backend(group) == "gloo":
+        # gloo has no reduce-scatter: all-reduce, keep the own slab (test rigs only)
+        host = full.detach().contiguous().cpu() if full.is_cuda else full.detach().clone()
+        dist.all_reduce(host, group=group)
+        k = dist.get_rank(group)
+        return host[k * cap:(k + 1) * cap].to(full.device)
+    out = full.new_empty((cap,) + tuple(full.shape[1:]))
+    dist.reduce_scatter_tensor(out, full.contiguous(), group=group)
+    return out
 
 
 def _flat_all_reduce(parts, group):
     """one flat all-reduce for a layer's parameter-gradient partial sums -> (work, flat, parts)"""
     parts = [t for t in parts if t is not None]
     flat = torch.cat([t.reshape(-1) for t in parts])
+    if _host_staged(flat, group):
+        host = flat.cpu()
+        dist.all_reduce(host, group=group)
+        flat.copy_(host)
+        return None, flat, parts
     return dist.all_reduce(flat, group=group, async_op=True), flat, parts
 
 
@@ -182,19 +378,69 @@ def _unflatten(flat, parts, has_root, has_bias):
     return next(it), (next(it) if has_root else None), (next(it) if has_bias else None)
 
 
+def _wait(red):
+    if red[0] is not None:
+        red[0].wait()
+
+
+def _zero_pad_rows(g: Tensor, num_own: int) -> Tensor:
+    """the slots past a rank's last node are padding: whatever arrives there must not reach a parameter gradient"""
+    if num_own >= g.size(0):
+        return g.contiguous()
+    g = g.clone()
+    g[num_own:] = 0
+    return g
+
+
+# ------------------------------------------------------------------------------------------
+# autograd nodes
+# ------------------------------------------------------------------------------------------
+def _layer_fwd(x, weight, root, bias, relu, shard: RankShard, backend, group):
+    """one layer on this rank's rows -> (out, agg as the parameter-gradient GEMM needs it)"""
+    if shard.scheme == "pull":
+        tbl = _Halo(x, shard.halo_in, group).table()
+        agg = backend.aggregate(shard.g_in, tbl)
+        return backend.transform_fwd(agg, x, weight, root, bias, relu, shard.g_in, table=tbl), agg
+    # push: partial aggregates of ALL rows from own sources; the transform is linear, so partial outputs add
+    part = backend.aggregate(shard.g_push, x)                                         # [P*cap, R*d_in]
+    dummy = x.new_zeros(part.size(0), x.size(1))
+    partial_out = backend.transform_fwd(part, dummy, weight, None, None, False, shard.g_push, table=x)
+    out = _reduce_scatter_rows(partial_out, shard.part.world, group)
+    if root is not None:
+        out = out + x @ root
+    if bias is not None:
+        out = out + bias
+    return (torch.relu(out) if relu else out), part
+
+
+def _param_grads(agg, x, g, shard: RankShard, backend, group, has_root, has_bias):
+    """parameter-gradient partial sums of this rank -> pending flat all-reduce"""
+    r = shard.num_relations
+    if shard.scheme == "pull":
+        return _flat_all_reduce(backend.transform_bwd_params(agg, x, g, r, has_root, has_bias, shard.g_in), group)
+    # push: grad_W from the partial aggregates of all rows against the gathered g; root / bias from own rows
+    g_all = _all_gather_rows(g, shard.part.world, group)
+    dummy = x.new_zeros(agg.size(0), x.size(1))
+    gw, _, _ = backend.transform_bwd_params(agg, dummy, g_all, r, False, False, shard.g_push)
+    return _flat_all_reduce([gw, x.t() @ g if has_root else None, g.sum(0) if has_bias else None], group)
+
+
+def _input_grad(g, weight, root, relu_mask, shard: RankShard, backend, group):
+    tbl = _Halo(g, shard.halo_out, group).table()
+    gagg = backend.aggregate(shard.g_out, tbl)
+    return backend.transform_bwd_input(gagg, g, weight, root, relu_mask, shard.g_out, table=tbl)
+
+
 class _PartitionedEncoder2Function(torch.autograd.Function):
     """conv1 -> ReLU -> conv2 on this rank's rows as ONE autograd node (cf. conv._Encoder2Function):
-    four exchanges per step, each issued asynchronously and overlapped with the work that needs
-    only own rows (the parameter-gradient GEMMs), ReLU and its backward in the GEMM epilogues."""
+    four exchanges per step, ReLU and its backward in the GEMM epilogues, parameter-gradient all-reduces
+    in flight behind the gathers."""
 
     @staticmethod
     def forward(ctx, x, w1, root1, b1, w2, root2, b2, shard: RankShard, backend, group):
-        world = shard.part.world
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
-        agg1 = backend.aggregate(shard.g_in, _Gather(x, world, group).result())
-        h = backend.transform_fwd(agg1, x, w1, root1, b1, True, shard.g_in)
-        agg2 = backend.aggregate(shard.g_in, _Gather(h, world, group).result())
-        out = backend.transform_fwd(agg2, h, w2, root2, b2, False, shard.g_in)
+        h, agg1 = _layer_fwd(x, w1, root1, b1, True, shard, backend, group)
+        out, agg2 = _layer_fwd(h, w2, root2, b2, False, shard, backend, group)
         ctx.shard, ctx.backend, ctx.group = shard, backend, group
         ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
         ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2)
@@ -204,23 +450,14 @@ class _PartitionedEncoder2Function(torch.autograd.Function):
     def backward(ctx, g):
         x, agg1, h, agg2, w1, root1, w2, root2 = ctx.saved_tensors
         shard, backend, group = ctx.shard, ctx.backend, ctx.group
-        world, r = shard.part.world, shard.num_relations
         has_root1, has_b1, has_root2, has_b2 = ctx.flags
-        g = g.contiguous()
-        g_all = _Gather(g, world, group)                                   # exchange in flight ...
-        red2 = _flat_all_reduce(backend.transform_bwd_params(agg2, h, g, r, has_root2, has_b2, shard.g_in), group)
-        gagg2 = backend.aggregate(shard.g_out, g_all.result())             # ... behind the GEMM above
-        gz = backend.transform_bwd_input(gagg2, g, w2, root2, h, shard.g_out)   # ReLU backward in the epilogue
-        gz_all = _Gather(gz, world, group)
-        red1 = _flat_all_reduce(backend.transform_bwd_params(agg1, x, gz, r, has_root1, has_b1, shard.g_in), group)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gagg1 = backend.aggregate(shard.g_out, gz_all.result())
-            gx = backend.transform_bwd_input(gagg1, gz, w1, root1, None, shard.g_out)
-        else:
-            gz_all.result()
-        red2[0].wait()
-        red1[0].wait()
+        g = _zero_pad_rows(g, shard.num_own)
+        red2 = _param_grads(agg2, h, g, shard, backend, group, has_root2, has_b2)     # all-reduce in flight ...
+        gz = _input_grad(g, w2, root2, h, shard, backend, group)                      # ... ReLU backward in the epilogue
+        red1 = _param_grads(agg1, x, gz, shard, backend, group, has_root1, has_b1)
+        gx = _input_grad(gz, w1, root1, None, shard, backend, group) if ctx.needs_input_grad[0] else None
+        _wait(red2)
+        _wait(red1)
         gw2, groot2, gb2 = _unflatten(red2[1], red2[2], has_root2, has_b2)
         gw1, groot1, gb1 = _unflatten(red1[1], red1[2], has_root1, has_b1)
         return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None, None
@@ -229,11 +466,8 @@ class _PartitionedEncoder2Function(torch.autograd.Function):
 class _PartitionedConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_own, weight, root, bias, shard: RankShard, backend, group, relu=False):
-        x_own = x_own.contiguous()
-        weight = weight.contiguous()
-        x_all = _all_gather_rows(x_own, shard.part.world, group)           # the layer's one exchange
-        agg = backend.aggregate(shard.g_in, x_all)
-        out = backend.transform_fwd(agg, x_own, weight, root, bias, relu, shard.g_in)
+        x_own, weight = x_own.contiguous(), weight.contiguous()
+        out, agg = _layer_fwd(x_own, weight, root, bias, relu, shard, backend, group)
         ctx.shard, ctx.backend, ctx.group, ctx.relu = shard, backend, group, relu
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
         ctx.save_for_backward(x_own, agg, weight, root, out if relu else None)
@@ -245,27 +479,11 @@ class _PartitionedConvFunction(torch.autograd.Function):
         shard, backend, group = ctx.shard, ctx.backend, ctx.group
         if ctx.relu:
             g_own = g_own * (out > 0)                                       # ReLU backward
-        g_own = g_own.contiguous()
-        need_x = ctx.needs_input_grad[0]
-        gw, groot, gbias = backend.transform_bwd_params(agg, x_own, g_own, shard.num_relations,
-                                                        ctx.has_root, ctx.has_bias, shard.g_in)
-        parts = [t for t in (gw, groot, gbias) if t is not None]
-        flat = torch.cat([t.reshape(-1) for t in parts])
-        work = dist.all_reduce(flat, group=group, async_op=True)            # overlaps the gather below
-        gx = None
-        if need_x:
-            g_all = _all_gather_rows(g_own, shard.part.world, group)
-            gagg = backend.aggregate(shard.g_out, g_all)
-            gx = backend.transform_bwd_input(gagg, g_own, weight, root, None, shard.g_out)
-        work.wait()
-        outs, off = [], 0
-        for t in parts:
-            outs.append(flat[off: off + t.numel()].view_as(t))
-            off += t.numel()
-        it = iter(outs)
-        gw = next(it)
-        groot = next(it) if ctx.has_root else None
-        gbias = next(it) if ctx.has_bias else None
+        g_own = _zero_pad_rows(g_own, shard.num_own)
+        red = _param_grads(agg, x_own, g_own, shard, backend, group, ctx.has_root, ctx.has_bias)
+        gx = _input_grad(g_own, weight, root, None, shard, backend, group) if ctx.needs_input_grad[0] else None
+        _wait(red)
+        gw, groot, gbias = _unflatten(red[1], red[2], ctx.has_root, ctx.has_bias)
         return gx, gw, groot, gbias, None, None, None, None
 
 
@@ -283,17 +501,27 @@ class PartitionedEncoder:
     with identical parameters on every rank; ``emb_full``: the [N, d] input table."""
 
     def __init__(self, edge_index: Tensor, edge_type: Tensor, num_nodes: int, num_relations: int,
-                 emb_full: Tensor, convs: Sequence[torch.nn.Module], device, backend=None, group=None):
+                 emb_full: Tensor, convs: Sequence[torch.nn.Module], device, backend=None, group=None,
+                 scheme: Optional[str] = None):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.group = group
+        self.scheme = scheme or os.environ.get("RGCN_DIST_SCHEME", "pull")
         self.backend = backend if backend is not None else HipBackend()
-        self.part = NodePartition(edge_index, num_nodes, self.world)
+        self.part = NodePartition.shared(edge_index, num_nodes, group, device)
         self.shard = RankShard(self.part, edge_index, edge_type, num_relations, self.rank, device,
-                               self.backend)
+                               self.backend, self.scheme)
         self.emb = self.part.shard_rows(emb_full, self.rank).to(device).requires_grad_(True)
         self.convs: List[torch.nn.Module] = [c.to(device) for c in convs]
         self.params = [self.emb] + [p for c in self.convs for p in c.parameters()]
+
+    def exchange_summary(self) -> dict:
+        """rows this rank receives per exchange, as a fraction of the rows it does not own"""
+        s = self.shard
+        return {"scheme": self.scheme, "rows_own": s.num_own, "rows_remote": self.part.num_nodes - s.num_own,
+                "halo_rows_forward": s.halo_in.num_halo if s.halo_in else None,
+                "halo_fraction_forward": s.halo_fraction_in,
+                "halo_rows_backward": s.halo_out.num_halo, "halo_fraction_backward": s.halo_fraction_out}
 
     def shard_rows(self, full: Tensor) -> Tensor:
         return self.part.shard_rows(full, self.rank)
@@ -366,7 +594,12 @@ class ReplicatedEncoder:
             p.grad = None
         out.backward(cot)
         torch._foreach_copy_(self._views, [p.grad for p in self.params])
-        dist.all_reduce(self._flat, group=self.group)
+        if _host_staged(self._flat, self.group):
+            host = self._flat.cpu()
+            dist.all_reduce(host, group=self.group)
+            self._flat.copy_(host)
+        else:
+            dist.all_reduce(self._flat, group=self.group)
         self._flat.div_(self.world)
         for p, v in zip(self.params, self._views):
             p.grad = v

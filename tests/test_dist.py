@@ -38,14 +38,14 @@ class OracleBackend:
             out = out / cnt.view(-1, 1)
         return out.view(s["n_key"], -1)
 
-    def transform_fwd(self, agg, x, weight, root, bias, relu=False, shard=None):
+    def transform_fwd(self, agg, x, weight, root, bias, relu=False, shard=None, table=None):
         out = agg @ weight.reshape(-1, weight.size(2))
         if root is not None:
             out = out + x @ root
         out = out + bias if bias is not None else out
         return torch.relu(out) if relu else out
 
-    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None, shard=None):
+    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None, shard=None, table=None):
         r, d_in, d_out = weight.shape
         gx = sum(gagg[:, k * d_out:(k + 1) * d_out] @ weight[k].t() for k in range(r))
         gx = gx + g @ root.t() if root is not None else gx
@@ -82,7 +82,7 @@ def _oracle_full(ei, et, emb, convs, cot):
     return out.detach(), e.grad, ps
 
 
-def _worker(rank, world, port, n, e, r, dims, seed, q, use_hip=False):
+def _worker(rank, world, port, n, e, r, dims, seed, q, use_hip=False, scheme="pull"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(1)
@@ -92,17 +92,21 @@ def _worker(rank, world, port, n, e, r, dims, seed, q, use_hip=False):
         if use_hip:        # every rank drives the real kernels on the one GPU of the box
             dev = torch.device("cuda:0")
             torch.cuda.set_device(dev)
-            enc = rdist.PartitionedEncoder(ei, et, n, r, emb, convs, dev)
+            enc = rdist.PartitionedEncoder(ei, et, n, r, emb, convs, dev, scheme=scheme)
         else:
             dev = torch.device("cpu")
-            enc = rdist.PartitionedEncoder(ei, et, n, r, emb, convs, dev, backend=OracleBackend())
-        out_own = enc.step(enc.shard_rows(cot).to(dev))
+            enc = rdist.PartitionedEncoder(ei, et, n, r, emb, convs, dev, backend=OracleBackend(), scheme=scheme)
+        cot_own = enc.shard_rows(cot).to(dev)
+        cot_own[enc.shard.num_own:] = 7.0            # junk in the padding slots must not reach any gradient
+        out_own = enc.step(cot_own)
         with torch.no_grad():                       # the per-layer nodes give the same rows
             assert torch.allclose(enc.forward_layers(), out_own, rtol=1e-6, atol=1e-6)
         out = enc.gather_output(out_own).cpu()
         gemb = enc.gather_output(enc.emb.grad).cpu()
         grads = {f"{i}.{k}": p.grad.cpu().numpy().copy() for i, c in enumerate(enc.convs)
                  for k, p in c.named_parameters()}
+        summ = enc.exchange_summary()
+        assert summ["halo_rows_backward"] <= summ["rows_remote"] and 0.0 <= summ["halo_fraction_backward"] <= 1.0
         balance = (enc.shard.num_in_edges, enc.shard.num_out_edges, enc.part.cap)
         # numpy payloads are pickled by value: no shared-memory handle outlives this process
         q.put((rank, out.numpy().copy(), gemb.numpy().copy(), grads, balance))
@@ -111,11 +115,11 @@ def _worker(rank, world, port, n, e, r, dims, seed, q, use_hip=False):
         dist.destroy_process_group()
 
 
-def _run_partitioned(world, n, e, r, dims, seed, use_hip):
+def _run_partitioned(world, n, e, r, dims, seed, use_hip, scheme="pull"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(k, world, port, n, e, r, dims, seed, q, use_hip))
+    procs = [ctx.Process(target=_worker, args=(k, world, port, n, e, r, dims, seed, q, use_hip, scheme))
              for k in range(world)]
     for p in procs:
         p.start()
@@ -148,10 +152,14 @@ def _check_partitioned(results, world, n, e, r, dims, seed):
             assert torch.equal(v, other[3][k])
 
 
+@pytest.mark.parametrize("scheme", ["pull", "push"])
 @pytest.mark.parametrize("world,n,e", [(2, 101, 1500), (3, 64, 900)])
-def test_partitioned_encoder_gloo(world, n, e):
+def test_partitioned_encoder_gloo(world, n, e, scheme):
+    """both exchange schemes - "pull" (halo all-to-all-v of the rows a rank's edges read, owner computes) and
+    "push" (the north star's form: partial sums from the source owner, reduce-scatter forward / all-gather
+    backward) - against the single-process oracle on the full graph"""
     r, dims, seed = 3, (16, 32, 32), 5
-    _check_partitioned(_run_partitioned(world, n, e, r, dims, seed, False), world, n, e, r, dims, seed)
+    _check_partitioned(_run_partitioned(world, n, e, r, dims, seed, False, scheme), world, n, e, r, dims, seed)
 
 
 def _oracle_encoder(emb, ei, et, c1, c2):
@@ -203,12 +211,102 @@ def test_replicated_encoder_gloo_averages_the_batches():
 
 
 @pytest.mark.gpu
-def test_partitioned_encoder_hip_two_ranks():
+@pytest.mark.parametrize("scheme", ["pull", "push"])
+def test_partitioned_encoder_hip_two_ranks(scheme):
     """two processes, both on the box's one GPU, the product HIP backend in each; collectives
     over gloo (RCCL refuses two ranks on one device) - the full multi-process path minus RCCL."""
     need_gpu()
     world, n, e, r, dims, seed = 2, 3000, 60000, 3, (64, 128, 128), 8
-    _check_partitioned(_run_partitioned(world, n, e, r, dims, seed, True), world, n, e, r, dims, seed)
+    _check_partitioned(_run_partitioned(world, n, e, r, dims, seed, True, scheme), world, n, e, r, dims, seed)
+
+
+def _replica_hip_worker(rank, world, port, n, e, r, dims, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        ei, et, emb, convs, _ = _make_problem(n, e, r, dims, seed)
+        enc = rdist.ReplicatedEncoder(ei, et, n, r, emb, convs, dev)          # product path: rgcn_encoder2 on the HIP library
+        cot = torch.randn(n, dims[2], generator=torch.Generator().manual_seed(100 + rank)).to(dev)
+        enc.step(cot)
+        q.put((rank, [p.grad.cpu().numpy().copy() for p in enc.params]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_replicated_encoder_hip_two_ranks():
+    """batch-replica mode with the HIP backend: two processes on the box's one GPU (gradient all-reduce
+    host-staged over gloo), each its own cotangent; both end with the mean of the two oracle gradients."""
+    need_gpu()
+    world, n, e, r, dims, seed = 2, 2000, 40000, 3, (64, 128, 128), 9
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_hip_worker, args=(k, world, port, n, e, r, dims, seed, q)) for k in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ei, et, emb, convs, _ = _make_problem(n, e, r, dims, seed)
+    want = None
+    for rank in range(world):
+        cot = torch.randn(n, dims[2], generator=torch.Generator().manual_seed(100 + rank))
+        _, gemb, ps = _oracle_full(ei, et, emb, convs, cot)
+        grads = [gemb] + [ps[i][k].grad for i in range(2) for k, _ in convs[i].named_parameters()]
+        want = grads if want is None else [a + b for a, b in zip(want, grads)]
+    for rank in range(world):
+        for g, w in zip(got[rank], want):
+            w = w / world
+            assert ((torch.from_numpy(g) - w).abs().max() / (w.abs().max() + 1e-30)).item() <= 1e-4
+    for a, b in zip(got[0], got[1]):
+        assert (a == b).all()
+
+
+def _rccl_worker(rank, world, port, n, e, r, dims, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        ei, et, emb, convs, cot = _make_problem(n, e, r, dims, seed)
+        enc = rdist.PartitionedEncoder(ei, et, n, r, emb, convs, dev)
+        out_own = enc.step(enc.shard_rows(cot).to(dev))
+        out = enc.gather_output(out_own).cpu()
+        gemb = enc.gather_output(enc.emb.grad).cpu()
+        grads = {f"{i}.{k}": p.grad.cpu().numpy().copy() for i, c in enumerate(enc.convs) for k, p in c.named_parameters()}
+        q.put((rank, out.numpy().copy(), gemb.numpy().copy(), grads,
+               (enc.shard.num_in_edges, enc.shard.num_out_edges, enc.part.cap)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: one RCCL rank per device")
+def test_partitioned_encoder_two_rccl_ranks():
+    """PartitionedEncoder.step on 2 real RCCL ranks (one per GPU, halo all-to-all-v over xGMI) against the
+    single-process oracle: runs wherever the box has two devices (the 1-GPU boxes of this pool skip it)."""
+    world, n, e, r, dims, seed = 2, 3000, 60000, 3, (64, 128, 128), 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(k, world, port, n, e, r, dims, seed, q)) for k in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results = [(rk, torch.from_numpy(o), torch.from_numpy(ge), {k: torch.from_numpy(v) for k, v in gr.items()}, b)
+               for rk, o, ge, gr, b in results]
+    _check_partitioned(results, world, n, e, r, dims, seed)
 
 
 def test_partition_is_balanced_and_consistent():
@@ -251,21 +349,50 @@ def test_hip_shards_match_single_gpu_bitwise(world, monkeypatch):
     # P ranks
     backend = rdist.HipBackend()
     part = rdist.NodePartition(ei, n, world)
-    x_all = torch.cat([part.shard_rows(x, k) for k in range(world)]).to(dev)
-    g_all = torch.cat([part.shard_rows(g, k) for k in range(world)]).to(dev)
+    xd, gd = x.to(dev), g.to(dev)
     outs, gxs, gw, groot, gbias = [], [], 0, 0, 0
     for k in range(world):
         shard = rdist.RankShard(part, ei, et, r, k, dev, backend)
         x_own, g_own = part.shard_rows(x, k).to(dev), part.shard_rows(g, k).to(dev)
-        agg = backend.aggregate(shard.g_in, x_all)
-        outs.append(backend.transform_fwd(agg, x_own, w, root, bias))
-        gxs.append(backend.transform_bwd_input(backend.aggregate(shard.g_out, g_all), g_own, w, root))
-        a, b, c = backend.transform_bwd_params(agg, x_own, g_own, r, True, True)
+        x_tbl = shard.halo_in.emulate(x_own, xd)          # [own rows | the rows the halo exchange would deliver]
+        g_tbl = shard.halo_out.emulate(g_own, gd)
+        assert shard.halo_in.num_halo <= n - shard.num_own and sum(shard.halo_in.recv_splits) == shard.halo_in.num_halo
+        agg = backend.aggregate(shard.g_in, x_tbl)
+        outs.append(backend.transform_fwd(agg, x_own, w, root, bias, False, shard.g_in, table=x_tbl))
+        gxs.append(backend.transform_bwd_input(backend.aggregate(shard.g_out, g_tbl), g_own, w, root, None, shard.g_out,
+                                               table=g_tbl))
+        a, b, c = backend.transform_bwd_params(agg, x_own, g_own, r, True, True, shard.g_in)
         gw, groot, gbias = gw + a, groot + b, gbias + c
     assert torch.equal(part.unshard_rows(torch.cat(outs)), out1)
     assert torch.equal(part.unshard_rows(torch.cat(gxs)), gx1)
     for got, want in ((gw, gw1), (groot, groot1), (gbias, gbias1)):
         assert ((got - want).abs().max() / want.abs().max()).item() < 1e-5
+
+
+def test_partition_bulk_tail_keeps_capacity_and_balance():
+    """nodes past the exact head are dealt in bulk (vectorised): every node gets one slot, nobody exceeds the
+    capacity, the loads stay balanced; below the head size the deal is the exact greedy one"""
+    ei, et, n, r = synth.primekg_like(num_edges=100000, seed=42)
+    exact = rdist.NodePartition(ei, n, 8)
+    for head in (0, 500, 5000):
+        part = rdist.NodePartition(ei, n, 8, exact_head=head)
+        assert torch.unique(part.pid).numel() == n and int(part.slot_of.max()) < part.cap
+        assert int(part.counts.max()) <= part.cap and int(part.counts.sum()) == n
+        deg = torch.bincount(ei[1], minlength=n).float()
+        per_rank = torch.zeros(8).index_add_(0, part.rank_of, deg)
+        assert per_rank.max() / per_rank.mean() < (1.05 if head >= 500 else 1.6)
+    same = rdist.NodePartition(ei, n, 8, exact_head=n)
+    assert torch.equal(same.rank_of, exact.rank_of) and torch.equal(same.slot_of, exact.slot_of)
+    # halo plans of all ranks fit together: what q sends to p is what p expects from q
+    class _Rec:
+        def make_shard(self, *a, **k):
+            return a
+    shards = [rdist.RankShard(exact, ei, et, r, k, torch.device("cpu"), _Rec()) for k in range(8)]
+    for p in range(8):
+        for q_ in range(8):
+            assert shards[p].halo_in.recv_splits[q_] == shards[q_].halo_in.send_splits[p]
+            assert shards[p].halo_out.recv_splits[q_] == shards[q_].halo_out.send_splits[p]
+        assert 0 < shards[p].halo_fraction_in < 1                      # a Zipf graph: a real halo, not the whole table
 
 
 @pytest.mark.gpu

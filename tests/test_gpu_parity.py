@@ -99,6 +99,27 @@ def test_bucket_rejects_out_of_range_ids():
     ops.BucketedGraph(ei, et, 6, 2)
 
 
+def test_failed_bucketing_frees_what_it_allocated():
+    """every device allocation of rgcn_graph_create belongs to the scratch object (freed by its destructor) or to
+    the handle (freed by rgcn_graph_destroy on the error path): 40 creations that fail at the range check, each
+    holding ~70 MB of sort scratch and half-built structure, must not lower the device's free memory."""
+    dev = need_gpu()
+    n, e = 100_000, 3_000_000
+    gen = torch.Generator().manual_seed(0)
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    ei[1, e - 1] = n + 5                                            # one id out of range, found after the allocations
+    eid, etd = ei.to(dev), torch.zeros(e, dtype=torch.int64, device=dev)
+    with pytest.raises(IndexError):
+        ops.BucketedGraph(eid, etd, n, 2)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(dev)[0]
+    for _ in range(40):
+        with pytest.raises(IndexError):
+            ops.BucketedGraph(eid, etd, n, 2)
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info(dev)[0] < 64 * 2 ** 20
+
+
 def test_graph_cache_hits_and_invalidates():
     dev = need_gpu()
     ops.clear_graph_cache()
