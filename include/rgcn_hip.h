@@ -256,6 +256,9 @@ int rgcn_slab_reduce(const rgcn_slab_job* job, void* stream);
  * the call scan that operand itself (one extra pass over it).  out_amax / grad_x_amax (or NULL):
  * receives max |result| (zeroed by the caller).  Shapes outside the kernels' tiling (d_in resp. d_out
  * not a multiple of 32; 64 for the parameter gradients) return RGCN_ERR_UNSUPPORTED: use the fp32 calls.
+ * half != 0: ONE pass on the hi parts only - both operands rounded to fp16 under their per-tensor scales (loss
+ * scaling per tensor), fp32 accumulate: the arithmetic of BASELINE.json configs[4] ("fp16 features + fp32
+ * accumulate") for the three gradient GEMMs, 2^-11 relative per operand.
  * `workspace`: rgcn_transform_split_workspace_bytes (fwd, bwd_input),
  * rgcn_transform_bwd_params_split_workspace_bytes (bwd_params).
  * ---------------------------------------------------------------------------------- */
@@ -273,12 +276,12 @@ size_t rgcn_transform_split_workspace_bytes(int64_t num_relations, int64_t d_in,
 int rgcn_transform_fwd_split(const float* agg, const float* x, const float* weight, const float* root,
                              const void* packed, const float* bias, int relu, const uint32_t* tile_mask,
                              int64_t num_nodes, int64_t num_relations, int64_t d_in, int64_t d_out,
-                             const float* agg_amax, float agg_amax_mul, const float* x_amax, float* out,
-                             float* out_amax, void* workspace, size_t workspace_bytes, void* stream);
+                             const float* agg_amax, float agg_amax_mul, const float* x_amax, int half,
+                             float* out, float* out_amax, void* workspace, size_t workspace_bytes, void* stream);
 int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const float* weight, const float* root,
                                    const void* packed, const float* relu_mask, const uint32_t* tile_mask,
                                    int64_t num_nodes, int64_t num_relations, int64_t d_in, int64_t d_out,
-                                   const float* gagg_amax, float gagg_amax_mul, const float* g_amax,
+                                   const float* gagg_amax, float gagg_amax_mul, const float* g_amax, int half,
                                    float* grad_x, float* grad_x_amax, void* workspace, size_t workspace_bytes,
                                    void* stream);
 size_t rgcn_transform_bwd_params_split_workspace_bytes(int64_t num_nodes, int64_t num_relations,
@@ -288,7 +291,8 @@ size_t rgcn_transform_bwd_params_split_workspace_bytes(int64_t num_nodes, int64_
 int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, const float* g,
                                           const uint32_t* tile_mask, int64_t num_nodes, int64_t num_relations,
                                           int64_t d_in, int64_t d_out, const float* agg_amax,
-                                          float agg_amax_mul, const float* x_amax, const float* g_amax, float* grad_weight,
+                                          float agg_amax_mul, const float* x_amax, const float* g_amax, int half,
+                                          float* grad_weight,
                                           float* grad_root, float* grad_bias, void* workspace,
                                           size_t workspace_bytes, void* stream, rgcn_slab_job* job);
 

@@ -277,6 +277,17 @@ def _r16(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.float32).half().to(t.dtype)
 
 
+def _r16_scaled(t: torch.Tensor) -> torch.Tensor:
+    """round to fp16 under the tensor's power-of-two scale (its largest magnitude scaled into [2^14, 2^15)):
+    what the one-pass gradient GEMMs of configs[4] do to an operand - loss scaling per tensor, so that
+    gradients of ~1e-7 neither underflow nor lose bits"""
+    amax = float(t.abs().max())
+    if amax == 0.0 or not math.isfinite(amax):
+        return t
+    e = 14 - math.floor(math.log2(amax))
+    return _r16(t * 2.0 ** e) * 2.0 ** (-e)
+
+
 def _segment_counts(edge_index, edge_type, n, r, dtype):
     key = edge_index[1] * r + edge_type
     return torch.bincount(key, minlength=n * r).clamp(min=1).to(dtype)          # cnt[dst * R + rel]
@@ -312,8 +323,9 @@ def encoder_explicit_f64(emb, conv1: dict, conv2: dict, edge_index, edge_type, c
     each transform rounds both operands ``[agg | x]`` and ``[W ; root]`` to fp16 (nearest even),
     products are exact and sums wide; the backward is the fp32 formula on the tensors the forward
     saved (un-rounded ``agg``, ``x``, ``h``, fp32 weights).  ``half_backward=True`` additionally
-    rounds the operands of the three gradient GEMMs per layer to fp16 (gradient tables, ``agg``,
-    ``x`` and weights), sums wide.
+    rounds the operands of the three gradient GEMMs per layer to fp16, each under its tensor's
+    power-of-two scale (``_r16_scaled``: gradient tables, their aggregates, ``[agg | x]`` and the weights),
+    sums wide; the gradient gathers stay exact.
 
     ``relu_mask`` [N, hidden] (bool): the ReLU decisions to use in the backward (pass the
     device's ``h > 0`` so that a pre-activation within rounding of zero cannot flip a unit
@@ -324,7 +336,7 @@ def encoder_explicit_f64(emb, conv1: dict, conv2: dict, edge_index, edge_type, c
     n, r = emb.size(0), (conv1["comp"].size(0) if conv1.get("comp") is not None else conv1["weight"].size(0))
     cnt = _segment_counts(edge_index, edge_type, n, r, f64)
     rf = _r16 if half_forward else (lambda t: t)
-    rb = _r16 if half_backward else (lambda t: t)
+    rb = _r16_scaled if half_backward else (lambda t: t)
 
     def weights(c):
         w = effective_weight(c["weight"].to(f64), None if c.get("comp") is None else c["comp"].to(f64), r)
@@ -358,10 +370,12 @@ def encoder_explicit_f64(emb, conv1: dict, conv2: dict, edge_index, edge_type, c
         gx = None
         if want_x:
             gagg = _mean_agg_transposed(g, edge_index, edge_type, n, r, cnt)
-            ga = torch.cat([gagg, g], 1) if c.get("root") is not None else gagg
-            wt = torch.cat([w.transpose(1, 2).reshape(-1, d_in)] +
-                           ([c["root"].to(f64).t()] if c.get("root") is not None else []))
-            gx = rb(ga) @ rb(wt)
+            wt = rb(torch.cat([w.transpose(1, 2).reshape(-1, d_in)] +
+                              ([c["root"].to(f64).t()] if c.get("root") is not None else [])))   # one scale for [W ; root]
+            k1 = r * w.size(2)
+            gx = rb(gagg) @ wt[:k1]                   # the aggregate and g carry a scale each
+            if c.get("root") is not None:
+                gx = gx + rb(g) @ wt[k1:]
         return out, gx
 
     x = emb.to(f64)

@@ -71,13 +71,13 @@ PROTOTYPES = {
     "rgcn_weights_split_bytes": (c_size_t, [_I64, _I64, _I64]),
     "rgcn_weights_split_pack": (c_int, [_P, _P, _I64, _I64, _I64, _P, c_size_t, _P]),
     "rgcn_transform_split_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),
-    "rgcn_transform_fwd_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P,
-                                         _P, _P, c_size_t, _P]),
-    "rgcn_transform_bwd_input_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P,
-                                               _P, _P, c_size_t, _P]),
+    "rgcn_transform_fwd_split": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, c_int,
+                                         _P, _P, _P, c_size_t, _P]),
+    "rgcn_transform_bwd_input_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, c_int,
+                                               _P, _P, _P, c_size_t, _P]),
     "rgcn_transform_bwd_params_split_workspace_bytes": (c_size_t, [_I64, _I64, _I64, _I64]),
-    "rgcn_transform_bwd_params_split_begin": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P, _P,
-                                                      _P, _P, _P, c_size_t, _P, POINTER(SlabJob)]),
+    "rgcn_transform_bwd_params_split_begin": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P, c_int,
+                                                      _P, _P, _P, _P, c_size_t, _P, POINTER(SlabJob)]),
     "distmult_fwd": (c_int, [_P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P]),
     "rgcn_index_error_fetch": (c_int, [POINTER(c_int), _P]),
     "distmult_bwd_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),

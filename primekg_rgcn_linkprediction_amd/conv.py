@@ -86,7 +86,8 @@ _TRANSFORM_FIRST_RATIO = float(_os.environ.get("RGCN_TRANSFORM_FIRST_RATIO", "4"
 
 def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Optional[Tensor],
                 tail: Optional["ops.PendingParamGrads"] = None, g_amax: Optional[Tensor] = None,
-                scales: Optional[_Scales] = None, packed: Optional["ops.SplitWeights"] = None) -> Tensor:
+                scales: Optional[_Scales] = None, packed: Optional["ops.SplitWeights"] = None,
+                precision: Optional[str] = None) -> Tensor:
     """``d loss / d x`` of one layer from ``g = d loss / d out``.
 
     Default: gather first (``gagg = transposed aggregate of g``, then one GEMM with
@@ -105,9 +106,10 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
         gagg = ops.aggregate(graph, g, transposed=True, tail=tail)       # autograd of A3 + A4 (fp32 grads)
         # |gagg| <= (largest sum of 1/cnt weights over a node's out-edges of one relation) * max |g|
         return ops.transform_bwd_input(gagg, g, weight, root, graph=graph, amax=(g_amax, g_amax),
-                                       amax_mul=graph.weight_bound(True), packed=packed)   # autograd of A6 wrt x
+                                       amax_mul=graph.weight_bound(True), packed=packed,
+                                       precision=precision)                               # autograd of A6 wrt x
     wcat = torch.cat([weight.reshape(r * d_in, d_out), root]).view(1, (r + 1) * d_in, d_out)
-    t = ops.transform_bwd_input(g, g, wcat, None, amax=(g_amax, None))   # [N, (R+1) d_in] = g @ wcat^T
+    t = ops.transform_bwd_input(g, g, wcat, None, amax=(g_amax, None), precision=precision)   # [N, (R+1) d_in] = g @ wcat^T
     return ops.aggregate(merged, t.view(-1, d_in), tail=tail)
 
 
@@ -116,13 +118,14 @@ class _RGCNConvFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
-                graph: ops.BucketedGraph, relu: bool = False, gather_dtype=None) -> Tensor:
+                graph: ops.BucketedGraph, relu: bool = False, gather_dtype=None, half_backward: bool = False) -> Tensor:
         x = x.contiguous()
         weight = weight.contiguous()
         root_c = root.contiguous() if root is not None else None
         bias_c = bias.contiguous() if bias is not None else None
         ctx.gather_dtype = gather_dtype
         half = gather_dtype == torch.float16
+        ctx.bwd_precision = "half" if (half and half_backward and ops.GEMM_PRECISION == "split") else None
         scales = _Scales(x, slots=1)
         x_amax = scales.first            # also the bound of agg: a mean of rows cannot exceed the table's maximum
         packed = ops.split_weights(weight, root_c)                                    # once, for forward and backward
@@ -149,13 +152,14 @@ class _RGCNConvFunction(torch.autograd.Function):
         if need_w or (need_root and ctx.has_root) or (need_bias and ctx.has_bias):
             pending = ops.transform_bwd_params(agg, x, g, graph.num_relations, want_root=ctx.has_root,
                                                want_bias=ctx.has_bias, graph=graph, defer=True,
-                                               amax=(x_amax, x_amax, g_amax))
+                                               amax=(x_amax, x_amax, g_amax), precision=ctx.bwd_precision)
         if need_x:
-            gx = _input_grad(graph, g, weight, root, tail=pending, g_amax=g_amax, scales=scales, packed=ctx.packed)
+            gx = _input_grad(graph, g, weight, root, tail=pending, g_amax=g_amax, scales=scales, packed=ctx.packed,
+                             precision=ctx.bwd_precision)
         if pending is not None:
             pending.finish()                                                # no gather took it along
             gw, groot, gbias = pending.grads
-        return gx, gw, groot, gbias, None, None, None
+        return gx, gw, groot, gbias, None, None, None, None
 
 
 class _Encoder2Function(torch.autograd.Function):
@@ -171,10 +175,14 @@ class _Encoder2Function(torch.autograd.Function):
     (small) weight operand of that GEMM."""
 
     @staticmethod
-    def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph, gather_dtype=None, p: float = 0.0):
+    def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph, gather_dtype=None, p: float = 0.0,
+                half_backward: bool = False):
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
         ctx.gather_dtype = gather_dtype
         half = gather_dtype == torch.float16          # configs[4]: fp16 operands on the fp16 matrix cores too
+        # configs[4] backward: the three gradient GEMMs per layer in ONE fp16 pass (operands rounded under their
+        # per-tensor power-of-two scales = loss scaling per tensor, fp32 accumulate); the gradient gathers stay fp32
+        ctx.bwd_precision = "half" if (half and half_backward and ops.GEMM_PRECISION == "split") else None
         # operand scales of the split-precision transforms: max |.| of every dense tensor, left behind by
         # the kernel that produced it (one zeroed buffer per pass); None throughout in fp32 / fp16 mode
         # A dense tensor's maximum is left behind by the launch that produces it (the first launch of the pass
@@ -207,24 +215,25 @@ class _Encoder2Function(torch.autograd.Function):
         pk1, pk2 = ctx.packed
         wb = graph.weight_bound(True)        # |transposed aggregate| <= wb * max |gradient table|
         # the slab reductions of the parameter gradients ride in the transposed gathers that follow them
+        prec = ctx.bwd_precision
         red2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2, graph=graph,
-                                        defer=True, amax=(h_amax, h_amax, g_amax))
+                                        defer=True, amax=(h_amax, h_amax, g_amax), precision=prec)
         gagg2 = ops.aggregate(graph, g, transposed=True, tail=red2)
         if ctx.p > 0:
             scale = 1.0 / (1.0 - ctx.p)
             w2, root2 = w2 * scale, (root2 * scale if root2 is not None else None)
             pk2 = None                                                      # split for the unscaled weights
         gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph, amax=(g_amax, g_amax),
-                                     amax_mul=wb, amax_out=gz_amax, packed=pk2)   # d loss / d (pre-ReLU of conv1)
+                                     amax_mul=wb, amax_out=gz_amax, packed=pk2, precision=prec)   # d loss / d (pre-ReLU of conv1)
         red1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1, graph=graph,
-                                        defer=True, amax=(x_amax, x_amax, gz_amax))
+                                        defer=True, amax=(x_amax, x_amax, gz_amax), precision=prec)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = _input_grad(graph, gz, w1, root1, tail=red1, g_amax=gz_amax, scales=scales, packed=pk1)
+            gx = _input_grad(graph, gz, w1, root1, tail=red1, g_amax=gz_amax, scales=scales, packed=pk1, precision=prec)
         red2.finish()
         red1.finish()
         (gw2, groot2, gb2), (gw1, groot1, gb1) = red2.grads, red1.grads
-        return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None, None
+        return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None, None, None
 
 
 def _check_x(x: Tensor) -> None:
@@ -240,7 +249,7 @@ def _check_gather_dtype(gather_dtype) -> None:
 
 def rgcn_conv(x: Tensor, edge_index: Tensor, edge_type: Tensor, weight: Tensor,
               root: Optional[Tensor], bias: Optional[Tensor], num_relations: int,
-              activation: Optional[str] = None, gather_dtype=None) -> Tensor:
+              activation: Optional[str] = None, gather_dtype=None, half_backward: bool = False) -> Tensor:
     """Functional form on effective weights ``[R, d_in, d_out]``; ``activation='relu'`` fuses
     the ReLU into the layer; ``gather_dtype=torch.float16`` makes the forward gather read an fp16
     copy of the feature table (fp32 accumulate; BASELINE configs[4]); gradients stay fp32."""
@@ -249,7 +258,7 @@ def rgcn_conv(x: Tensor, edge_index: Tensor, edge_type: Tensor, weight: Tensor,
     if activation not in (None, "relu"):
         raise ValueError(f"activation must be None or 'relu', got {activation!r}")
     graph = ops.bucket(edge_index, edge_type, x.size(0), num_relations)
-    return _RGCNConvFunction.apply(x, weight, root, bias, graph, activation == "relu", gather_dtype)
+    return _RGCNConvFunction.apply(x, weight, root, bias, graph, activation == "relu", gather_dtype, half_backward)
 
 
 def rgcn_encoder2(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: "RGCNConv",
@@ -262,7 +271,7 @@ def rgcn_encoder2(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: "RGCN
     graph = ops.bucket(edge_index, edge_type, x.size(0), conv1.num_relations)
     return _Encoder2Function.apply(x, conv1.effective_weight(), conv1.root, conv1.bias,
                                    conv2.effective_weight(), conv2.root, conv2.bias, graph,
-                                   conv1.gather_dtype, float(dropout_p))
+                                   conv1.gather_dtype, float(dropout_p), conv1.half_backward)
 
 
 class RGCNConv(nn.Module):
@@ -277,10 +286,13 @@ class RGCNConv(nn.Module):
     def __init__(self, in_channels: Union[int, Tuple[int, int]], out_channels: int,
                  num_relations: int, num_bases: Optional[int] = None,
                  num_blocks: Optional[int] = None, aggr: str = "mean", root_weight: bool = True,
-                 is_sorted: bool = False, bias: bool = True, gather_dtype=None, **kwargs):
+                 is_sorted: bool = False, bias: bool = True, gather_dtype=None,
+                 half_backward: Optional[bool] = None, **kwargs):
         super().__init__()
         _check_gather_dtype(gather_dtype)
         self.gather_dtype = gather_dtype    # None/float32, or float16: fp16 row table, fp32 accumulate
+        # configs[4]: with the fp16 feature table the gradient GEMMs take fp16 operands too (fp32 accumulate)
+        self.half_backward = (gather_dtype == torch.float16) if half_backward is None else bool(half_backward)
         if num_bases is not None and num_blocks is not None:
             raise ValueError("Can not apply both basis-decomposition and "
                              "block-diagonal-decomposition at the same time.")
@@ -344,7 +356,7 @@ class RGCNConv(nn.Module):
         if x.dim() != 2 or x.size(1) != self.in_channels_l:
             raise ValueError(f"x must be [N, {self.in_channels_l}], got {tuple(x.shape)}")
         return rgcn_conv(x, edge_index, edge_type, self.effective_weight(), self.root, self.bias,
-                         self.num_relations, activation, self.gather_dtype)
+                         self.num_relations, activation, self.gather_dtype, self.half_backward)
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}({self.in_channels_l}, {self.out_channels}, "

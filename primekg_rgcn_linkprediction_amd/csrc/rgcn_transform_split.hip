@@ -194,7 +194,9 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_split(const float* __rest
 // workgroups per CU; 4 -> 128 x 128 tile, 512 threads, ring of 4 (128 KB), one workgroup per CU.  These
 // transforms run at the rate their LDS-DMA bytes in flight allow (about 96 KB per CU either way), and B -
 // the same 256 KB for every workgroup - is two thirds of the 64-row tile's traffic: 128 rows halve it.
-template <int WM, int TN, int EPI>
+// LO = false: ONE pass on the hi parts only - operands rounded to fp16 (under their per-tensor power-of-two
+// scales, which is loss scaling per tensor), fp32 accumulate: BASELINE configs[4]'s gradient GEMMs.
+template <int WM, int TN, int EPI, bool LO>
 __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restrict__ A1, int K1,
                                                             const float* __restrict__ A2, int K2,
                                                             const __half* __restrict__ Bh,
@@ -206,10 +208,11 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
                                                             int M, int N, const uint32_t* __restrict__ tile_mask,
                                                             int kseg, unsigned* __restrict__ amax_out) {
   constexpr int BM = 32 * WM, BN = 64 * TN, NBUF = WM == 2 ? 3 : 4, D = NBUF - 1;   // D k-tiles in flight
-  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + 2 * B_BYTES;
+  constexpr int PARTS = LO ? 2 : 1;              // B images staged: hi (and lo)
+  constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + PARTS * B_BYTES;
   constexpr int A_PW = 2;                        // A DMA instructions per wave and k-tile (8 rows of 128 B each)
   constexpr int B_PW = BN / (32 * WM);           // B DMA instructions per wave, k-tile and part (16 rows of 64 B each)
-  constexpr int P = A_PW + 2 * B_PW;
+  constexpr int P = A_PW + PARTS * B_PW;
   static_assert(B_PW >= 1 && A_PW * 8 * 2 * WM == BM, "tile / wave layout");
   __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF_BYTES];   // the ONLY LDS object
 
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
 #pragma unroll
     for (int j = 0; j < B_PW; ++j) {
       glds16(Bh + kt + b_off[j], sBh + (wave * B_PW + j) * 16 * BK * 2);
-      glds16(Bl + kt + b_off[j], sBl + (wave * B_PW + j) * 16 * BK * 2);
+      if (LO) glds16(Bl + kt + b_off[j], sBl + (wave * B_PW + j) * 16 * BK * 2);
     }
   };
 
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(fh[s][b]) : "v"(b_addr[b][s] + buf));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl[s][b]) : "v"(b_addr[b][s] + buf), "n"(B_BYTES));
+        if (LO) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fl[s][b]) : "v"(b_addr[b][s] + buf), "n"(B_BYTES));
       }
     }
     const int kt_new = ktq[D - 1] < K ? next_kt(ktq[D - 1]) : K;   // the DMA issue covers the LDS latency of the reads above
@@ -342,18 +345,12 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
     const float sa = tile_in_a1 ? sa1 : sa2;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      // step 0 may start once its own 2 + 2 TN reads are back (the last 2 + 2 TN issued are step 1's)
-      if (TN == 2) {
-        if (s == 0)
-          asm volatile("s_waitcnt lgkmcnt(6)"
-                       : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fh[0][0]), "+v"(fh[0][1]), "+v"(fl[0][0]), "+v"(fl[0][1]));
-        else
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fh[1][0]), "+v"(fh[1][1]), "+v"(fl[1][0]), "+v"(fl[1][1]));
-      } else {
-        if (s == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fh[0][0]), "+v"(fl[0][0]));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fh[1][0]), "+v"(fl[1][0]));
-      }
+      // step 0 may start once its own reads are back (the last 2 + PARTS TN issued are step 1's); the wait is
+      // tied to the registers it guards so that their uses stay below it
+      constexpr int kStepReads = 2 + PARTS * TN;
+      if (s == 0) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fh[0][0]), "+v"(fh[0][TN - 1]) : "n"(kStepReads));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fh[1][0]), "+v"(fh[1][TN - 1]));
+      if (LO) asm volatile("" : "+v"(fl[s][0]), "+v"(fl[s][TN - 1]));
       // split the lane's 8 k of A: v = a * 2^ea; hi = fp16(v); lo = fp16(v - hi)
       half8 ah, al;
 #pragma unroll
@@ -363,13 +360,16 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
           const float v = fa[s][q][c] * sa;
           const _Float16 h = (_Float16)v;
           ah[4 * q + c] = h;
-          al[4 * q + c] = (_Float16)(v - (float)h);
+          if (LO) al[4 * q + c] = (_Float16)(v - (float)h);
         }
 #pragma unroll
       for (int b = 0; b < TN; ++b) {             // small terms first
-        const half8 bh = __builtin_bit_cast(half8, fh[s][b]), bl = __builtin_bit_cast(half8, fl[s][b]);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+        const half8 bh = __builtin_bit_cast(half8, fh[s][b]);
+        if (LO) {
+          const half8 bl = __builtin_bit_cast(half8, fl[s][b]);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+        }
         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
       }
     }
@@ -465,6 +465,7 @@ __global__ __launch_bounds__(kThreads) void k_absmax_init(const float* __restric
 // root), which therefore never skips an m-tile.
 // ---------------------------------------------------------------------------------------
 constexpr int TN_TKC = 128;
+template <bool LO>                               // false: one pass on the hi parts (configs[4], see k_gemm_nt_split)
 __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __restrict__ A1, int K1,
                                                                 const float* __restrict__ A2, int K2,
                                                                 const float* __restrict__ G, int M, int N,
@@ -624,19 +625,21 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
         const float v = fa[s][j] * sa;
         const _Float16 h = (_Float16)v;
         ah[j] = h;
-        al[j] = (_Float16)(v - (float)h);
+        if (LO) al[j] = (_Float16)(v - (float)h);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const float u = fg[s][b][j] * sg;
           const _Float16 hg = (_Float16)u;
           gh[b][j] = hg;
-          gl[b][j] = (_Float16)(u - (float)hg);
+          if (LO) gl[b][j] = (_Float16)(u - (float)hg);
         }
       }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh[b], acc[b], 0, 0, 0);
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl[b], acc[b], 0, 0, 0);
+        if (LO) {
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh[b], acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl[b], acc[b], 0, 0, 0);
+        }
         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh[b], acc[b], 0, 0, 0);
       }
     }
@@ -713,7 +716,7 @@ size_t nt_workspace_bytes(int64_t R, int64_t d_in, int64_t d_out) {
 int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __half* Bh, const __half* Bl,
                     const float* b_inv, const float* bias, const float* mask, int epi, float* C, int M, int N,
                     const uint32_t* tile_mask, int kseg, const float* a1_amax, float a1_mul, const float* a2_amax,
-                    float* c_amax, float* scan_slots, hipStream_t stream) {
+                    float* c_amax, float* scan_slots, bool half, hipStream_t stream) {
   const int K = K1 + K2;
   if (K1 % BK || K2 % BK || K <= 0) return RGCN_ERR_UNSUPPORTED;
   // maxima of the A operands: from their producers, or scanned here (one launch over what is missing)
@@ -730,9 +733,14 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
   if (!r1.slots) { r1 = r2; r2 = amax_ref{nullptr, 0}; a1_mul = 1.f; }   // the kernels read r1 unconditionally
   if (kseg <= 0 || kseg % BK != 0) tile_mask = nullptr;
   unsigned* amax_out = reinterpret_cast<unsigned*>(c_amax);
-#define RGCN_NT_SPLIT(WM_, TN_, EPI_)                                                                                   \
-  k_gemm_nt_split<WM_, TN_, EPI_><<<grid, 128 * WM_, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, \
-                                                            C, M, N, tile_mask, kseg, amax_out)
+#define RGCN_NT_LAUNCH(WM_, TN_, EPI_, LO_)                                                                          \
+  k_gemm_nt_split<WM_, TN_, EPI_, LO_><<<grid, 128 * WM_, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, \
+                                                                        bias, mask, C, M, N, tile_mask, kseg, amax_out)
+#define RGCN_NT_SPLIT(WM_, TN_, EPI_)        \
+  do {                                       \
+    if (half) RGCN_NT_LAUNCH(WM_, TN_, EPI_, false); \
+    else RGCN_NT_LAUNCH(WM_, TN_, EPI_, true);       \
+  } while (0)
   if (N <= 64) {
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
     if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 1, EPI_RELU);
@@ -749,6 +757,7 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
     else if (epi == EPI_MASK) RGCN_NT_SPLIT(4, 2, EPI_MASK);
     else RGCN_NT_SPLIT(4, 2, EPI_NONE);
   }
+#undef RGCN_NT_LAUNCH
 #undef RGCN_NT_SPLIT
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
@@ -816,7 +825,7 @@ size_t rgcn_transform_split_workspace_bytes(int64_t R, int64_t d_in, int64_t d_o
 int rgcn_transform_fwd_split(const float* agg, const float* x, const float* weight, const float* root,
                              const void* packed, const float* bias, int relu, const uint32_t* tile_mask, int64_t N,
                              int64_t R, int64_t d_in, int64_t d_out, const float* agg_amax, float agg_amax_mul,
-                             const float* x_amax, float* out, float* out_amax, void* workspace,
+                             const float* x_amax, int half, float* out, float* out_amax, void* workspace,
                              size_t workspace_bytes, void* stream_) {
   if (bad_dims(N, R, d_in, d_out) || !out) return RGCN_ERR_ARG;
   if (N == 0) return RGCN_OK;
@@ -834,14 +843,15 @@ int rgcn_transform_fwd_split(const float* agg, const float* x, const float* weig
   float* scan = (float*)((char*)workspace + packed_bytes(R, d_in, d_out));
   const int K1 = (int)(R * d_in), K2 = root ? (int)d_in : 0;
   return launch_nt_split(agg, K1, x, K2, v.Bh_f, v.Bl_f, v.inv_scale, bias, nullptr, relu ? EPI_RELU : EPI_NONE, out,
-                         (int)N, (int)d_out, tile_mask, (int)d_in, agg_amax, agg_amax_mul, x_amax, out_amax, scan, stream);
+                         (int)N, (int)d_out, tile_mask, (int)d_in, agg_amax, agg_amax_mul, x_amax, out_amax, scan, half != 0,
+                         stream);
 }
 
 int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const float* weight, const float* root,
                                    const void* packed, const float* relu_mask, const uint32_t* tile_mask, int64_t N,
                                    int64_t R, int64_t d_in, int64_t d_out, const float* gagg_amax,
-                                   float gagg_amax_mul, const float* g_amax, float* grad_x, float* grad_x_amax,
-                                   void* workspace, size_t workspace_bytes, void* stream_) {
+                                   float gagg_amax_mul, const float* g_amax, int half, float* grad_x,
+                                   float* grad_x_amax, void* workspace, size_t workspace_bytes, void* stream_) {
   if (bad_dims(N, R, d_in, d_out) || !grad_x) return RGCN_ERR_ARG;
   if (N == 0) return RGCN_OK;
   if (!gagg || !g || !weight) return RGCN_ERR_ARG;
@@ -859,7 +869,7 @@ int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const floa
   const int K1 = (int)(R * d_out), K2 = root ? (int)d_out : 0;
   return launch_nt_split(gagg, K1, g, K2, v.Bh_b, v.Bl_b, v.inv_scale, nullptr, relu_mask,
                          relu_mask ? EPI_MASK : EPI_NONE, grad_x, (int)N, (int)d_in, tile_mask, (int)d_out, gagg_amax,
-                         gagg_amax_mul, g_amax, grad_x_amax, scan, stream);
+                         gagg_amax_mul, g_amax, grad_x_amax, scan, half != 0, stream);
 }
 
 size_t rgcn_transform_bwd_params_split_workspace_bytes(int64_t N, int64_t R, int64_t d_in, int64_t d_out) {
@@ -870,7 +880,8 @@ size_t rgcn_transform_bwd_params_split_workspace_bytes(int64_t N, int64_t R, int
 int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, const float* g,
                                           const uint32_t* tile_mask, int64_t N, int64_t R, int64_t d_in,
                                           int64_t d_out, const float* agg_amax, float agg_amax_mul,
-                                          const float* x_amax, const float* g_amax, float* grad_weight, float* grad_root,
+                                          const float* x_amax, const float* g_amax, int half, float* grad_weight,
+                                          float* grad_root,
                                           float* grad_bias, void* workspace, size_t workspace_bytes, void* stream_,
                                           rgcn_slab_job* job) {
   if (!job) return RGCN_ERR_ARG;
@@ -907,8 +918,14 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
   const uint32_t* tmask = (d_in % 64 == 0) ? tile_mask : nullptr;
   float* bp = grad_bias ? bias_part : nullptr;
-  k_gemm_tn_split<<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles, p.rows_per_split,
-                                                     r1, a1_mul, r2, rg, slab, bp, tmask, (int)d_in);
+  if (half)
+    k_gemm_tn_split<false><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
+                                                              p.rows_per_split, r1, a1_mul, r2, rg, slab, bp, tmask,
+                                                              (int)d_in);
+  else
+    k_gemm_tn_split<true><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
+                                                             p.rows_per_split, r1, a1_mul, r2, rg, slab, bp, tmask,
+                                                             (int)d_in);
   RGCN_HIP_TRY(hipGetLastError());
   job->slab = slab;
   job->bias_part = bias_part;

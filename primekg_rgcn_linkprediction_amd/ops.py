@@ -82,11 +82,16 @@ if GEMM_PRECISION not in ("split", "fp32"):
     raise ValueError(f"RGCN_GEMM_PRECISION must be 'split' or 'fp32', got {GEMM_PRECISION!r}")
 
 
-def _use_split(precision: Optional[str], k_dim: int, multiple: int) -> bool:
+def _use_split(precision: Optional[str], k_dim: int, multiple: int) -> int:
+    """0: the fp32 kernels; 1: split precision (three fp16 MFMA passes); 2: ``"half"`` - one pass, operands
+    rounded to fp16 under their per-tensor scales, fp32 accumulate (BASELINE configs[4]'s gradient GEMMs).
+    Widths the split kernels do not tile run the fp32 kernels (more precise, never less)."""
     mode = GEMM_PRECISION if precision is None else precision
-    if mode not in ("split", "fp32"):
-        raise ValueError(f"precision must be 'split' or 'fp32', got {mode!r}")
-    return mode == "split" and k_dim % multiple == 0
+    if mode not in ("split", "fp32", "half"):
+        raise ValueError(f"precision must be 'split', 'half' or 'fp32', got {mode!r}")
+    if mode == "fp32" or k_dim % multiple:
+        return 0
+    return 2 if mode == "half" else 1
 
 
 # An "amax buffer" (include/rgcn_hip.h, RGCN_AMAX_FLOATS): AMAX_FLOATS floats; its VALUE, max |tensor|, is the
@@ -155,7 +160,7 @@ def split_weights(weight: torch.Tensor, root: Optional[torch.Tensor]) -> Optiona
     if weight.dim() != 3:
         raise ValueError("weight must be [R, d_in, d_out]")
     r, d_in, d_out = weight.shape
-    if GEMM_PRECISION != "split" or d_in % 32 or d_out % 32:
+    if GEMM_PRECISION == "fp32" or d_in % 32 or d_out % 32:
         return None
     if root is not None:
         _need_gpu("root", root, torch.float32)
@@ -636,7 +641,8 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
     n, r, d_in, d_out = _check_layer(agg, x, weight, root, bias)
     lib = _lib.load()
     _check_amax("amax_out", amax_out, x.device)
-    if not half and _use_split(precision, d_in, 32) and n > 0:
+    split = 0 if half else _use_split(precision, d_in, 32)
+    if split and n > 0:
         a1, a2 = amax if amax is not None else (None, None)
         _check_amax("agg_amax", a1, x.device)
         _check_amax("x_amax", a2, x.device)
@@ -646,12 +652,12 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
             out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
             nbytes = lib.rgcn_transform_split_workspace_bytes(r, d_in, d_out)
             ws = _workspace(nbytes, x.device)
-            with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "split"):
+            with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "split" if split == 1 else "half"):
                 rc = lib.rgcn_transform_fwd_split(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root),
                                                   _ptr(packed.buf) if packed is not None else None, _ptr(bias),
                                                   int(relu), _mask_for(graph, False, n, r), n, r, d_in, d_out,
-                                                  _ptr(a1), float(amax_mul), _ptr(a2), _ptr(out), _ptr(amax_out),
-                                                  _ptr(ws), nbytes, _stream())
+                                                  _ptr(a1), float(amax_mul), _ptr(a2), int(split == 2), _ptr(out),
+                                                  _ptr(amax_out), _ptr(ws), nbytes, _stream())
         _lib.check(rc, "rgcn_transform_fwd_split")
         return out
     if half and d_in % 32 == 0:
@@ -702,7 +708,8 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
     _check_amax("amax_out", amax_out, g.device)
     if d_in % 4 or d_out % 4:
         raise ValueError("in/out channels must be multiples of 4")
-    if _use_split(precision, d_out, 32) and n > 0:
+    split = _use_split(precision, d_out, 32)
+    if split and n > 0:
         a1, a2 = amax if amax is not None else (None, None)
         _check_amax("gagg_amax", a1, g.device)
         _check_amax("g_amax", a2, g.device)
@@ -712,12 +719,12 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
             gx = torch.empty(n, d_in, dtype=torch.float32, device=g.device)
             nbytes = lib.rgcn_transform_split_workspace_bytes(r, d_in, d_out)
             ws = _workspace(nbytes, g.device)
-            with _GemmBracket("bwd_input", n, (r + (root is not None)) * d_out, d_in, "split"):
+            with _GemmBracket("bwd_input", n, (r + (root is not None)) * d_out, d_in, "split" if split == 1 else "half"):
                 rc = lib.rgcn_transform_bwd_input_split(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root),
                                                         _ptr(packed.buf) if packed is not None else None,
                                                         _ptr(relu_mask), _mask_for(graph, True, n, r), n, r, d_in,
-                                                        d_out, _ptr(a1), float(amax_mul), _ptr(a2), _ptr(gx),
-                                                        _ptr(amax_out), _ptr(ws), nbytes, _stream())
+                                                        d_out, _ptr(a1), float(amax_mul), _ptr(a2), int(split == 2),
+                                                        _ptr(gx), _ptr(amax_out), _ptr(ws), nbytes, _stream())
         _lib.check(rc, "rgcn_transform_bwd_input_split")
         return gx
     with _on(g.device):
@@ -750,17 +757,19 @@ def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, 
         gw = torch.empty(r, d_in, d_out, dtype=torch.float32, device=x.device)
         groot = torch.empty(d_in, d_out, dtype=torch.float32, device=x.device) if want_root else None
         gbias = torch.empty(d_out, dtype=torch.float32, device=x.device) if want_bias else None
-        if _use_split(precision, d_in, 64) and n > 0:
+        split = _use_split(precision, d_in, 64)
+        if split and n > 0:
             a1, a2, a3 = amax if amax is not None else (None, None, None)
             for nm, t in (("agg_amax", a1), ("x_amax", a2), ("g_amax", a3)):
                 _check_amax(nm, t, x.device)
             nbytes = lib.rgcn_transform_bwd_params_split_workspace_bytes(n, r, d_in, d_out)
             ws = _workspace(nbytes, x.device)
             job = _lib.SlabJob()
-            with _GemmBracket("bwd_params", (r + want_root) * d_in, n, d_out, "split"):
+            with _GemmBracket("bwd_params", (r + want_root) * d_in, n, d_out, "split" if split == 1 else "half"):
                 rc = lib.rgcn_transform_bwd_params_split_begin(_ptr(agg), _ptr(x), _ptr(g),
                                                                _mask_for(graph, False, n, r), n, r, d_in, d_out,
-                                                               _ptr(a1), float(amax_mul), _ptr(a2), _ptr(a3), _ptr(gw), _ptr(groot),
+                                                               _ptr(a1), float(amax_mul), _ptr(a2), _ptr(a3),
+                                                               int(split == 2), _ptr(gw), _ptr(groot),
                                                                _ptr(gbias), _ptr(ws), nbytes, _stream(),
                                                                ctypes.byref(job))
             _lib.check(rc, "rgcn_transform_bwd_params_split_begin")

@@ -292,6 +292,33 @@ def test_transform_kernels(n, r, d_in, d_out, precision):
     assert groot2 is None and gbias2 is None and rel_err(gw2, gw.cpu()) <= 1e-6
 
 
+def test_one_pass_fp16_gradient_gemms_equal_their_rounded_operand_meaning():
+    """precision="half" (configs[4]'s gradient GEMMs): each operand rounded to fp16 under its tensor's
+    power-of-two scale, exact products, fp32 sums - against that meaning in float64, gradient-sized inputs"""
+    dev = need_gpu()
+    n, r, d_in, d_out = 1500, 3, 64, 128
+    gen = torch.Generator().manual_seed(21)
+    agg, x = torch.randn(n, r * d_in, generator=gen) * 0.01, torch.randn(n, d_in, generator=gen) * 0.01
+    w, root = torch.randn(r, d_in, d_out, generator=gen) * 0.1, torch.randn(d_in, d_out, generator=gen) * 0.1
+    g, gagg = torch.randn(n, d_out, generator=gen) * 1e-7, torch.randn(n, r * d_out, generator=gen) * 3e-7
+    rs = lambda t: O._r16_scaled(t.double())                                        # noqa: E731
+    A, X, W, Rt, G, GA = (t.to(dev) for t in (agg, x, w, root, g, gagg))
+    wcat = rs(torch.cat([w.reshape(-1, d_out), root]))
+    a_sc = rs(torch.cat([agg, x], 1))
+    gw, groot, gbias = ops.transform_bwd_params(A, X, G, r, precision="half")
+    want = a_sc.t() @ rs(g)
+    assert rel_err(gw, want[: r * d_in].view(r, d_in, d_out)) <= 2e-6 and rel_err(groot, want[r * d_in:]) <= 2e-6
+    assert rel_err(gbias, g.double().sum(0)) <= 2e-6                                # the column sums stay fp32
+    wt = rs(torch.cat([w.transpose(1, 2).reshape(-1, d_in), root.t()]))
+    want_gx = rs(gagg) @ wt[: r * d_out] + rs(g) @ wt[r * d_out:]
+    gx = ops.transform_bwd_input(GA, G, W, Rt, precision="half")
+    assert rel_err(gx, want_gx) <= 2e-6
+    full = ops.transform_bwd_input(GA, G, W, Rt, precision="split")
+    assert 1e-5 < rel_err(gx, full.cpu()) < 3e-3                                    # it IS fp16 operand arithmetic
+    out = ops.transform_fwd(A, X, W, Rt, None, precision="half")
+    assert rel_err(out, a_sc @ wcat) <= 2e-6
+
+
 @pytest.mark.parametrize("a_scale,b_scale,g_scale", [(1e-6, 1.0, 1e-7), (3e4, 1e-3, 1e5), (1.0, 1e-9, 1e-12),
                                                      (1e-20, 1e10, 1e15)])
 def test_split_precision_scales_with_the_operands(a_scale, b_scale, g_scale):
@@ -933,11 +960,14 @@ def test_fp16_matrix_core_transform_respects_relation_masks():
                        ops.transform_fwd(agg, x, w, root, None, half=True))       # skipped tiles were exact zeros
 
 
-def test_config_c5_fp16_features_exact_meaning_and_fp32_oracle():
+@pytest.mark.parametrize("half_backward", [True, False])
+def test_config_c5_fp16_features_exact_meaning_and_fp32_oracle(half_backward):
     """configs[4]: PrimeKG shape, fp16 feature tables + fp16 matrix-core transforms, fp32 accumulate.
-    Gate: the path's EXACT MEANING (``O.encoder_explicit_f64(half_forward=True)``: fp16-rounded gather
-    tables and GEMM operands in the forward, the fp32 backward formulas on the saved forward tensors, the
-    device's own ReLU decisions) - forward 1e-5, every gradient 1e-4.  Against the fp32 oracle the
+    Gate: the path's EXACT MEANING (``O.encoder_explicit_f64(half_forward=True, half_backward=...)``:
+    fp16-rounded gather tables and GEMM operands in the forward; in the backward the fp32 formulas on the
+    saved forward tensors - with ``half_backward`` (the default of an fp16 layer) the operands of the three
+    gradient GEMMs per layer rounded to fp16 under their per-tensor power-of-two scales, one matrix-core
+    pass, fp32 accumulate; the device's own ReLU decisions) - forward 1e-5, every gradient 1e-4.  Against the fp32 oracle the
     forward keeps SURVEY 8d's 2e-3 gate; the gradient distance to the fp32 oracle is REPORTED, not
     gated: rounding the features flips the ReLU of the pre-activations within fp16 precision of zero,
     which no fp16 feature path can avoid (observed 6e-3 .. 7e-3 relative L2)."""
@@ -945,10 +975,12 @@ def test_config_c5_fp16_features_exact_meaning_and_fp32_oracle():
     ei, et, n, r = synth.primekg_like(seed=42)
     torch.manual_seed(5)
     emb = torch.nn.init.xavier_uniform_(torch.empty(n, 64))
-    convs = [RGCNConv(64, 128, r, gather_dtype=torch.float16), RGCNConv(128, 128, r, gather_dtype=torch.float16)]
+    convs = [RGCNConv(64, 128, r, gather_dtype=torch.float16, half_backward=half_backward),
+             RGCNConv(128, 128, r, gather_dtype=torch.float16, half_backward=half_backward)]
+    assert RGCNConv(64, 128, r, gather_dtype=torch.float16).half_backward and not RGCNConv(64, 128, r).half_backward
     for c in convs:
         c.bias.data.uniform_(-0.1, 0.1)
-    cot = torch.randn(n, 128)
+    cot = torch.randn(n, 128) * 1e-6                    # gradient-sized: fp16 operands without scaling would underflow
     ref_p = [{k: v.detach().clone().requires_grad_(True) for k, v in c.named_parameters()} for c in convs]
     e_ref = emb.clone().requires_grad_(True)
     out_ref = O.encoder_ref(e_ref, ref_p[0], ref_p[1], ei, et)
@@ -962,7 +994,7 @@ def test_config_c5_fp16_features_exact_meaning_and_fp32_oracle():
         mask = (convs[0](emb.to(dev), eid, etd, activation="relu") > 0).cpu()
     p64 = [{k: v.detach() for k, v in rp.items()} for rp in ref_p]
     exact = O.encoder_explicit_f64(emb, p64[0], p64[1], ei, et, cot, relu_mask=mask, half_forward=True,
-                                   half_backward=getattr(convs[0], "half_backward", False))
+                                   half_backward=half_backward)
     assert_fwd(out, exact["out"], 1e-5)
     assert_grad(e_gpu.grad, exact["grads"]["emb"])
     for name, c in zip(("conv1", "conv2"), convs):
@@ -974,7 +1006,7 @@ def test_config_c5_fp16_features_exact_meaning_and_fp32_oracle():
         want = want.double()
         return ((got.double().cpu() - want).norm() / want.norm()).item()
 
-    _record("C5", fwd_max_abs_vs_exact_meaning=(out.double().cpu() - exact["out"]).abs().max(),
+    _record("C5_half_backward" if half_backward else "C5_fp32_backward", fwd_max_abs_vs_exact_meaning=(out.double().cpu() - exact["out"]).abs().max(),
             fwd_rel_vs_oracle32=rel_err(out, out_ref.detach()),
             grad_emb_rel_vs_exact_meaning=rel_err(e_gpu.grad, exact["grads"]["emb"]),
             grad_params_rel_vs_exact_meaning_max=max(rel_err(v.grad, exact["grads"][f"{name}.{k}"])
