@@ -236,6 +236,51 @@ class _Encoder2Function(torch.autograd.Function):
         return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None, None, None
 
 
+# No-grad encoder (``DrugDiseaseModel.get_embeddings / predict / predict_all_tails``, ``Trainer.validate``,
+# ``ModelEvaluator``: src/train.py:389-395, src/evaluate.py:189-195, 251-254): nothing needs the aggregate
+# afterwards, so it is never materialised as one [N, R * d] tensor once that would exceed _EVAL_BLOCK_BYTES:
+# the destination rows are walked in blocks - gather a block into ONE reused buffer, transform it straight
+# into its rows of the output, next block.  Same kernels, same per-segment order: results equal the training
+# path's bit for bit.
+# What this buys is MEMORY (C4 on one GPU, 2-layer forward: peak 5.10 GiB -> 1.32 GiB with 32 MB blocks), not
+# traffic: measured with rocprofv3 FETCH_SIZE / WRITE_SIZE the HBM-side bytes of the blocked forward are not
+# lower (a block written by one launch is re-read by the next through the memory side: the 4 MB L2s are per XCD
+# and the 256 MB Infinity Cache is already cycling the 256 MB row table), and 128 blocks x 3 launches per layer
+# cost time (13.5 ms against 5.95 ms per forward; tools/eval_blocks_probe.py).  Hence the default block is
+# large - 1 GiB: C2 runs as one block, C4 as four - and DESIGN.md section 9 says what a real fusion of the
+# gather into the transform's A tile would have to look like.
+_EVAL_BLOCK_BYTES = int(_os.environ.get("RGCN_EVAL_BLOCK_BYTES", str(1 << 30)))
+
+
+def _layer_eval_blocked(graph: "ops.BucketedGraph", x: Tensor, table: Tensor, weight: Tensor, root, bias, relu: bool,
+                        half: bool, amax, amax_out, packed) -> Tensor:
+    n, r, d_in, d_out = x.size(0), graph.num_relations, x.size(1), weight.size(2)
+    rows = max(32, _EVAL_BLOCK_BYTES // max(1, r * d_in * 4))
+    out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
+    if rows >= n:                                   # one block: the plain two launches, a temporary aggregate
+        agg = ops.aggregate(graph, table)
+        return ops.transform_fwd(agg, x, weight, root, bias, relu=relu, graph=graph, half=half, amax=amax,
+                                 amax_out=amax_out, packed=packed, out=out)
+    blocks = graph.row_blocks(rows)
+    buf = torch.empty(blocks[0][1] - blocks[0][0], r * d_in, dtype=torch.float32, device=x.device)
+    for lo, hi, shard in blocks:
+        agg = ops.aggregate(shard, table, out=buf[: hi - lo])
+        ops.transform_fwd(agg, x[lo:hi], weight, root, bias, relu=relu, graph=shard, half=half, amax=amax,
+                          amax_out=amax_out, packed=packed, out=out[lo:hi])
+    return out
+
+
+def encoder2_eval(x: Tensor, graph: "ops.BucketedGraph", w1, root1, b1, w2, root2, b2, gather_dtype=None) -> Tensor:
+    """conv2(relu(conv1(x))) with nothing kept for a backward and no whole-graph aggregate (see above)"""
+    x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
+    half = gather_dtype == torch.float16
+    scales = _Scales(x)
+    x_amax, h_amax = scales.first, scales.slot()
+    pk1, pk2 = ops.split_weights(w1, root1), ops.split_weights(w2, root2)
+    h = _layer_eval_blocked(graph, x, _table(x, gather_dtype), w1, root1, b1, True, half, (x_amax, x_amax), h_amax, pk1)
+    return _layer_eval_blocked(graph, h, _table(h, gather_dtype), w2, root2, b2, False, half, (h_amax, h_amax), None, pk2)
+
+
 def _check_x(x: Tensor) -> None:
     if x.dtype != torch.float32:
         raise TypeError(f"x must be float32 (got {x.dtype}); integer-index / embedding mode of "
@@ -269,6 +314,10 @@ def rgcn_encoder2(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: "RGCN
     if not 0.0 <= dropout_p < 1.0:
         raise ValueError(f"dropout_p must be in [0, 1), got {dropout_p}")
     graph = ops.bucket(edge_index, edge_type, x.size(0), conv1.num_relations)
+    tensors = [x] + list(conv1.parameters()) + list(conv2.parameters())
+    if dropout_p == 0.0 and not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors)):
+        return encoder2_eval(x, graph, conv1.effective_weight(), conv1.root, conv1.bias, conv2.effective_weight(),
+                             conv2.root, conv2.bias, conv1.gather_dtype)       # nothing to differentiate, no dropout
     return _Encoder2Function.apply(x, conv1.effective_weight(), conv1.root, conv1.bias,
                                    conv2.effective_weight(), conv2.root, conv2.bias, graph,
                                    conv1.gather_dtype, float(dropout_p), conv1.half_backward)

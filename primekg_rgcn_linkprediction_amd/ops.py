@@ -358,6 +358,32 @@ class BucketedGraph:
         _lib.check(rc, "rgcn_graph_export")
         return rowptr, col, perm, val
 
+    def row_blocks(self, block_rows: int):
+        """The forward structure cut into consecutive destination-row blocks of ``block_rows`` rows, each a shard
+        structure of its own over the SAME source table: ``[(lo, hi, BucketedGraph), ...]``, built once (cached
+        per block size) from the bucketed arrays - a block's edges are already in (row, relation, original
+        column) order, so its stable re-bucketing keeps every segment's summation order.  The no-grad encoder
+        walks these blocks (gather a block, transform it, next) so that the aggregate exists one cache-sized
+        block at a time instead of as an ``[N, R * d]`` tensor in HBM."""
+        if self.bipartite:
+            raise ValueError("row blocks are cut from a whole graph")
+        block_rows = max(32, (int(block_rows) + 31) // 32 * 32)
+        cache = self.__dict__.setdefault("_row_blocks", {})
+        if block_rows not in cache:
+            n, r = self.num_nodes, self.num_relations
+            rowptr, col, _, _ = self.arrays(False)
+            rp = rowptr.long()
+            blocks = []
+            for lo in range(0, n, block_rows):
+                hi = min(n, lo + block_rows)
+                e0, e1 = int(rp[lo * r]), int(rp[hi * r])
+                counts = rp[lo * r + 1: hi * r + 1] - rp[lo * r: hi * r]
+                seg = torch.repeat_interleave(torch.arange((hi - lo) * r, device=self.device), counts)
+                shard = BucketedGraph.from_shard(seg // r, col[e0:e1].long(), seg % r, hi - lo, n, r)
+                blocks.append((lo, hi, shard))
+            cache[block_rows] = blocks
+        return cache[block_rows]
+
     def merged_transposed(self) -> Optional["BucketedGraph"]:
         """The out-edges of every node across ALL relations as one weighted gather structure over
         a table of ``N * (R + 1)`` rows: edge (j -> i, r) reads row ``i * (R + 1) + r`` with weight
@@ -387,6 +413,9 @@ class BucketedGraph:
         if merged is not None:
             merged.destroy()
             self._merged = None
+        for blocks in self.__dict__.pop("_row_blocks", {}).values():
+            for _, _, shard in blocks:
+                shard.destroy()
         if self._handle is not None:
             try:
                 _lib.load().rgcn_graph_destroy(self._handle)
@@ -518,7 +547,8 @@ class PendingParamGrads:
 
 
 def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
-              tail: Optional[PendingParamGrads] = None, amax_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              tail: Optional[PendingParamGrads] = None, amax_out: Optional[torch.Tensor] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``[N, R*d]``: per-(dst, rel) mean of source rows (``transposed=False``) or the
     1/cnt-weighted sum over out-edges per (src, rel) (``transposed=True``).  For a shard
     (``BucketedGraph.from_shard``) x holds the gathered rows of all ranks and the result has
@@ -541,8 +571,13 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
     if amax_out is not None and half_in:
         raise ValueError("amax_out goes with the fp32 gather (the fp16 path's transform needs no scale)")
     lib = _lib.load()
+    if out is not None:
+        _need_gpu("out", out, torch.float32)
+        if tuple(out.shape) != (graph.num_nodes, graph.num_relations * d) or out.device != x.device:
+            raise ValueError(f"out must be [{graph.num_nodes}, {graph.num_relations * d}] on x's device")
     with _on(x.device):
-        out = torch.empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
         nbytes = graph.workspace_bytes(transposed, d)
         ws = _workspace(nbytes, x.device)
         if tail is not None and not tail.done and (half_in or GATHER_EVENTS is not None):
@@ -622,7 +657,8 @@ def _mask_for(graph: Optional[BucketedGraph], transposed: bool, n: int, r: int) 
 def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
                   graph: Optional[BucketedGraph] = None, half: bool = False, amax=None,
                   amax_out: Optional[torch.Tensor] = None, precision: Optional[str] = None,
-                  packed: Optional[SplitWeights] = None, amax_mul: float = 1.0) -> torch.Tensor:
+                  packed: Optional[SplitWeights] = None, amax_mul: float = 1.0,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``sum_r agg[:, r] @ weight[r] + x @ root + bias`` as one fp32-MFMA GEMM; ``relu``
     fuses the activation that follows conv1 (``rgcn.py:124``) into the epilogue.  ``graph``
     (the structure ``agg`` was aggregated over) lets the kernel skip the k-tiles of relations
@@ -641,6 +677,11 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
     n, r, d_in, d_out = _check_layer(agg, x, weight, root, bias)
     lib = _lib.load()
     _check_amax("amax_out", amax_out, x.device)
+    if out is not None:
+        _need_gpu("out", out, torch.float32)
+        if tuple(out.shape) != (n, d_out) or out.device != x.device:
+            raise ValueError(f"out must be [{n}, {d_out}] on x's device")
+    given_out = out
     split = 0 if half else _use_split(precision, d_in, 32)
     if split and n > 0:
         a1, a2 = amax if amax is not None else (None, None)
@@ -649,7 +690,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
         if packed is not None and not packed.matches(weight, root):
             raise ValueError("packed does not belong to these weights")
         with _on(x.device):
-            out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
+            out = given_out if given_out is not None else torch.empty(n, d_out, dtype=torch.float32, device=x.device)
             nbytes = lib.rgcn_transform_split_workspace_bytes(r, d_in, d_out)
             ws = _workspace(nbytes, x.device)
             with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "split" if split == 1 else "half"):
@@ -662,7 +703,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
         return out
     if half and d_in % 32 == 0:
         with _on(x.device):
-            out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
+            out = given_out if given_out is not None else torch.empty(n, d_out, dtype=torch.float32, device=x.device)
             nbytes = lib.rgcn_transform_fwd_f16_workspace_bytes(r, d_in, d_out)
             ws = _workspace(nbytes, x.device)
             with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "f16"):
@@ -674,7 +715,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
             absmax(out, amax_out)
         return out
     with _on(x.device):
-        out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
+        out = given_out if given_out is not None else torch.empty(n, d_out, dtype=torch.float32, device=x.device)
         with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "fp32"):
             rc = lib.rgcn_transform_fwd(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu),
                                         _mask_for(graph, False, n, r), n, r, d_in, d_out, _ptr(out), _stream())

@@ -776,6 +776,37 @@ def test_encoder_training_mode_uses_torch_dropout_stream():
     assert torch.equal(e1, e2)
 
 
+def test_no_grad_encoder_walks_row_blocks_and_equals_the_training_path(monkeypatch):
+    """eval path (get_embeddings / validate / evaluate: src/train.py:389-395, src/evaluate.py:189-195): no [N, R*d]
+    aggregate - destination rows in cache-sized blocks, one reused buffer - same bits as the training path's
+    forward, for one block, a few blocks and ragged last blocks; hubs inside a block keep their partial-row levels"""
+    from primekg_rgcn_linkprediction_amd import conv as C
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=200000, seed=12)
+    torch.manual_seed(3)
+    emb = torch.nn.init.xavier_uniform_(torch.empty(n, 64)).to(dev)
+    for gdt in (None, torch.float16):
+        convs = [RGCNConv(64, 128, r, gather_dtype=gdt).to(dev), RGCNConv(128, 128, r, gather_dtype=gdt).to(dev)]
+        for c in convs:
+            c.bias.data.uniform_(-0.1, 0.1)
+        eid, etd = ei.to(dev), et.to(dev)
+        e_train = emb.clone().requires_grad_(True)
+        want = rgcn_encoder2(e_train, eid, etd, convs[0], convs[1]).detach()       # the autograd node's forward
+        graph = ops.bucket(eid, etd, n, r)
+        for block_bytes in (1 << 40, 8 << 20, 3_000_000):
+            monkeypatch.setattr(C, "_EVAL_BLOCK_BYTES", block_bytes)
+            with torch.no_grad():
+                got = rgcn_encoder2(emb, eid, etd, convs[0], convs[1])
+            assert torch.equal(got, want), block_bytes
+        blocks = graph.row_blocks(3_000_000 // (r * 128 * 4))
+        assert len(blocks) > 3 and blocks[-1][1] == n and sum(b[2].num_edges for b in blocks) == ei.size(1)
+        assert graph.row_blocks(3_000_000 // (r * 128 * 4)) is blocks               # cached
+    # ops.aggregate(out=) / transform_fwd(out=) write where they are told
+    buf = torch.full((n, r * 64), 7.0, device=dev)
+    agg = ops.aggregate(graph, emb, out=buf)
+    assert agg.data_ptr() == buf.data_ptr() and torch.equal(agg, ops.aggregate(graph, emb))
+
+
 def test_functional_entry_and_r16():
     dev = need_gpu()
     ei, et, n, r = synth.uniform_graph(2000, 60000, 16, seed=4)     # C4's relation count, small N
