@@ -292,7 +292,6 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
   const int ea1 = scale_exponent(amax_of(amax1, lane) * a1_mul);
   const int ea2 = amax2.slots ? scale_exponent(amax_of(amax2, lane)) : ea1;
   const float sa1 = pow2f(ea1), sa2 = pow2f(ea2);
-  bool in_a1 = true;
 
   // byte addresses inside one buffer for the two 16-k steps of a k-tile
   const int arow = wm * 32 + li;
@@ -309,7 +308,12 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
     }
   }
 
-  for (int t = 0; ktq[0] < K; ++t) {
+  int t = 0;
+  // one k-tile: wait, barrier, fragment reads, next DMA issue, split of A, MFMAs.  `sa`: the scale of the A
+  // operand this tile lies in.  The k loop runs the A1 tiles, re-expresses the sums in A2's scale ONCE, then runs
+  // the A2 tiles - with the rescale inside one loop hipcc turns it into a select and multiplies all accumulators
+  // (and shuttles them between the register files) in EVERY iteration: 100 of 150 vector instructions per k-tile.
+  auto k_tile = [&](const float sa) {
     // k-tile ktq[0] has landed for this wave (all but the DMAs of the tiles staged behind it are done), then for
     // every wave; the barrier also says all waves are done reading the buffer the stage() below refills
     if (D == 3 && ktq[D - 1] < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
@@ -330,19 +334,10 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
     }
     const int kt_new = ktq[D - 1] < K ? next_kt(ktq[D - 1]) : K;   // the DMA issue covers the LDS latency of the reads above
     if (kt_new < K) stage(kt_new, (t + D) % NBUF);
-    const bool tile_in_a1 = ktq[0] < K1;
 #pragma unroll
     for (int j = 0; j + 1 < D; ++j) ktq[j] = ktq[j + 1];
     ktq[D - 1] = kt_new;
-    if (in_a1 && !tile_in_a1) {                  // first k-tile of A2: re-express the sums so far in A2's scale
-      in_a1 = false;
-      const float down = pow2f(-ea1);
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[b][r] = acc[b][r] * down * sa2;
-    }
-    const float sa = tile_in_a1 ? sa1 : sa2;
+    ++t;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       // step 0 may start once its own reads are back (the last 2 + PARTS TN issued are step 1's); the wait is
@@ -373,10 +368,19 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
         acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
       }
     }
+  };
+  while (ktq[0] < K1) k_tile(sa1);
+  if (K2 > 0) {                                  // sums so far -> A2's scale (two exact power-of-two factors)
+    const float down = pow2f(-ea1);
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] = acc[b][r] * down * sa2;
+    while (ktq[0] < K) k_tile(sa2);
   }
 
   // C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const float ia = pow2f(in_a1 ? -ea1 : -ea2), ib = b_inv_scale[0];   // two exact power-of-two factors
+  const float ia = pow2f(K2 > 0 ? -ea2 : -ea1), ib = b_inv_scale[0];   // two exact power-of-two factors
   float cmax = 0.f;
   if (m0 + BM <= M && n0 + BN <= N) {            // interior tile: straight-line stores (see k_gemm_nt_dma)
     float bv[TN];
