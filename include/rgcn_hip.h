@@ -266,12 +266,23 @@ int rgcn_slab_reduce(const rgcn_slab_job* job, void* stream);
  * same launch clears the heads of `zero_count` (<= 256) further amax buffers laid out back to back from
  * `zero_buffers` - the buffers the kernels of the coming pass publish into. */
 int rgcn_absmax(const float* x, int64_t n, float* out, float* zero_buffers, int zero_count, void* stream);
+/* The same for up to 8 tensors in the one launch, each into its own amax buffer: the embedding table AND the
+ * layers' weights at the start of a pass.  tensors / numels / outs: HOST arrays of `count` entries. */
+int rgcn_absmax_multi(int count, const float* const* tensors, const int64_t* numels, float* const* outs,
+                      float* zero_buffers, int zero_count, void* stream);
 /* The weights of one layer split ONCE per step for both transforms that multiply by them ([W ; root] as fp16
  * hi / lo images in the forward and in the input-gradient orientation, one scale): pass the result as `packed`
  * to the two calls below; with packed == NULL each call splits the weights itself (into its workspace). */
 size_t rgcn_weights_split_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
 int rgcn_weights_split_pack(const float* weight, const float* root, int64_t num_relations, int64_t d_in,
                             int64_t d_out, void* packed, size_t packed_bytes, void* stream);
+/* Up to 4 layers in ONE launch; w_amax[l] / r_amax[l]: the amax buffers of weights[l] and roots[l] when a
+ * previous launch (rgcn_absmax_multi) left them, else NULL arrays / entries (the kernel scans the weights itself).
+ * All array arguments are HOST arrays of `count` entries. */
+int rgcn_weights_split_pack_multi(int count, const float* const* weights, const float* const* roots,
+                                  const int64_t* num_relations, const int64_t* d_in, const int64_t* d_out,
+                                  const float* const* w_amax, const float* const* r_amax, void* const* packed,
+                                  const size_t* packed_bytes, void* stream);
 size_t rgcn_transform_split_workspace_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
 int rgcn_transform_fwd_split(const float* agg, const float* x, const float* weight, const float* root,
                              const void* packed, const float* bias, int relu, const uint32_t* tile_mask,

@@ -68,6 +68,8 @@ PROTOTYPES = {
     "rgcn_aggregate_and_reduce": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, POINTER(SlabJob), _P]),
     "rgcn_aggregate_amax": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, POINTER(SlabJob), _P, _P]),
     "rgcn_absmax": (c_int, [_P, _I64, _P, _P, c_int, _P]),
+    "rgcn_absmax_multi": (c_int, [c_int, _P, _P, _P, _P, c_int, _P]),
+    "rgcn_weights_split_pack_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rgcn_weights_split_bytes": (c_size_t, [_I64, _I64, _I64]),
     "rgcn_weights_split_pack": (c_int, [_P, _P, _I64, _I64, _I64, _P, c_size_t, _P]),
     "rgcn_transform_split_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),

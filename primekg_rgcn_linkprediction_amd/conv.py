@@ -67,11 +67,19 @@ class _Scales:
     the others, which the pass's kernels then publish their results' maxima into, handed out slot by
     slot.  In fp32 mode nothing is allocated and every slot is None."""
 
-    def __init__(self, t: Tensor, slots: int = 2):
+    def __init__(self, t: Tensor, slots: int = 2, weights=()):
+        """``weights``: further tensors (a layer's ``weight`` / ``root``) whose maxima the same first launch
+        takes - ``self.extra[i]`` (None for a None tensor) - so that splitting them needs no scan of its own"""
         self._buf, self._next, self.first = None, 1, None
+        self.extra = [None] * len(weights)
         if ops.GEMM_PRECISION == "split":
-            self._buf = torch.empty(slots, ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
-            self.first = ops.absmax(t, self._buf[0], clear=self._buf[1:])
+            present = [i for i, w in enumerate(weights) if w is not None]
+            self._buf = torch.empty(slots + len(present), ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
+            self.first = self._buf[0]
+            for j, i in enumerate(present):
+                self.extra[i] = self._buf[slots + j]
+            ops.absmax_many([t] + [weights[i] for i in present], [self.first] + [self.extra[i] for i in present],
+                            clear=self._buf[1:slots])
 
     def slot(self) -> Optional[Tensor]:
         if self._buf is None:
@@ -188,9 +196,10 @@ class _Encoder2Function(torch.autograd.Function):
         # A dense tensor's maximum is left behind by the launch that produces it (the first launch of the pass
         # for x, the epilogue of conv1's transform for h); an aggregate is scaled by the bound its table's
         # maximum gives (a mean of rows cannot exceed it), so the gathers publish nothing.
-        scales = _Scales(x)
+        scales = _Scales(x, weights=(w1, root1, w2, root2))          # ONE launch: max |x|, the weights' maxima, cleared slots
         x_amax, h_amax = scales.first, scales.slot()
-        pk1, pk2 = ops.split_weights(w1, root1), ops.split_weights(w2, root2)   # once, for forward and backward
+        wmax = None if scales.first is None else [(scales.extra[0], scales.extra[1]), (scales.extra[2], scales.extra[3])]
+        pk1, pk2 = ops.split_weights_many([(w1, root1), (w2, root2)], amax=wmax)   # once, for forward and backward
         agg1 = ops.aggregate(graph, _table(x, gather_dtype))
         h = ops.transform_fwd(agg1, x, w1, root1, b1, relu=True, graph=graph, half=half, amax=(x_amax, x_amax),
                               amax_out=h_amax, packed=pk1)
@@ -274,9 +283,10 @@ def encoder2_eval(x: Tensor, graph: "ops.BucketedGraph", w1, root1, b1, w2, root
     """conv2(relu(conv1(x))) with nothing kept for a backward and no whole-graph aggregate (see above)"""
     x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
     half = gather_dtype == torch.float16
-    scales = _Scales(x)
+    scales = _Scales(x, weights=(w1, root1, w2, root2))
     x_amax, h_amax = scales.first, scales.slot()
-    pk1, pk2 = ops.split_weights(w1, root1), ops.split_weights(w2, root2)
+    wmax = None if scales.first is None else [(scales.extra[0], scales.extra[1]), (scales.extra[2], scales.extra[3])]
+    pk1, pk2 = ops.split_weights_many([(w1, root1), (w2, root2)], amax=wmax)
     h = _layer_eval_blocked(graph, x, _table(x, gather_dtype), w1, root1, b1, True, half, (x_amax, x_amax), h_amax, pk1)
     return _layer_eval_blocked(graph, h, _table(h, gather_dtype), w2, root2, b2, False, half, (h_amax, h_amax), None, pk2)
 

@@ -121,42 +121,62 @@ __device__ inline float amax_of(const amax_ref& r, int lane) {
 // scans the (small, L2-resident) weights for their maximum itself - a second launch for it would cost more
 // than the redundant reads; scale_out[0] = 2^-eb for the consumers' epilogues.
 // ---------------------------------------------------------------------------------------
-constexpr int kPackThreads = 1024;
-__global__ __launch_bounds__(kPackThreads) void k_pack_split(const float* __restrict__ W, const float* __restrict__ Rt,
-                                                             int R, int d_in, int d_out,
-                                                             __half* __restrict__ Bh_f, __half* __restrict__ Bl_f,
-                                                             __half* __restrict__ Bh_b, __half* __restrict__ Bl_b,
-                                                             float* __restrict__ scale_out) {
+constexpr int kPackThreads = 1024, kPackJobs = 4;
+struct pack_job {
+  const float *W, *Rt;
+  int R, d_in, d_out;
+  const float *w_amax, *r_amax;                  // amax buffers of W and root (rgcn_absmax_multi), or NULL: scan here
+  __half *Bh_f, *Bl_f, *Bh_b, *Bl_b;
+  float* scale_out;
+};
+struct pack_jobs {
+  pack_job j[kPackJobs];
+};
+
+__global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ) {
   __shared__ float red[kPackThreads / 64];
+  const pack_job& J = JJ.j[blockIdx.y];          // one layer per grid row
+  const float* __restrict__ W = J.W;
+  const float* __restrict__ Rt = J.Rt;
+  const int R = J.R, d_in = J.d_in, d_out = J.d_out;
   const int lane = threadIdx.x & 63;
-  const int64_t wn4 = (int64_t)R * d_in * d_out / 4, rn4 = Rt ? (int64_t)d_in * d_out / 4 : 0;   // d_out % 4 == 0
   float m = 0.f;
-  auto scan = [&](const float* __restrict__ p, int64_t n4) {     // 8 independent loads per thread and round
-    const float4* p4 = reinterpret_cast<const float4*>(p);
-    for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 8 * kPackThreads) {
-      float4 v[8];
+  if (J.w_amax) {                                // maxima left by the pass's first launch: four loads per lane
+    m = rgcn_amax_value(J.w_amax, lane);
+    if (Rt) m = fmaxf(m, rgcn_amax_value(J.r_amax, lane));
+  } else {
+    const int64_t wn4 = (int64_t)R * d_in * d_out / 4, rn4 = Rt ? (int64_t)d_in * d_out / 4 : 0;   // d_out % 4 == 0
+    auto scan = [&](const float* __restrict__ p, int64_t n4) {     // 8 independent loads per thread and round
+      const float4* p4 = reinterpret_cast<const float4*>(p);
+      for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 8 * kPackThreads) {
+        float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t i = i0 + (int64_t)u * kPackThreads;
-        v[u] = i < n4 ? p4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 8; ++u) {
+          const int64_t i = i0 + (int64_t)u * kPackThreads;
+          v[u] = i < n4 ? p4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
       }
+    };
+    scan(W, wn4);
+    if (Rt) scan(Rt, rn4);
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
-    }
-  };
-  scan(W, wn4);
-  if (Rt) scan(Rt, rn4);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = red[lane & (kPackThreads / 64 - 1)];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if (lane == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  m = red[lane & (kPackThreads / 64 - 1)];
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  }
   const int eb = scale_exponent(m);
   const float sb = pow2f(eb);
-  if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = pow2f(-eb);
+  if (blockIdx.x == 0 && threadIdx.x == 0) J.scale_out[0] = pow2f(-eb);
+  __half* __restrict__ Bh_f = J.Bh_f;
+  __half* __restrict__ Bl_f = J.Bl_f;
+  __half* __restrict__ Bh_b = J.Bh_b;
+  __half* __restrict__ Bl_b = J.Bl_b;
   const int blocks = R + (Rt ? 1 : 0);
   const int Kf = blocks * d_in, Kb = blocks * d_out;
   const int64_t total = (int64_t)blocks * d_in * d_out;
@@ -432,25 +452,43 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
   if (amax_out) rgcn_amax_publish(amax_out, cmax, seen);
 }
 
-// max |x| into the amax buffer `out`, no atomics and no prior clearing: workgroup b of RGCN_AMAX_HEADS
-// writes its partial maximum to head b; it also ZEROES head b of `zero_count` further amax buffers that
-// start at `zero` (the buffers the kernels of this pass will publish into).
-__global__ __launch_bounds__(kThreads) void k_absmax_init(const float* __restrict__ p, int64_t n, float* __restrict__ out,
-                                                          float* __restrict__ zero, int zero_count) {
+// max |x| of up to kPrepTensors tensors, each into its own amax buffer, in ONE launch - no atomics and no prior
+// clearing: workgroup b of RGCN_AMAX_HEADS writes its partial maximum of every tensor to head b of that
+// tensor's buffer; it also ZEROES head b of `zero_count` further amax buffers that start at `zero` (the buffers
+// the kernels of the coming pass publish into).
+constexpr int kPrepTensors = 8;
+struct absmax_multi_job {
+  const float* p[kPrepTensors];
+  int64_t n[kPrepTensors];
+  float* out[kPrepTensors];
+  int count;
+};
+
+__global__ __launch_bounds__(kThreads) void k_absmax_multi(const absmax_multi_job J, float* __restrict__ zero,
+                                                           int zero_count) {
   __shared__ float red[kThreads / 64];
-  float m = 0.f;
-  const int64_t n4 = n >> 2;
-  const float4* p4 = reinterpret_cast<const float4*>(p);
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kThreads) {
-    const float4 v = p4[i];
-    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(p[n4 * 4 + threadIdx.x]));
+  for (int t = 0; t < J.count; ++t) {
+    const float* __restrict__ p = J.p[t];
+    const int64_t n = J.n[t], n4 = n >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    float m = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+      float4 v[4];                               // four independent loads per thread and round
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x * RGCN_AMAX_HEAD_STRIDE] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      for (int u = 0; u < 4; ++u) v[u] = (i0 + u * stride < n4) ? p4[i0 + u * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(p[n4 * 4 + threadIdx.x]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) J.out[t][blockIdx.x * RGCN_AMAX_HEAD_STRIDE] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+  }
   if ((int)threadIdx.x < zero_count) zero[(size_t)threadIdx.x * RGCN_AMAX_FLOATS + blockIdx.x * RGCN_AMAX_HEAD_STRIDE] = 0.f;
 }
 
@@ -692,13 +730,26 @@ PackedWeights packed_view(void* base, int64_t R, int64_t d_in, int64_t d_out) {
   return v;
 }
 
+pack_job make_pack_job(const float* weight, const float* root, int64_t R, int64_t d_in, int64_t d_out, void* packed,
+                       const float* w_amax, const float* r_amax) {
+  const PackedWeights v = packed_view(packed, R, d_in, d_out);
+  pack_job j{};
+  j.W = weight; j.Rt = root;
+  j.R = (int)R; j.d_in = (int)d_in; j.d_out = (int)d_out;
+  j.w_amax = w_amax; j.r_amax = root ? r_amax : nullptr;
+  if (root && !r_amax) j.w_amax = nullptr;                     // both maxima or none
+  j.Bh_f = v.Bh_f; j.Bl_f = v.Bl_f; j.Bh_b = v.Bh_b; j.Bl_b = v.Bl_b;
+  j.scale_out = v.inv_scale;
+  return j;
+}
+
 int pack_weights(const float* weight, const float* root, int64_t R, int64_t d_in, int64_t d_out, void* packed,
                  hipStream_t stream) {
-  const PackedWeights v = packed_view(packed, R, d_in, d_out);
-  const int64_t wn = R * d_in * d_out, rn = root ? d_in * d_out : 0;
-  const int pack_blocks = (int)std::min<int64_t>(64, ceil_div64(wn + rn, kPackThreads));
-  k_pack_split<<<pack_blocks, kPackThreads, 0, stream>>>(weight, root, (int)R, (int)d_in, (int)d_out, v.Bh_f, v.Bl_f,
-                                                         v.Bh_b, v.Bl_b, v.inv_scale);
+  pack_jobs JJ{};
+  JJ.j[0] = make_pack_job(weight, root, R, d_in, d_out, packed, nullptr, nullptr);
+  const int64_t total = (R + (root ? 1 : 0)) * d_in * d_out;
+  dim3 grid((unsigned)std::min<int64_t>(64, ceil_div64(total, kPackThreads)), 1);
+  k_pack_split<<<grid, kPackThreads, 0, stream>>>(JJ);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -800,12 +851,24 @@ size_t tn_workspace_bytes(int64_t N, int64_t R, int64_t d_in, int64_t d_out) {
 
 extern "C" {
 
-int rgcn_absmax(const float* x, int64_t n, float* out, float* zero_buffers, int zero_count, void* stream_) {
-  if (n < 0 || !out || (n > 0 && !x) || zero_count < 0 || zero_count > kThreads || (zero_count > 0 && !zero_buffers))
+int rgcn_absmax_multi(int count, const float* const* tensors, const int64_t* numels, float* const* outs,
+                      float* zero_buffers, int zero_count, void* stream_) {
+  if (count < 1 || count > kPrepTensors || !tensors || !numels || !outs || zero_count < 0 || zero_count > kThreads ||
+      (zero_count > 0 && !zero_buffers))
     return RGCN_ERR_ARG;
-  k_absmax_init<<<RGCN_AMAX_HEADS, kThreads, 0, (hipStream_t)stream_>>>(x, n, out, zero_buffers, zero_count);
+  absmax_multi_job J{};
+  J.count = count;
+  for (int t = 0; t < count; ++t) {
+    if (numels[t] < 0 || !outs[t] || (numels[t] > 0 && !tensors[t])) return RGCN_ERR_ARG;
+    J.p[t] = tensors[t]; J.n[t] = numels[t]; J.out[t] = outs[t];
+  }
+  k_absmax_multi<<<RGCN_AMAX_HEADS, kThreads, 0, (hipStream_t)stream_>>>(J, zero_buffers, zero_count);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
+}
+
+int rgcn_absmax(const float* x, int64_t n, float* out, float* zero_buffers, int zero_count, void* stream_) {
+  return rgcn_absmax_multi(1, &x, &n, &out, zero_buffers, zero_count, stream_);
 }
 
 size_t rgcn_weights_split_bytes(int64_t R, int64_t d_in, int64_t d_out) {
@@ -819,6 +882,28 @@ int rgcn_weights_split_pack(const float* weight, const float* root, int64_t R, i
   if ((R + 1) * d_in > (1 << 24) || (R + 1) * d_out > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
   if (!packed || packed_bytes_ < packed_bytes(R, d_in, d_out)) return RGCN_ERR_WORKSPACE;
   return pack_weights(weight, root, R, d_in, d_out, packed, (hipStream_t)stream_);
+}
+
+int rgcn_weights_split_pack_multi(int count, const float* const* weights, const float* const* roots,
+                                  const int64_t* R, const int64_t* d_in, const int64_t* d_out,
+                                  const float* const* w_amax, const float* const* r_amax, void* const* packed,
+                                  const size_t* packed_bytes_, void* stream_) {
+  if (count < 1 || count > kPackJobs || !weights || !roots || !R || !d_in || !d_out || !packed || !packed_bytes_)
+    return RGCN_ERR_ARG;
+  pack_jobs JJ{};
+  int64_t most = 0;
+  for (int l = 0; l < count; ++l) {
+    if (R[l] <= 0 || d_in[l] <= 0 || d_out[l] <= 0 || (d_out[l] & 3) || !weights[l]) return RGCN_ERR_ARG;
+    if ((R[l] + 1) * d_in[l] > (1 << 24) || (R[l] + 1) * d_out[l] > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
+    if (!packed[l] || packed_bytes_[l] < packed_bytes(R[l], d_in[l], d_out[l])) return RGCN_ERR_WORKSPACE;
+    JJ.j[l] = make_pack_job(weights[l], roots[l], R[l], d_in[l], d_out[l], packed[l], w_amax ? w_amax[l] : nullptr,
+                            r_amax ? r_amax[l] : nullptr);
+    most = std::max<int64_t>(most, (R[l] + (roots[l] ? 1 : 0)) * d_in[l] * d_out[l]);
+  }
+  dim3 grid((unsigned)std::min<int64_t>(64, ceil_div64(most, kPackThreads)), (unsigned)count);
+  k_pack_split<<<grid, kPackThreads, 0, (hipStream_t)stream_>>>(JJ);
+  RGCN_HIP_TRY(hipGetLastError());
+  return RGCN_OK;
 }
 
 size_t rgcn_transform_split_workspace_bytes(int64_t R, int64_t d_in, int64_t d_out) {

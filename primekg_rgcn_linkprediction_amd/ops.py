@@ -142,6 +142,31 @@ def absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None, clear: Optional[
     return out
 
 
+def absmax_many(tensors, outs, clear: Optional[torch.Tensor] = None) -> None:
+    """``absmax`` of up to 8 tensors in ONE launch (``rgcn_absmax_multi``), tensor i into amax buffer ``outs[i]``:
+    the first launch of a pass - the embedding table and both layers' weights."""
+    if not tensors or len(tensors) != len(outs) or len(tensors) > 8:
+        raise ValueError("1..8 tensors, one amax buffer each")
+    dev = tensors[0].device
+    for i, (t, o) in enumerate(zip(tensors, outs)):
+        _need_gpu(f"tensors[{i}]", t, torch.float32)
+        _check_amax(f"outs[{i}]", o, dev)
+    count = 0
+    if clear is not None:
+        _need_gpu("clear", clear, torch.float32)
+        if clear.numel() % AMAX_FLOATS or clear.device != dev:
+            raise ValueError("clear must hold whole amax buffers on the tensors' device")
+        count = clear.numel() // AMAX_FLOATS
+    n = len(tensors)
+    ptrs = (ctypes.c_void_p * n)(*[_ptr(t) for t in tensors])
+    numels = (ctypes.c_int64 * n)(*[t.numel() for t in tensors])
+    outp = (ctypes.c_void_p * n)(*[_ptr(o) for o in outs])
+    with _on(dev):
+        rc = _lib.load().rgcn_absmax_multi(n, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(numels, ctypes.c_void_p),
+                                           ctypes.cast(outp, ctypes.c_void_p), _ptr(clear), count, _stream())
+    _lib.check(rc, "rgcn_absmax_multi")
+
+
 class SplitWeights:
     """``[W ; root]`` of one layer split into fp16 hi / lo images for the split-precision transforms
     (``rgcn_weights_split_pack``): made once per step by ``split_weights`` and handed to
@@ -156,23 +181,54 @@ class SplitWeights:
 
 def split_weights(weight: torch.Tensor, root: Optional[torch.Tensor]) -> Optional[SplitWeights]:
     """-> ``SplitWeights`` (None in fp32 mode or for widths the split kernels do not tile)"""
-    _need_gpu("weight", weight, torch.float32)
-    if weight.dim() != 3:
-        raise ValueError("weight must be [R, d_in, d_out]")
-    r, d_in, d_out = weight.shape
-    if GEMM_PRECISION == "fp32" or d_in % 32 or d_out % 32:
-        return None
-    if root is not None:
-        _need_gpu("root", root, torch.float32)
-        if tuple(root.shape) != (d_in, d_out):
-            raise ValueError(f"root must be [{d_in}, {d_out}]")
+    return split_weights_many([(weight, root)])[0]
+
+
+def split_weights_many(layers, amax=None):
+    """``[(weight, root | None), ...]`` (up to 4 layers) -> ``[SplitWeights | None, ...]`` in ONE launch
+    (``rgcn_weights_split_pack_multi``).  ``amax``: per layer ``(weight_amax, root_amax)`` buffers when the
+    pass's first launch (``absmax_many``) already left the weights' maxima; otherwise the kernel scans them."""
+    if not layers or len(layers) > 4:
+        raise ValueError("1..4 layers")
+    todo, out = [], [None] * len(layers)
+    for i, (weight, root) in enumerate(layers):
+        _need_gpu("weight", weight, torch.float32)
+        if weight.dim() != 3:
+            raise ValueError("weight must be [R, d_in, d_out]")
+        r, d_in, d_out = weight.shape
+        if root is not None:
+            _need_gpu("root", root, torch.float32)
+            if tuple(root.shape) != (d_in, d_out):
+                raise ValueError(f"root must be [{d_in}, {d_out}]")
+        if GEMM_PRECISION != "fp32" and d_in % 32 == 0 and d_out % 32 == 0:
+            todo.append(i)
+    if not todo:
+        return out
     lib = _lib.load()
-    with _on(weight.device):
-        nbytes = lib.rgcn_weights_split_bytes(r, d_in, d_out)
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-        rc = lib.rgcn_weights_split_pack(_ptr(weight), _ptr(root), r, d_in, d_out, _ptr(buf), nbytes, _stream())
-    _lib.check(rc, "rgcn_weights_split_pack")
-    return SplitWeights(buf, weight, root)
+    dev = layers[todo[0]][0].device
+    n = len(todo)
+    with _on(dev):
+        sizes = [lib.rgcn_weights_split_bytes(*layers[i][0].shape) for i in todo]
+        bufs = [torch.empty(sz, dtype=torch.uint8, device=dev) for sz in sizes]
+        arr = ctypes.c_void_p * n
+        i64 = ctypes.c_int64 * n
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)                                   # noqa: E731
+        wam = ram = None
+        if amax is not None:
+            for i in todo:
+                _check_amax("weight_amax", amax[i][0], dev)
+                _check_amax("root_amax", amax[i][1], dev)
+            wam = cast(arr(*[_ptr(amax[i][0]) for i in todo]))
+            ram = cast(arr(*[_ptr(amax[i][1]) for i in todo]))
+        rc = lib.rgcn_weights_split_pack_multi(
+            n, cast(arr(*[_ptr(layers[i][0]) for i in todo])), cast(arr(*[_ptr(layers[i][1]) for i in todo])),
+            cast(i64(*[layers[i][0].size(0) for i in todo])), cast(i64(*[layers[i][0].size(1) for i in todo])),
+            cast(i64(*[layers[i][0].size(2) for i in todo])), wam, ram, cast(arr(*[_ptr(b) for b in bufs])),
+            cast((ctypes.c_size_t * n)(*sizes)), _stream())
+    _lib.check(rc, "rgcn_weights_split_pack_multi")
+    for i, b in zip(todo, bufs):
+        out[i] = SplitWeights(b, layers[i][0], layers[i][1])
+    return out
 
 
 def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:

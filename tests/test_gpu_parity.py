@@ -363,6 +363,19 @@ def test_split_precision_scales_with_the_operands(a_scale, b_scale, g_scale):
     assert torch.equal(gx, ops.transform_bwd_input(GA, G, W, Rt, precision="split", packed=pk))
     with pytest.raises(ValueError):
         ops.transform_fwd(A, X, W, None, None, precision="split", packed=pk)
+    # ... and the one-launch forms: maxima of several tensors at once, several layers split at once
+    bufs = torch.full((5, ops.AMAX_FLOATS), 3.0, device=dev)
+    ops.absmax_many([X, W, Rt], [bufs[0], bufs[1], bufs[2]], clear=bufs[3:])
+    assert [ops.amax_value(bufs[i]).item() for i in range(3)] == [t.abs().max().item() for t in (x, w, root)]
+    assert ops.amax_value(bufs[3:]).item() == 0.0
+    W2 = (torch.randn(r, d_out, 64, generator=gen) * 3.0).to(dev)
+    many = ops.split_weights_many([(W, Rt), (W2, None)], amax=[(bufs[1], bufs[2]), (ops.absmax(W2), None)])
+    assert torch.equal(out, ops.transform_fwd(A, X, W, Rt, None, precision="split", packed=many[0]))
+    lone = ops.split_weights(W2, None)
+    agg2 = torch.randn(n, r * d_out, generator=gen).to(dev)
+    x2 = torch.randn(n, d_out, generator=gen).to(dev)
+    assert torch.equal(ops.transform_fwd(agg2, x2, W2, None, None, precision="split", packed=many[1]),
+                       ops.transform_fwd(agg2, x2, W2, None, None, precision="split", packed=lone))
     junk = torch.full((3, ops.AMAX_FLOATS), 7.0, device=dev)
     ops.absmax(X, junk[0], clear=junk[1:])
     assert ops.amax_value(junk[0]).item() == x.abs().max().item() and ops.amax_value(junk[1:]).item() == 0.0
