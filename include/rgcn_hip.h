@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 9
+#define RGCN_ABI_VERSION 10
 
 enum {
   RGCN_OK = 0,
@@ -306,6 +306,42 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
                                           float* grad_weight,
                                           float* grad_root, float* grad_bias, void* workspace,
                                           size_t workspace_bytes, void* stream, rgcn_slab_job* job);
+
+/* ------------------------------------------------------------------------------------
+ * One layer forward as ONE kernel (rows A3 + A4 + A6 for the no-grad encoder; rgcn.py:123,128 under
+ * evaluate.py's torch.no_grad()): out = [mean-aggregate(x) | x] * [W ; root] + bias (+ ReLU) with the aggregate
+ * formed in LDS as the transform's A operand - no [N, R * d_in] tensor in HBM.  Mean structures only
+ * (what rgcn_graph_create / _bipartite without weights bucket), split precision only; bit-identical to
+ * rgcn_aggregate -> rgcn_transform_fwd_split.
+ *   supported     1 if the kernel covers the shape: d_in in {64, 128, 256}, d_out in {128, 256},
+ *                 num_relations < d_in / 2 and <= 32 (else use the two-call path)
+ *   rowptr, col   int32 [N * R + 1], [rowptr[N * R]]: the CSR the kernel walks, in (node, relation) segment order
+ *                 like the forward structure's (rgcn_graph_export), except that an id < 0 names row -id - 1 of
+ *                 hub_agg ([*, d_in]) instead of a row of x.  Every segment LONGER than the inline limit the caller
+ *                 chose (<= d_in / 4 edges) should be ONE such entry, its mean formed beforehand: the kernel walks a
+ *                 segment edge by edge with one lane group per row, and a long walk makes its workgroup a
+ *                 straggler.  The usual producer of hub_agg is rgcn_aggregate over a structure of the long segments
+ *                 only (rgcn_graph_create_bipartite with key = hub row, one relation): same runs / packs / hub
+ *                 reduce, same bits.  A segment's mean divides by its number of entries.
+ *   tile_mask     rgcn_graph_tile_mask of the forward structure (relations no row of a 32-row block has are
+ *                 skipped), or NULL
+ *   packed        rgcn_weights_split_pack of this layer; frag: its forward images in MFMA fragment order
+ *                 (rgcn_layer_fwd_fused_pack into rgcn_layer_fwd_fused_weights_bytes bytes), valid while packed is
+ *   x_amax        amax buffer of x (rgcn_absmax): scale of the whole A operand (a mean cannot exceed it)
+ *   out_amax      optional amax buffer that receives max |out| (the next layer's x_amax)
+ *   agg           NULL, or [N, R * d_in]: the aggregate is ALSO written there (the training forward keeps it for
+ *                 the parameter gradients; it is still not read back here).  Rows of relations no row of a 32-row
+ *                 block has are NOT written (they are zero): hand in a zeroed tensor, or one a previous call with
+ *                 the same graph filled
+ * ---------------------------------------------------------------------------------- */
+int rgcn_layer_fwd_fused_supported(int64_t num_relations, int64_t d_in, int64_t d_out);
+size_t rgcn_layer_fwd_fused_weights_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
+int rgcn_layer_fwd_fused_pack(const void* packed, int has_root, int64_t num_relations, int64_t d_in, int64_t d_out,
+                              void* frag, size_t frag_bytes, void* stream);
+int rgcn_layer_fwd_fused(const int32_t* rowptr, const int32_t* col, const uint32_t* tile_mask, int64_t num_nodes,
+                         int64_t num_relations, const float* hub_agg, const float* x, const void* packed,
+                         const void* frag, int has_root, const float* bias, int relu, int64_t d_in, int64_t d_out,
+                         const float* x_amax, float* out, float* out_amax, float* agg, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DistMult head (rows C1 + C2; rgcn.py:325-326 row gathers + rgcn.py:207-211):

@@ -1,0 +1,348 @@
+// One R-GCN layer forward as ONE kernel: the neighbour mean of a block of 32 destination rows is formed in
+// LDS, as the A operand of the transform, and never exists in HBM.
+//
+// Replaces, for the no-grad (evaluation / inference) encoder, the pair rgcn_aggregate -> rgcn_transform_fwd_split
+// (SURVEY.md section 8a rows A3 + A4 + A6; reference call sites src/models/rgcn.py:123,128 under
+// evaluate.py's torch.no_grad()): the [N, R * d_in] aggregate costs a write and a read of N * R * d_in * 4 bytes
+// per layer (4.1 GB at BASELINE configs[3]'s single-GPU size) that this kernel does not make.
+//
+// Work decomposition.  One 256-thread workgroup owns 32 destination rows and all d_out columns.  The K
+// dimension of out = [agg | x] * [W ; root] is walked in R + 1 chunks of d_in: chunk r < R is relation r's
+// mean, chunk R the rows themselves.  Per chunk:
+//   gather   lane groups of G = d_in / 4 lanes (one float4 column slice per lane, as in k_aggregate) each take
+//            32 / (256 / G) of the rows: a SHORT segment (at most the plan's inline limit of edges) is summed right here in
+//            edge order, eight row loads in flight, and divided by its count - the same adds in the same order
+//            as k_aggregate, so the row is bit-identical to the unfused aggregate's; a LONG segment's mean was
+//            formed beforehand by the ordinary gather over a structure that holds only the long segments
+//            (ops.BucketedGraph.fused_plan: runs, packs and the hub reduce keep the launch free of stragglers)
+//            and is one row read here: the CSR this kernel walks holds ONE entry for it, a negative id that
+//            names the pre-aggregated row.  The group gathers all its rows of the chunk at once (kInFlight row
+//            loads per lane), the ids of the next chunk are fetched behind the multiply of this one.  The lane splits its four values (v * 2^e = hi + lo, fp16 each, e from
+//            the table's maximum: a mean cannot exceed it, and chunk R IS the table) and writes them to the two
+//            fp16 A images in LDS - no other lane repeats the split, unlike the stand-alone transform where
+//            every wave that shares an A tile splits it again.
+//   multiply wave w owns columns [32 TNW w, 32 TNW (w + 1)): A fragments are two ds_read_b128 (hi, lo), B
+//            fragments come straight from L2 in MFMA register order (k_frag_pack: one coalesced 1 KB read per
+//            wave, fragment and part; no LDS staging: no two waves of the workgroup share a B column), two
+//            k-steps ahead; three v_mfma_f32_32x32x16_f16 per fragment pair, small terms first, exactly the
+//            stand-alone kernel's order - outputs are bit-identical to the unfused pair's.
+// Chunks whose relation no row of the block has (tile_mask) are skipped whole.
+#include <algorithm>
+
+#include "rgcn_common.h"
+#include "rgcn_split.h"
+
+namespace {
+
+constexpr int kThreads = 256, kRows = 32, kInFlight = 8;
+#ifndef RGCN_FUSED_AHEAD_WIDE
+#define RGCN_FUSED_AHEAD_WIDE 1
+#endif
+
+__device__ inline float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ inline void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// [n][K] (k contiguous) fp16 images -> MFMA B-fragment order: fragment ((s * NT + nt) * 64 + lane) holds the 8
+// consecutive k = 16 s + 8 (lane >> 5) + j of column n = 32 nt + (lane & 31).  One 16-byte fragment per thread.
+__global__ __launch_bounds__(kThreads) void k_frag_pack(const __half* __restrict__ Bh, const __half* __restrict__ Bl,
+                                                        __half* __restrict__ Fh, __half* __restrict__ Fl, int K,
+                                                        int N) {
+  const int64_t f = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  const int NT = N / 32;
+  if (f >= (int64_t)(K / 16) * NT * 64) return;
+  const int lane = (int)(f & 63);
+  const int nt = (int)((f >> 6) % NT), s = (int)((f >> 6) / NT);
+  const size_t src = (size_t)(32 * nt + (lane & 31)) * K + 16 * s + 8 * (lane >> 5);
+  reinterpret_cast<uint4*>(Fh)[f] = *reinterpret_cast<const uint4*>(Bh + src);
+  reinterpret_cast<uint4*>(Fl)[f] = *reinterpret_cast<const uint4*>(Bl + src);
+}
+
+template <int G, int TNW, bool RELU, bool WIDE, bool STORE_AGG>
+__global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
+    const float* __restrict__ x, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+    const float* __restrict__ hub_agg, const __half* __restrict__ Fh, const __half* __restrict__ Fl, const float* __restrict__ b_inv_scale,
+    const float* __restrict__ x_amax, const float* __restrict__ bias, float* __restrict__ out,
+    float* __restrict__ agg, int N, int R, int chunks, const uint32_t* __restrict__ tile_mask, unsigned* __restrict__ amax_out) {
+  constexpr int D_IN = 4 * G, KS = D_IN / 16, NG = kThreads / G, RPG = kRows / NG;
+  constexpr int ROWB = D_IN * 2 + 16;            // bytes of one A row per image: + 16 keeps the fragment reads conflict-free
+  constexpr int NT = 4 * TNW, D_OUT = 32 * NT;
+  // k-steps the B fragments are loaded ahead: registers decide (4 waves per SIMD need VGPRs + AGPRs <= 128)
+  constexpr int kAhead = G == 16 ? 2 : RGCN_FUSED_AHEAD_WIDE;
+  // two A buffers (hi and lo image each): a chunk is gathered into the one the previous chunk's multiply does not
+  // read, so ONE barrier per chunk orders everything (a wave that passed barrier c + 1 has finished multiply c)
+  constexpr int IMG = kRows * ROWB;
+  __shared__ __attribute__((aligned(16))) char lds[4 * IMG];
+
+  const int m0 = blockIdx.x * kRows;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int grp = tid / G, gl = tid % G;
+
+  // the rows this lane group gathers: the segment bounds of ALL their relations in one load (two when a row has
+  // more than G - 1 relations: WIDE)
+  constexpr int W = WIDE ? 2 : 1;
+  int rp[RPG][W];
+#pragma unroll
+  for (int q = 0; q < RPG; ++q) {
+    const int node = m0 + grp * RPG + q;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      const int j = gl + w * G;
+      rp[q][w] = (node < N && j <= R) ? rowptr[(size_t)node * R + j] : 0;
+    }
+  }
+  const unsigned seen = rgcn_amax_peek(amax_out);
+  unsigned rel_mask = tile_mask ? tile_mask[blockIdx.x] : 0xffffffffu;
+  rel_mask = __builtin_amdgcn_readfirstlane(rel_mask);
+  const int ea = scale_exponent(rgcn_amax_value(x_amax, lane));
+  const float sa = pow2f(ea);
+
+  floatx16 acc[TNW];
+#pragma unroll
+  for (int b = 0; b < TNW; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+  const uint4* __restrict__ Fh4 = reinterpret_cast<const uint4*>(Fh);
+  const uint4* __restrict__ Fl4 = reinterpret_cast<const uint4*>(Fl);
+  const unsigned a_off = (unsigned)(li * ROWB + 16 * lh);
+
+  // the chunks this block multiplies: the relations some row of it has, then the rows themselves
+  unsigned long long todo = (unsigned long long)rel_mask & ((1ull << R) - 1ull);
+  if (chunks > R) todo |= 1ull << R;
+
+  // the group's rows of the chunk being gathered: segment start / length and the ids of its edges (lane j: edge
+  // j).  An id < 0 is row -id - 1 of hub_agg: the plan replaces every segment longer than its inline limit by ONE
+  // such entry (mean of one row = the row), and keeps every segment within G entries; a longer one (a caller's own
+  // CSR) is finished by the slow loop below.
+  constexpr int U = kInFlight / RPG;             // row loads in flight per lane: U per row, all rows of the group at once
+  int beg[RPG], len[RPG], idw[RPG];
+  auto fetch_ids = [&](int c) {                  // c < R, uniform: entry c sits in lane c % G of register c / G
+#pragma unroll
+    for (int q = 0; q < RPG; ++q) {
+      beg[q] = __shfl(rp[q][WIDE && c >= G], c & (G - 1), G);
+      len[q] = __shfl(rp[q][WIDE && c + 1 >= G], (c + 1) & (G - 1), G) - beg[q];
+      idw[q] = gl < len[q] ? col[beg[q] + gl] : 0;
+    }
+  };
+  auto row_of = [&](int id) -> const float* {    // a table row, or a pre-aggregated one
+    return id >= 0 ? x + (size_t)id * D_IN + 4 * gl : hub_agg + (size_t)(-id - 1) * D_IN + 4 * gl;
+  };
+  if (todo) {
+    const int c0 = __ffsll((long long)todo) - 1;
+    if (c0 < R) fetch_ids(c0);
+  }
+
+  int parity = 0;
+  while (todo) {
+    char* sAh = lds + parity * 2 * IMG;
+    char* sAl = sAh + IMG;
+    parity ^= 1;
+    const int c = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    // B fragments of the chunk's first k-steps: in flight behind the gather
+    uint4 qh[kAhead + 1][TNW], ql[kAhead + 1][TNW];
+    const size_t fbase = ((size_t)c * KS * NT + wave * TNW) * 64 + lane;
+    auto load_b = [&](int s, int slot) {
+#pragma unroll
+      for (int b = 0; b < TNW; ++b) {
+        const size_t f = fbase + ((size_t)s * NT + b) * 64;
+        qh[slot][b] = Fh4[f];
+        ql[slot][b] = Fl4[f];
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < kAhead; ++s) load_b(s, s);
+
+    // ---- gather: this group's rows of chunk c, all rows at once -> split -> LDS ----
+    float4 a[RPG];
+    if (c == R) {
+#pragma unroll
+      for (int q = 0; q < RPG; ++q) {
+        const int node = m0 + grp * RPG + q;
+        a[q] = node < N ? *reinterpret_cast<const float4*>(x + (size_t)node * D_IN + 4 * gl) : f4zero();
+      }
+    } else {
+      int most = 0;
+#pragma unroll
+      for (int q = 0; q < RPG; ++q) {
+        a[q] = f4zero();
+        most = max(most, min(len[q], G));
+      }
+      for (int p = 0; p < most; p += U) {        // every row's adds stay in edge order
+        float4 v[RPG][U];
+#pragma unroll
+        for (int q = 0; q < RPG; ++q)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int id = __shfl(idw[q], (p + u) & (G - 1), G);
+            v[q][u] = f4zero();
+            if (p + u < min(len[q], G)) v[q][u] = *reinterpret_cast<const float4*>(row_of(id));
+          }
+#pragma unroll
+        for (int q = 0; q < RPG; ++q)
+#pragma unroll
+          for (int u = 0; u < U; ++u) f4add(a[q], v[q][u]);
+      }
+#pragma unroll
+      for (int q = 0; q < RPG; ++q) {
+        if (len[q] <= 1) continue;                           // sum / 1 = sum
+        for (int w0 = beg[q] + G; w0 < beg[q] + len[q]; w0 += G) {   // beyond the plan's limit: G ids at a time
+          const int wn = min(G, beg[q] + len[q] - w0);
+          const int ids = gl < wn ? col[w0 + gl] : 0;
+          for (int p = 0; p < wn; ++p) f4add(a[q], *reinterpret_cast<const float4*>(row_of(__shfl(ids, p, G))));
+        }
+        const float cq = (float)len[q];                      // true division, as `sum / count` does
+        a[q].x /= cq; a[q].y /= cq; a[q].z /= cq; a[q].w /= cq;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RPG; ++q) {
+      const int i = grp * RPG + q;
+      if (STORE_AGG && c < R && m0 + i < N)
+        *reinterpret_cast<float4*>(agg + ((size_t)(m0 + i) * R + c) * D_IN + 4 * gl) = a[q];
+      half4v h, l;
+      const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = av[k] * sa;
+        h[k] = (_Float16)v;
+        l[k] = (_Float16)(v - (float)h[k]);
+      }
+      *reinterpret_cast<half4v*>(sAh + i * ROWB + 8 * gl) = h;
+      *reinterpret_cast<half4v*>(sAl + i * ROWB + 8 * gl) = l;
+    }
+    if (todo) {                                  // the next chunk's ids: in flight behind the multiply
+      const int cn_ = __ffsll((long long)todo) - 1;
+      if (cn_ < R) fetch_ids(cn_);
+    }
+    __syncthreads();
+
+    // ---- multiply: KS k-steps of this chunk ----
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + kAhead < KS) load_b(s + kAhead, (s + kAhead) % (kAhead + 1));
+      const half8 ah = *reinterpret_cast<const half8*>(sAh + a_off + 32 * s);
+      const half8 al = *reinterpret_cast<const half8*>(sAl + a_off + 32 * s);
+#pragma unroll
+      for (int b = 0; b < TNW; ++b) {                        // small terms first
+        const half8 bh = __builtin_bit_cast(half8, qh[s % (kAhead + 1)][b]);
+        const half8 bl = __builtin_bit_cast(half8, ql[s % (kAhead + 1)][b]);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+      }
+    }
+  }
+
+  // C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const float ia = pow2f(-ea), ib = b_inv_scale[0];
+  float cmax = 0.f;
+#pragma unroll
+  for (int b = 0; b < TNW; ++b) {
+    const int n = (wave * TNW + b) * 32 + li;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < N) {
+        float v = acc[b][r] * ia * ib + bv;
+        if (RELU) v = fmaxf(v, 0.f);
+        cmax = fmaxf(cmax, fabsf(v));
+        out[(size_t)m * D_OUT + n] = v;
+      }
+    }
+  }
+  if (amax_out) rgcn_amax_publish(amax_out, cmax, seen);
+}
+
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+bool supported(int64_t R, int64_t d_in, int64_t d_out) {
+  if (!(d_in == 64 || d_in == 128 || d_in == 256)) return false;
+  if (!(d_out == 128 || d_out == 256)) return false;
+  return R >= 1 && R < d_in / 2 && R <= 32;                  // a lane group holds a row's R + 1 segment bounds in <= 2 registers
+}
+
+size_t frag_bytes(int64_t R, int64_t d_in, int64_t d_out) {
+  return 2 * align256((size_t)(R + 1) * d_in * d_out * sizeof(__half));
+}
+
+}  // namespace
+
+extern "C" {
+
+int rgcn_layer_fwd_fused_supported(int64_t R, int64_t d_in, int64_t d_out) { return supported(R, d_in, d_out) ? 1 : 0; }
+
+size_t rgcn_layer_fwd_fused_weights_bytes(int64_t R, int64_t d_in, int64_t d_out) {
+  return supported(R, d_in, d_out) ? frag_bytes(R, d_in, d_out) : 0;
+}
+
+int rgcn_layer_fwd_fused_pack(const void* packed, int has_root, int64_t R, int64_t d_in, int64_t d_out, void* frag,
+                              size_t frag_bytes_, void* stream_) {
+  if (!packed || !frag) return RGCN_ERR_ARG;
+  if (!supported(R, d_in, d_out)) return RGCN_ERR_UNSUPPORTED;
+  if (frag_bytes_ < frag_bytes(R, d_in, d_out)) return RGCN_ERR_WORKSPACE;
+  const rgcn_split_fwd_view v = rgcn_split_forward_images(packed, R, d_in, d_out);
+  const int K = (int)((R + (has_root ? 1 : 0)) * d_in);
+  __half* Fh = (__half*)frag;
+  __half* Fl = (__half*)((char*)frag + frag_bytes(R, d_in, d_out) / 2);
+  const int64_t frags = (int64_t)(K / 16) * (d_out / 32) * 64;
+  k_frag_pack<<<(unsigned)ceil_div64(frags, kThreads), kThreads, 0, (hipStream_t)stream_>>>(v.Bh, v.Bl, Fh, Fl, K,
+                                                                                          (int)d_out);
+  RGCN_HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+int rgcn_layer_fwd_fused(const int32_t* rowptr, const int32_t* col, const uint32_t* tile_mask, int64_t N, int64_t R,
+                         const float* hub_agg, const float* x, const void* packed, const void* frag, int has_root,
+                         const float* bias, int relu, int64_t d_in, int64_t d_out, const float* x_amax, float* out,
+                         float* out_amax, float* agg, void* stream_) {
+  if (N < 0 || !rowptr || !x || !packed || !frag || !x_amax || !out) return RGCN_ERR_ARG;
+  if (!supported(R, d_in, d_out)) return RGCN_ERR_UNSUPPORTED;
+  if (N == 0) return RGCN_OK;
+  if (N > INT32_MAX / 2) return RGCN_ERR_UNSUPPORTED;
+  const rgcn_split_fwd_view v = rgcn_split_forward_images(packed, R, d_in, d_out);
+  const __half* Fh = (const __half*)frag;
+  const __half* Fl = (const __half*)((const char*)frag + frag_bytes(R, d_in, d_out) / 2);
+  const int chunks = (int)R + (has_root ? 1 : 0);
+  const unsigned grid = (unsigned)ceil_div64(N, kRows);
+  const uint32_t* tmask = tile_mask;
+  unsigned* amax_out = reinterpret_cast<unsigned*>(out_amax);
+  hipStream_t stream = (hipStream_t)stream_;
+#define RGCN_FUSED_LAUNCH2(G_, TNW_, RELU_, WIDE_, STORE_)                                                          \
+  k_layer_fwd_fused<G_, TNW_, RELU_, WIDE_, STORE_><<<grid, kThreads, 0, stream>>>(                                    \
+      x, rowptr, col, hub_agg, Fh, Fl, v.inv_scale, x_amax, bias, out, agg, (int)N, (int)R, chunks, tmask, amax_out)
+#define RGCN_FUSED_LAUNCH(G_, TNW_, RELU_, WIDE_)             \
+  do {                                                         \
+    if (agg) RGCN_FUSED_LAUNCH2(G_, TNW_, RELU_, WIDE_, true); \
+    else RGCN_FUSED_LAUNCH2(G_, TNW_, RELU_, WIDE_, false);    \
+  } while (0)
+#define RGCN_FUSED(G_, TNW_)                                   \
+  do {                                                         \
+    if (R >= G_) {                                             \
+      if (relu) RGCN_FUSED_LAUNCH(G_, TNW_, true, true);       \
+      else RGCN_FUSED_LAUNCH(G_, TNW_, false, true);           \
+    } else {                                                   \
+      if (relu) RGCN_FUSED_LAUNCH(G_, TNW_, true, false);      \
+      else RGCN_FUSED_LAUNCH(G_, TNW_, false, false);          \
+    }                                                          \
+  } while (0)
+  if (d_out == 128) {
+    if (d_in == 64) RGCN_FUSED(16, 1);
+    else if (d_in == 128) RGCN_FUSED(32, 1);
+    else RGCN_FUSED(64, 1);
+  } else {
+    if (d_in == 64) RGCN_FUSED(16, 2);
+    else if (d_in == 128) RGCN_FUSED(32, 2);
+    else RGCN_FUSED(64, 2);
+  }
+#undef RGCN_FUSED
+#undef RGCN_FUSED_LAUNCH
+#undef RGCN_FUSED_LAUNCH2
+  RGCN_HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+}  // extern "C"

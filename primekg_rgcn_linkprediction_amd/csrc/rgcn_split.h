@@ -1,0 +1,40 @@
+// Split-precision helpers shared by the transforms (rgcn_transform_split.hip) and the fused layer
+// (rgcn_layer_fused.hip): per-tensor power-of-two scales, MFMA operand types, the packed-weights view.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <string.h>
+
+#include "rgcn_common.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// 2^e with the tensor maximum `amax` scaled into [2^14, 2^15); 1 for amax == 0 / not finite.
+// Exponents are clamped so that both the scale and its inverse are normal floats.
+__device__ __host__ inline int scale_exponent(float amax) {
+  uint32_t bits;
+  memcpy(&bits, &amax, 4);
+  const int e = (int)((bits >> 23) & 0xff);                  // amax in [2^(e-127), 2^(e-126))
+  if (e == 0 || e == 255) return 0;
+  int s = 141 - e;                                           // amax * 2^s in [2^14, 2^15)
+  if (s > 100) s = 100;
+  if (s < -100) s = -100;
+  return s;
+}
+__device__ __host__ inline float pow2f(int s) {
+  const uint32_t bits = (uint32_t)(127 + s) << 23;
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+// The forward-orientation images of a layer's split weights (rgcn_weights_split_pack): Bh / Bl [d_out][K],
+// K = (R + 1) * d_in, k contiguous, and the inverse of their common scale.  Defined in rgcn_transform_split.hip.
+struct rgcn_split_fwd_view {
+  const __half *Bh, *Bl;
+  const float* inv_scale;
+};
+rgcn_split_fwd_view rgcn_split_forward_images(const void* packed, int64_t R, int64_t d_in, int64_t d_out);
+size_t rgcn_split_packed_bytes(int64_t R, int64_t d_in, int64_t d_out);

@@ -30,15 +30,12 @@
 
 #include "rgcn_common.h"
 #include "rgcn_slab_reduce.h"
+#include "rgcn_split.h"
 
 namespace {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef _Float16 half4v __attribute__((ext_vector_type(4)));
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 constexpr int kThreads = 256;
 constexpr int BK = 32;
@@ -50,25 +47,6 @@ enum { B_KN = 0, B_BLK = 1 };
 __device__ inline void glds16(const void* src, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// 2^e with the tensor maximum `amax` scaled into [2^14, 2^15); 1 for amax == 0 / not finite.
-// Exponents are clamped so that both the scale and its inverse are normal floats.
-__device__ __host__ inline int scale_exponent(float amax) {
-  uint32_t bits;
-  memcpy(&bits, &amax, 4);
-  const int e = (int)((bits >> 23) & 0xff);                  // amax in [2^(e-127), 2^(e-126))
-  if (e == 0 || e == 255) return 0;
-  int s = 141 - e;                                           // amax * 2^s in [2^14, 2^15)
-  if (s > 100) s = 100;
-  if (s < -100) s = -100;
-  return s;
-}
-__device__ __host__ inline float pow2f(int s) {
-  const uint32_t bits = (uint32_t)(127 + s) << 23;
-  float f;
-  memcpy(&f, &bits, 4);
-  return f;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -848,6 +826,12 @@ size_t tn_workspace_bytes(int64_t N, int64_t R, int64_t d_in, int64_t d_out) {
 }
 
 }  // namespace
+
+rgcn_split_fwd_view rgcn_split_forward_images(const void* packed, int64_t R, int64_t d_in, int64_t d_out) {
+  const PackedWeights v = packed_view(const_cast<void*>(packed), R, d_in, d_out);
+  return rgcn_split_fwd_view{v.Bh_f, v.Bl_f, v.inv_scale};
+}
+size_t rgcn_split_packed_bytes(int64_t R, int64_t d_in, int64_t d_out) { return packed_bytes(R, d_in, d_out); }
 
 extern "C" {
 

@@ -179,6 +179,30 @@ class SplitWeights:
         return tuple(weight.shape) == self.shape and (root is not None) == self.has_root and weight.device == self.buf.device
 
 
+def fused_supported(num_relations: int, d_in: int, d_out: int) -> bool:
+    """does the one-kernel layer forward cover this shape (in split precision)?"""
+    return GEMM_PRECISION != "fp32" and bool(_lib.load().rgcn_layer_fwd_fused_supported(num_relations, d_in, d_out))
+
+
+def _fragments(packed: SplitWeights) -> torch.Tensor:
+    """the forward images of ``packed`` in MFMA fragment order (``rgcn_layer_fwd_fused_pack``), made once per
+    ``SplitWeights``"""
+    frag = getattr(packed, "_frag", None)
+    if frag is None:
+        lib = _lib.load()
+        r, d_in, d_out = packed.shape
+        with _on(packed.buf.device):
+            nbytes = lib.rgcn_layer_fwd_fused_weights_bytes(r, d_in, d_out)
+            if nbytes == 0:
+                raise ValueError(f"the fused layer does not cover R={r}, d_in={d_in}, d_out={d_out}")
+            frag = torch.empty(nbytes, dtype=torch.uint8, device=packed.buf.device)
+            rc = lib.rgcn_layer_fwd_fused_pack(_ptr(packed.buf), int(packed.has_root), r, d_in, d_out, _ptr(frag), nbytes,
+                                               _stream())
+        _lib.check(rc, "rgcn_layer_fwd_fused_pack")
+        packed._frag = frag
+    return frag
+
+
 def split_weights(weight: torch.Tensor, root: Optional[torch.Tensor]) -> Optional[SplitWeights]:
     """-> ``SplitWeights`` (None in fp32 mode or for widths the split kernels do not tile)"""
     return split_weights_many([(weight, root)])[0]
@@ -240,6 +264,17 @@ def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
 # ----------------------------------------------------------------------------------
 # bucketed graph (row A2) + cache
 # ----------------------------------------------------------------------------------
+class FusedPlan:
+    """``BucketedGraph.fused_plan``: the CSR the one-kernel layer walks - ``rowptr`` int32[N * R + 1] / ``col`` int32 in
+    the forward structure's segment order, a segment longer than ``inline_limit`` edges replaced by ONE entry
+    ``-(row + 1)`` naming its row of the pre-aggregated table - and ``hub``, the gather structure of those long
+    segments (None if there is none)."""
+
+    def __init__(self, inline_limit: int, rowptr, col, hub, hub_rows: int, hub_edges: int):
+        self.inline_limit, self.rowptr, self.col, self.hub = inline_limit, rowptr, col, hub
+        self.hub_rows, self.hub_edges = hub_rows, hub_edges
+
+
 class BucketedGraph:
     """Owner of one ``rgcn_graph`` handle: the CSR-by-relation structures (forward and
     transposed) of a static multigraph, built once on the device."""
@@ -440,6 +475,44 @@ class BucketedGraph:
             cache[block_rows] = blocks
         return cache[block_rows]
 
+    def fused_plan(self, inline_limit: int = 16) -> "FusedPlan":
+        """What the one-kernel layer forward (``layer_fwd_fused``) needs beside this structure: which
+        (node, relation) segments it walks itself (at most ``inline_limit`` <= 64 edges) and, for the longer
+        ones, a gather structure of their own (one segment per long segment, one relation, key = row of the
+        pre-aggregated ``hub`` table) - built once per limit from the bucketed arrays; a long segment keeps its
+        edge order, run / pack cuts and hub reduce, so its mean has the bits the whole-graph aggregate gives it."""
+        if self.weighted_shard:
+            raise ValueError("the fused layer covers mean structures only")
+        limit = int(inline_limit)
+        if not 1 <= limit <= 64:
+            raise ValueError("inline_limit must be in [1, 64] (a longer walk is cut into runs by the gather)")
+        cache = self.__dict__.setdefault("_fused_plans", {})
+        if limit not in cache:
+            rowptr, col, _, _ = self.arrays(False)
+            rp = rowptr.long()
+            lens = rp[1:] - rp[:-1]
+            long_seg = lens > limit
+            hubs = int(long_seg.sum())
+            if hubs == 0:
+                cache[limit] = FusedPlan(limit, rowptr, col, None, 0, 0)
+            else:
+                hub_row = torch.cumsum(long_seg.long(), 0) - 1                  # of a long segment
+                seg_of_edge = torch.repeat_interleave(torch.arange(lens.numel(), device=self.device), lens)
+                in_hub = long_seg[seg_of_edge]
+                hub = BucketedGraph.from_shard(hub_row[seg_of_edge[in_hub]], col[in_hub].long(),
+                                               torch.zeros(int(in_hub.sum()), dtype=torch.int64, device=self.device),
+                                               hubs, self.num_other_nodes, 1)
+                # the walked CSR: short segments as they are, a long one as the single entry -(hub row + 1)
+                first = torch.zeros_like(in_hub)
+                first[rp[:-1][long_seg]] = True
+                keep = ~in_hub | first
+                new_col = torch.where(in_hub, -(hub_row[seg_of_edge] + 1), col.long())[keep].int()
+                new_lens = torch.where(long_seg, torch.ones_like(lens), lens)
+                new_rowptr = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=self.device)
+                new_rowptr[1:] = torch.cumsum(new_lens, 0)
+                cache[limit] = FusedPlan(limit, new_rowptr.int(), new_col.contiguous(), hub, hubs, int(in_hub.sum()))
+        return cache[limit]
+
     def merged_transposed(self) -> Optional["BucketedGraph"]:
         """The out-edges of every node across ALL relations as one weighted gather structure over
         a table of ``N * (R + 1)`` rows: edge (j -> i, r) reads row ``i * (R + 1) + r`` with weight
@@ -472,6 +545,9 @@ class BucketedGraph:
         for blocks in self.__dict__.pop("_row_blocks", {}).values():
             for _, _, shard in blocks:
                 shard.destroy()
+        for plan in self.__dict__.pop("_fused_plans", {}).values():
+            if plan.hub is not None:
+                plan.hub.destroy()
         if self._handle is not None:
             try:
                 _lib.load().rgcn_graph_destroy(self._handle)
@@ -670,6 +746,62 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
                     weighted = bool(transposed) or (graph.bipartite and graph.weighted_shard)
                     GATHER_EVENTS.append((weighted, d, graph.num_edges, graph.num_nodes * graph.num_relations, beg, end))
     _lib.check(rc, "rgcn_aggregate")
+    return out
+
+
+FUSED_EVENTS = None      # bench / probes: list that receives (rows, edges, d_in, d_out, begin, end) per fused launch
+
+
+def layer_fwd_fused(graph: BucketedGraph, x: torch.Tensor, packed: SplitWeights, bias: Optional[torch.Tensor],
+                    relu: bool, amax: torch.Tensor, amax_out: Optional[torch.Tensor] = None,
+                    inline_limit: int = 16, out: Optional[torch.Tensor] = None,
+                    agg_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[mean-aggregate(x) | x] @ [W ; root] + bias`` (+ ReLU) in ONE kernel whose A operand is gathered into
+    LDS (``rgcn_layer_fwd_fused``): no ``[N, R * d_in]`` aggregate in HBM.  Segments longer than ``inline_limit``
+    edges are pre-aggregated by the ordinary gather over ``graph.fused_plan(inline_limit).hub``.  Bit-identical
+    to ``aggregate`` -> ``transform_fwd(precision="split")``.  ``amax``: amax buffer of ``x``.  ``agg_out``
+    (ZEROED ``[N, R * d_in]``, optional): also receives the aggregate, for a backward that needs it."""
+    _need_gpu("x", x, torch.float32)
+    if graph.weighted_shard:
+        raise ValueError("the fused layer covers mean structures only")
+    if x.dim() != 2 or x.size(0) != graph.num_other_nodes or x.device != graph.device:
+        raise ValueError(f"x must be [{graph.num_other_nodes}, d] on the graph's device, got {tuple(x.shape)}")
+    r, d_in, d_out = packed.shape
+    if r != graph.num_relations or d_in != x.size(1):
+        raise ValueError(f"packed weights are [{r}, {d_in}, {d_out}]; graph has {graph.num_relations} relations, x width {x.size(1)}")
+    if bias is not None:
+        _need_gpu("bias", bias, torch.float32)
+        if tuple(bias.shape) != (d_out,):
+            raise ValueError(f"bias must be [{d_out}]")
+    _check_amax("amax", amax, x.device)
+    if amax is None:
+        raise ValueError("amax (the amax buffer of x) is required")
+    _check_amax("amax_out", amax_out, x.device)
+    if agg_out is not None:
+        _need_gpu("agg_out", agg_out, torch.float32)
+        if tuple(agg_out.shape) != (graph.num_nodes, r * d_in) or agg_out.device != x.device or not agg_out.is_contiguous():
+            raise ValueError(f"agg_out must be a contiguous [{graph.num_nodes}, {r * d_in}] on x's device")
+    plan = graph.fused_plan(min(int(inline_limit), d_in // 4))    # one id window of d_in / 4 lanes per segment
+    frag = _fragments(packed)
+    hub_agg = aggregate(plan.hub, x) if plan.hub is not None else None
+    tile_mask = graph.tile_mask_ptr(False) if graph.num_relations <= 32 else None
+    lib = _lib.load()
+    with _on(x.device):
+        if out is None:
+            out = torch.empty(graph.num_nodes, d_out, dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != (graph.num_nodes, d_out) or out.dtype != torch.float32 or out.device != x.device:
+            raise ValueError(f"out must be float32 [{graph.num_nodes}, {d_out}] on x's device")
+        if FUSED_EVENTS is not None:
+            beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            beg.record()
+        rc = lib.rgcn_layer_fwd_fused(_ptr(plan.rowptr), _ptr(plan.col), tile_mask, graph.num_nodes, r, _ptr(hub_agg),
+                                      _ptr(x), _ptr(packed.buf), _ptr(frag), int(packed.has_root), _ptr(bias),
+                                      int(bool(relu)), d_in, d_out, _ptr(amax), _ptr(out), _ptr(amax_out), _ptr(agg_out),
+                                      _stream())
+        if FUSED_EVENTS is not None:
+            end.record()
+            FUSED_EVENTS.append((graph.num_nodes, graph.num_edges - plan.hub_edges, d_in, d_out, beg, end))
+    _lib.check(rc, "rgcn_layer_fwd_fused")
     return out
 
 

@@ -795,6 +795,7 @@ def test_no_grad_encoder_walks_row_blocks_and_equals_the_training_path(monkeypat
     forward, for one block, a few blocks and ragged last blocks; hubs inside a block keep their partial-row levels"""
     from primekg_rgcn_linkprediction_amd import conv as C
     dev = need_gpu()
+    monkeypatch.setattr(C, "_EVAL_FUSED", False)               # the two-launch path (fp16 tables, fp32 mode, other widths)
     ei, et, n, r = synth.primekg_like(num_edges=200000, seed=12)
     torch.manual_seed(3)
     emb = torch.nn.init.xavier_uniform_(torch.empty(n, 64)).to(dev)
@@ -1239,3 +1240,78 @@ def test_deferred_slab_reduction_rides_in_a_gather_and_changes_nothing():
     assert pend.grads[1] is None and pend.grads[2] is None
     assert torch.equal(pend.grads[0], ops.transform_bwd_params(agg, x, g, r, want_root=False, want_bias=False,
                                                               graph=graph)[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,e,r,d_in,d_out,limit", [
+    (1000, 20000, 3, 64, 128, 16), (30926, 849456, 3, 128, 128, 16), (2049, 60000, 16, 64, 128, 8),
+    (777, 30000, 5, 256, 256, 64), (500, 9000, 3, 128, 256, 1), (4097, 90000, 20, 64, 128, 16),
+    (33, 40, 3, 64, 128, 16), (5000, 300000, 3, 256, 128, 24)])
+def test_fused_layer_forward_is_bit_identical_to_gather_then_transform(n, e, r, d_in, d_out, limit):
+    """rgcn_layer_fwd_fused (the aggregate formed in LDS as the transform's A operand; rgcn.py:123,128 under
+    no_grad) against rgcn_aggregate -> rgcn_transform_fwd_split: same adds in the same order, same fragments
+    through the same MFMA sequence - every bit equal, for hub-heavy graphs (long segments pre-aggregated), ragged
+    last row blocks, relations missing from whole blocks (tile masks), R >= lanes per row, with / without bias,
+    ReLU and root; and within 1e-5 of the float64 value."""
+    dev = need_gpu()
+    if (n, e) == (30926, 849456):
+        ei, et, n, r = synth.primekg_like(seed=42)
+    else:
+        gen = torch.Generator().manual_seed(n + e)
+        dst = (torch.rand(e, generator=gen) ** 3 * n).long().clamp_(max=n - 1)       # skewed: a few hubs
+        src = torch.randint(0, n, (e,), generator=gen)
+        et = torch.randint(0, r, (e,), generator=gen)
+        et[dst < n // 3] = 0                                  # whole row blocks without most relations
+        ei = torch.stack([src, dst])
+    eid, etd = ei.to(dev), et.to(dev)
+    graph = ops.bucket(eid, etd, n, r)
+    assert ops.fused_supported(r, d_in, d_out)
+    torch.manual_seed(e)
+    x = torch.randn(n, d_in, device=dev)
+    weight = torch.randn(r, d_in, d_out, device=dev) / d_in ** 0.5
+    root = torch.randn(d_in, d_out, device=dev) / d_in ** 0.5
+    bias = torch.randn(d_out, device=dev)
+    plan = graph.fused_plan(limit)
+    rowptr = graph.arrays(False)[0].long()
+    lens = rowptr[1:] - rowptr[:-1]
+    assert plan.hub_rows == int((lens > limit).sum()) and plan.hub_edges == int(lens[lens > limit].sum())
+    for rt, bs, relu in ((root, bias, True), (root, None, False), (None, bias, False)):
+        x_amax = ops.absmax(x)
+        packed = ops.split_weights(weight, rt)
+        agg = ops.aggregate(graph, x)
+        want_amax, got_amax = ops.amax_buffer(dev), ops.amax_buffer(dev)
+        want = ops.transform_fwd(agg, x, weight, rt, bs, relu=relu, graph=graph, amax=(x_amax, x_amax),
+                                 amax_out=want_amax, packed=packed, precision="split")
+        got = ops.layer_fwd_fused(graph, x, packed, bs, relu, x_amax, got_amax, inline_limit=limit)
+        assert torch.equal(got, want), (rt is None, bs is None, relu)
+        assert float(ops.amax_value(got_amax)) == float(ops.amax_value(want_amax)) == float(want.abs().max())
+    ref = agg.double() @ weight.double().reshape(r * d_in, d_out) + bias.double()
+    assert float((got.double() - ref).abs().max()) <= FWD_ATOL * max(1.0, float(ref.abs().max()))
+    with pytest.raises(ValueError):
+        graph.fused_plan(65)
+    assert not ops.fused_supported(r, d_in, 64) and not ops.fused_supported(40, d_in, d_out)
+
+
+@pytest.mark.gpu
+def test_no_grad_encoder_through_the_fused_layer_equals_the_training_path(monkeypatch):
+    """RGCN_EVAL_FUSED=1: get_embeddings / validate / evaluate run each layer as one kernel; same bits as the
+    autograd node's forward"""
+    from primekg_rgcn_linkprediction_amd import conv as C
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=200000, seed=12)
+    torch.manual_seed(3)
+    emb = torch.nn.init.xavier_uniform_(torch.empty(n, 64)).to(dev)
+    convs = [RGCNConv(64, 128, r).to(dev), RGCNConv(128, 128, r).to(dev)]
+    for c in convs:
+        c.bias.data.uniform_(-0.1, 0.1)
+    eid, etd = ei.to(dev), et.to(dev)
+    want = rgcn_encoder2(emb.clone().requires_grad_(True), eid, etd, convs[0], convs[1]).detach()
+    monkeypatch.setattr(C, "_EVAL_FUSED", True)
+    events = []
+    monkeypatch.setattr(ops, "FUSED_EVENTS", events)
+    for limit in (16, 4, 64):
+        monkeypatch.setattr(C, "_EVAL_INLINE_LIMIT", limit)
+        with torch.no_grad():
+            got = rgcn_encoder2(emb, eid, etd, convs[0], convs[1])
+        assert torch.equal(got, want), limit
+    assert len(events) == 6                                   # two fused launches per forward: the path was taken
