@@ -341,9 +341,18 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
       // step 0 may start once its own reads are back (the last 2 + PARTS TN issued are step 1's); the wait is
       // tied to the registers it guards so that their uses stay below it
       constexpr int kStepReads = 2 + PARTS * TN;
-      if (s == 0) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fh[0][0]), "+v"(fh[0][TN - 1]) : "n"(kStepReads));
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fh[1][0]), "+v"(fh[1][TN - 1]));
-      if (LO) asm volatile("" : "+v"(fl[s][0]), "+v"(fl[s][TN - 1]));
+      // (one operand per DISTINCT register: naming fh[s][0] twice at TN == 1 makes the compiler copy it into a
+      // second register ABOVE the wait - a read of a register whose ds_read has not landed: the one-pass
+      // 64-column kernel returned different bits in one run of five)
+      if constexpr (TN > 1) {
+        if (s == 0) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fh[0][0]), "+v"(fh[0][TN - 1]) : "n"(kStepReads));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fh[1][0]), "+v"(fh[1][TN - 1]));
+        if (LO) asm volatile("" : "+v"(fl[s][0]), "+v"(fl[s][TN - 1]));
+      } else {
+        if (s == 0) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fh[0][0]) : "n"(kStepReads));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fh[1][0]));
+        if (LO) asm volatile("" : "+v"(fl[s][0]));
+      }
       // split the lane's 8 k of A: v = a * 2^ea; hi = fp16(v); lo = fp16(v - hi)
       half8 ah, al;
 #pragma unroll

@@ -1315,3 +1315,41 @@ def test_no_grad_encoder_through_the_fused_layer_equals_the_training_path(monkey
             got = rgcn_encoder2(emb, eid, etd, convs[0], convs[1])
         assert torch.equal(got, want), limit
     assert len(events) == 6                                   # two fused launches per forward: the path was taken
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["half", "split", "fp32"])
+@pytest.mark.parametrize("d_in,d_out", [(64, 128), (128, 128), (128, 64), (64, 64)])
+def test_transforms_return_the_same_bits_every_run(d_in, d_out, precision):
+    """Every transform entry, 100 launches each on the same operands (the caches and the allocator disturbed in
+    between): bit-identical results.  Guards the hand-scheduled waits of the LDS-DMA GEMMs - the one-pass
+    64-column kernel once read a fragment register above its s_waitcnt and differed in one run of five."""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=300000, seed=9)
+    graph = ops.bucket(ei.to(dev), et.to(dev), n, r)
+    torch.manual_seed(d_in + d_out)
+    g = torch.randn(n, d_out, device=dev) * 1e-6 * (torch.rand(n, d_out, device=dev) > 0.5)
+    x = torch.randn(n, d_in, device=dev)
+    w = torch.randn(r, d_in, d_out, device=dev) * 0.1
+    root = torch.randn(d_in, d_out, device=dev) * 0.1
+    bias = torch.randn(d_out, device=dev)
+    g_amax, x_amax = ops.absmax(g), ops.absmax(x)
+    pk = ops.split_weights(w, root) if precision != "fp32" else None
+    agg, gagg = ops.aggregate(graph, x), ops.aggregate(graph, g, transposed=True)
+    wb = graph.weight_bound(True)
+
+    def run():
+        fwd = ops.transform_fwd(agg, x, w, root, bias, relu=True, graph=graph, amax=(x_amax, x_amax), packed=pk,
+                                precision="fp32" if precision == "fp32" else "split")
+        gx = ops.transform_bwd_input(gagg, g, w, root, relu_mask=x, graph=graph, amax=(g_amax, g_amax), amax_mul=wb,
+                                     packed=pk, precision=precision)
+        gp = ops.transform_bwd_params(agg, x, g, r, graph=graph, amax=(x_amax, x_amax, g_amax), precision=precision)
+        return (fwd, gx) + tuple(gp)
+
+    want = run()
+    for it in range(100):
+        got = run()
+        if it % 9 == 0:
+            torch.randn(1 << 22, device=dev)                 # other traffic between the launches
+        for name, a, b in zip(("fwd", "bwd_input", "grad_weight", "grad_root", "grad_bias"), got, want):
+            assert torch.equal(a, b), (name, it)
