@@ -1287,6 +1287,10 @@ def test_fused_layer_forward_is_bit_identical_to_gather_then_transform(n, e, r, 
         assert float(ops.amax_value(got_amax)) == float(ops.amax_value(want_amax)) == float(want.abs().max())
     ref = agg.double() @ weight.double().reshape(r * d_in, d_out) + bias.double()
     assert float((got.double() - ref).abs().max()) <= FWD_ATOL * max(1.0, float(ref.abs().max()))
+    # STORE mode: the aggregate the kernel formed, written out as well (a training forward keeps it)
+    kept = torch.zeros(n, r * d_in, device=dev)
+    again = ops.layer_fwd_fused(graph, x, packed, bs, relu, x_amax, None, inline_limit=limit, agg_out=kept)
+    assert torch.equal(again, got) and torch.equal(kept, agg)
     with pytest.raises(ValueError):
         graph.fused_plan(65)
     assert not ops.fused_supported(r, d_in, 64) and not ops.fused_supported(40, d_in, d_out)
