@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 10
+#define RGCN_ABI_VERSION 11
 
 enum {
   RGCN_OK = 0,
@@ -271,7 +271,8 @@ int rgcn_absmax(const float* x, int64_t n, float* out, float* zero_buffers, int 
 int rgcn_absmax_multi(int count, const float* const* tensors, const int64_t* numels, float* const* outs,
                       float* zero_buffers, int zero_count, void* stream);
 /* The weights of one layer split ONCE per step for both transforms that multiply by them ([W ; root] as fp16
- * hi / lo images in the forward and in the input-gradient orientation, one scale): pass the result as `packed`
+ * hi / lo images in the forward and in the input-gradient orientation - each k-contiguous and in MFMA
+ * B-fragment order -, one scale): pass the result as `packed`
  * to the two calls below; with packed == NULL each call splits the weights itself (into its workspace). */
 size_t rgcn_weights_split_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
 int rgcn_weights_split_pack(const float* weight, const float* root, int64_t num_relations, int64_t d_in,
@@ -325,8 +326,7 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
  *                 reduce, same bits.  A segment's mean divides by its number of entries.
  *   tile_mask     rgcn_graph_tile_mask of the forward structure (relations no row of a 32-row block has are
  *                 skipped), or NULL
- *   packed        rgcn_weights_split_pack of this layer; frag: its forward images in MFMA fragment order
- *                 (rgcn_layer_fwd_fused_pack into rgcn_layer_fwd_fused_weights_bytes bytes), valid while packed is
+ *   packed        rgcn_weights_split_pack of this layer (the kernel reads its fragment-order forward images)
  *   x_amax        amax buffer of x (rgcn_absmax): scale of the whole A operand (a mean cannot exceed it)
  *   out_amax      optional amax buffer that receives max |out| (the next layer's x_amax)
  *   agg           NULL, or [N, R * d_in]: the aggregate is ALSO written there (the training forward keeps it for
@@ -335,12 +335,9 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
  *                 the same graph filled
  * ---------------------------------------------------------------------------------- */
 int rgcn_layer_fwd_fused_supported(int64_t num_relations, int64_t d_in, int64_t d_out);
-size_t rgcn_layer_fwd_fused_weights_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
-int rgcn_layer_fwd_fused_pack(const void* packed, int has_root, int64_t num_relations, int64_t d_in, int64_t d_out,
-                              void* frag, size_t frag_bytes, void* stream);
 int rgcn_layer_fwd_fused(const int32_t* rowptr, const int32_t* col, const uint32_t* tile_mask, int64_t num_nodes,
                          int64_t num_relations, const float* hub_agg, const float* x, const void* packed,
-                         const void* frag, int has_root, const float* bias, int relu, int64_t d_in, int64_t d_out,
+                         int has_root, const float* bias, int relu, int64_t d_in, int64_t d_out,
                          const float* x_amax, float* out, float* out_amax, float* agg, void* stream);
 
 /* ------------------------------------------------------------------------------------

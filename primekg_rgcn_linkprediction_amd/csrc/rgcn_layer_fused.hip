@@ -22,8 +22,8 @@
 //            fp16 A images in LDS - no other lane repeats the split, unlike the stand-alone transform where
 //            every wave that shares an A tile splits it again.
 //   multiply wave w owns columns [32 TNW w, 32 TNW (w + 1)): A fragments are two ds_read_b128 (hi, lo), B
-//            fragments come straight from L2 in MFMA register order (k_frag_pack: one coalesced 1 KB read per
-//            wave, fragment and part; no LDS staging: no two waves of the workgroup share a B column), two
+//            fragments come straight from L2 in MFMA register order (k_pack_split's fragment images: one coalesced
+//            1 KB read per wave, fragment and part; no LDS staging: no two waves of the workgroup share a B column), two
 //            k-steps ahead; three v_mfma_f32_32x32x16_f16 per fragment pair, small terms first, exactly the
 //            stand-alone kernel's order - outputs are bit-identical to the unfused pair's.
 // Chunks whose relation no row of the block has (tile_mask) are skipped whole.
@@ -41,21 +41,6 @@ constexpr int kThreads = 256, kRows = 32, kInFlight = 8;
 
 __device__ inline float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ inline void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
-
-// [n][K] (k contiguous) fp16 images -> MFMA B-fragment order: fragment ((s * NT + nt) * 64 + lane) holds the 8
-// consecutive k = 16 s + 8 (lane >> 5) + j of column n = 32 nt + (lane & 31).  One 16-byte fragment per thread.
-__global__ __launch_bounds__(kThreads) void k_frag_pack(const __half* __restrict__ Bh, const __half* __restrict__ Bl,
-                                                        __half* __restrict__ Fh, __half* __restrict__ Fl, int K,
-                                                        int N) {
-  const int64_t f = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-  const int NT = N / 32;
-  if (f >= (int64_t)(K / 16) * NT * 64) return;
-  const int lane = (int)(f & 63);
-  const int nt = (int)((f >> 6) % NT), s = (int)((f >> 6) / NT);
-  const size_t src = (size_t)(32 * nt + (lane & 31)) * K + 16 * s + 8 * (lane >> 5);
-  reinterpret_cast<uint4*>(Fh)[f] = *reinterpret_cast<const uint4*>(Bh + src);
-  reinterpret_cast<uint4*>(Fl)[f] = *reinterpret_cast<const uint4*>(Bl + src);
-}
 
 template <int G, int TNW, bool RELU, bool WIDE, bool STORE_AGG>
 __global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
@@ -257,16 +242,10 @@ __global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
   if (amax_out) rgcn_amax_publish(amax_out, cmax, seen);
 }
 
-size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
-
 bool supported(int64_t R, int64_t d_in, int64_t d_out) {
   if (!(d_in == 64 || d_in == 128 || d_in == 256)) return false;
   if (!(d_out == 128 || d_out == 256)) return false;
   return R >= 1 && R < d_in / 2 && R <= 32;                  // a lane group holds a row's R + 1 segment bounds in <= 2 registers
-}
-
-size_t frag_bytes(int64_t R, int64_t d_in, int64_t d_out) {
-  return 2 * align256((size_t)(R + 1) * d_in * d_out * sizeof(__half));
 }
 
 }  // namespace
@@ -275,37 +254,17 @@ extern "C" {
 
 int rgcn_layer_fwd_fused_supported(int64_t R, int64_t d_in, int64_t d_out) { return supported(R, d_in, d_out) ? 1 : 0; }
 
-size_t rgcn_layer_fwd_fused_weights_bytes(int64_t R, int64_t d_in, int64_t d_out) {
-  return supported(R, d_in, d_out) ? frag_bytes(R, d_in, d_out) : 0;
-}
-
-int rgcn_layer_fwd_fused_pack(const void* packed, int has_root, int64_t R, int64_t d_in, int64_t d_out, void* frag,
-                              size_t frag_bytes_, void* stream_) {
-  if (!packed || !frag) return RGCN_ERR_ARG;
-  if (!supported(R, d_in, d_out)) return RGCN_ERR_UNSUPPORTED;
-  if (frag_bytes_ < frag_bytes(R, d_in, d_out)) return RGCN_ERR_WORKSPACE;
-  const rgcn_split_fwd_view v = rgcn_split_forward_images(packed, R, d_in, d_out);
-  const int K = (int)((R + (has_root ? 1 : 0)) * d_in);
-  __half* Fh = (__half*)frag;
-  __half* Fl = (__half*)((char*)frag + frag_bytes(R, d_in, d_out) / 2);
-  const int64_t frags = (int64_t)(K / 16) * (d_out / 32) * 64;
-  k_frag_pack<<<(unsigned)ceil_div64(frags, kThreads), kThreads, 0, (hipStream_t)stream_>>>(v.Bh, v.Bl, Fh, Fl, K,
-                                                                                          (int)d_out);
-  RGCN_HIP_TRY(hipGetLastError());
-  return RGCN_OK;
-}
-
 int rgcn_layer_fwd_fused(const int32_t* rowptr, const int32_t* col, const uint32_t* tile_mask, int64_t N, int64_t R,
-                         const float* hub_agg, const float* x, const void* packed, const void* frag, int has_root,
+                         const float* hub_agg, const float* x, const void* packed, int has_root,
                          const float* bias, int relu, int64_t d_in, int64_t d_out, const float* x_amax, float* out,
                          float* out_amax, float* agg, void* stream_) {
-  if (N < 0 || !rowptr || !x || !packed || !frag || !x_amax || !out) return RGCN_ERR_ARG;
+  if (N < 0 || !rowptr || !x || !packed || !x_amax || !out) return RGCN_ERR_ARG;
   if (!supported(R, d_in, d_out)) return RGCN_ERR_UNSUPPORTED;
   if (N == 0) return RGCN_OK;
   if (N > INT32_MAX / 2) return RGCN_ERR_UNSUPPORTED;
   const rgcn_split_fwd_view v = rgcn_split_forward_images(packed, R, d_in, d_out);
-  const __half* Fh = (const __half*)frag;
-  const __half* Fl = (const __half*)((const char*)frag + frag_bytes(R, d_in, d_out) / 2);
+  const __half* Fh = v.Fh;
+  const __half* Fl = v.Fl;
   const int chunks = (int)R + (has_root ? 1 : 0);
   const unsigned grid = (unsigned)ceil_div64(N, kRows);
   const uint32_t* tmask = tile_mask;

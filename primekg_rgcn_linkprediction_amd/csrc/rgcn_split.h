@@ -30,10 +30,11 @@ __device__ __host__ inline float pow2f(int s) {
   return f;
 }
 
-// The forward-orientation images of a layer's split weights (rgcn_weights_split_pack): Bh / Bl [d_out][K],
-// K = (R + 1) * d_in, k contiguous, and the inverse of their common scale.  Defined in rgcn_transform_split.hip.
+// The forward-orientation images of a layer's split weights (rgcn_weights_split_pack) in MFMA B-fragment order
+// (element ((s * NT + nt) * 64 + lane) * 8 + j = image[n = 32 nt + (lane & 31)][k = 16 s + 8 (lane >> 5) + j],
+// K = (R + 1) * d_in) and the inverse of their common scale.  Defined in rgcn_transform_split.hip.
 struct rgcn_split_fwd_view {
-  const __half *Bh, *Bl;
+  const __half *Fh, *Fl;
   const float* inv_scale;
 };
 rgcn_split_fwd_view rgcn_split_forward_images(const void* packed, int64_t R, int64_t d_in, int64_t d_out);

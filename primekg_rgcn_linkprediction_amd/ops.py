@@ -184,25 +184,6 @@ def fused_supported(num_relations: int, d_in: int, d_out: int) -> bool:
     return GEMM_PRECISION != "fp32" and bool(_lib.load().rgcn_layer_fwd_fused_supported(num_relations, d_in, d_out))
 
 
-def _fragments(packed: SplitWeights) -> torch.Tensor:
-    """the forward images of ``packed`` in MFMA fragment order (``rgcn_layer_fwd_fused_pack``), made once per
-    ``SplitWeights``"""
-    frag = getattr(packed, "_frag", None)
-    if frag is None:
-        lib = _lib.load()
-        r, d_in, d_out = packed.shape
-        with _on(packed.buf.device):
-            nbytes = lib.rgcn_layer_fwd_fused_weights_bytes(r, d_in, d_out)
-            if nbytes == 0:
-                raise ValueError(f"the fused layer does not cover R={r}, d_in={d_in}, d_out={d_out}")
-            frag = torch.empty(nbytes, dtype=torch.uint8, device=packed.buf.device)
-            rc = lib.rgcn_layer_fwd_fused_pack(_ptr(packed.buf), int(packed.has_root), r, d_in, d_out, _ptr(frag), nbytes,
-                                               _stream())
-        _lib.check(rc, "rgcn_layer_fwd_fused_pack")
-        packed._frag = frag
-    return frag
-
-
 def split_weights(weight: torch.Tensor, root: Optional[torch.Tensor]) -> Optional[SplitWeights]:
     """-> ``SplitWeights`` (None in fp32 mode or for widths the split kernels do not tile)"""
     return split_weights_many([(weight, root)])[0]
@@ -782,7 +763,6 @@ def layer_fwd_fused(graph: BucketedGraph, x: torch.Tensor, packed: SplitWeights,
         if tuple(agg_out.shape) != (graph.num_nodes, r * d_in) or agg_out.device != x.device or not agg_out.is_contiguous():
             raise ValueError(f"agg_out must be a contiguous [{graph.num_nodes}, {r * d_in}] on x's device")
     plan = graph.fused_plan(min(int(inline_limit), d_in // 4))    # one id window of d_in / 4 lanes per segment
-    frag = _fragments(packed)
     hub_agg = aggregate(plan.hub, x) if plan.hub is not None else None
     tile_mask = graph.tile_mask_ptr(False) if graph.num_relations <= 32 else None
     lib = _lib.load()
@@ -795,7 +775,7 @@ def layer_fwd_fused(graph: BucketedGraph, x: torch.Tensor, packed: SplitWeights,
             beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             beg.record()
         rc = lib.rgcn_layer_fwd_fused(_ptr(plan.rowptr), _ptr(plan.col), tile_mask, graph.num_nodes, r, _ptr(hub_agg),
-                                      _ptr(x), _ptr(packed.buf), _ptr(frag), int(packed.has_root), _ptr(bias),
+                                      _ptr(x), _ptr(packed.buf), int(packed.has_root), _ptr(bias),
                                       int(bool(relu)), d_in, d_out, _ptr(amax), _ptr(out), _ptr(amax_out), _ptr(agg_out),
                                       _stream())
         if FUSED_EVENTS is not None:
