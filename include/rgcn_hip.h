@@ -329,10 +329,8 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
  *   packed        rgcn_weights_split_pack of this layer (the kernel reads its fragment-order forward images)
  *   x_amax        amax buffer of x (rgcn_absmax): scale of the whole A operand (a mean cannot exceed it)
  *   out_amax      optional amax buffer that receives max |out| (the next layer's x_amax)
- *   agg           NULL, or [N, R * d_in]: the aggregate is ALSO written there (the training forward keeps it for
- *                 the parameter gradients; it is still not read back here).  Rows of relations no row of a 32-row
- *                 block has are NOT written (they are zero): hand in a zeroed tensor, or one a previous call with
- *                 the same graph filled
+ *   agg           NULL, or [N, R * d_in]: the aggregate is ALSO written there, every row of it (the training
+ *                 forward keeps it for the parameter gradients; it is not read back here)
  * ---------------------------------------------------------------------------------- */
 int rgcn_layer_fwd_fused_supported(int64_t num_relations, int64_t d_in, int64_t d_out);
 int rgcn_layer_fwd_fused(const int32_t* rowptr, const int32_t* col, const uint32_t* tile_mask, int64_t num_nodes,

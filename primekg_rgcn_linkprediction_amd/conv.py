@@ -121,6 +121,33 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
     return ops.aggregate(merged, t.view(-1, d_in), tail=tail)
 
 
+# Training forward of one layer: gather -> transform (two launches, the aggregate written by one and read by the
+# other), or the one-kernel layer in its STORE mode (ops.layer_fwd_fused(agg_out=): the aggregate formed in LDS
+# feeds the MFMAs directly and is written once, for the parameter gradients).  The fused form saves the read of
+# the aggregate - worth it where the path is HBM-bound, i.e. once the aggregate no longer fits the 256 MB
+# Infinity Cache; at C2's size the separate kernels are faster.  RGCN_TRAIN_FUSED = auto
+# (default: by that size) | 1 | 0.  Same bits either way.
+_TRAIN_FUSED = _os.environ.get("RGCN_TRAIN_FUSED", "auto")
+_TRAIN_FUSED_MIN_BYTES = 256 << 20
+
+
+def _layer_train_forward(graph: "ops.BucketedGraph", x: Tensor, gather_dtype, weight, root, bias, relu: bool,
+                         half: bool, x_amax, amax_out, packed):
+    """-> (agg, out) of one layer's training forward"""
+    n, r, d_in, d_out = x.size(0), graph.num_relations, x.size(1), weight.size(2)
+    fused = _TRAIN_FUSED == "1" or (_TRAIN_FUSED == "auto" and n * r * d_in * 4 >= _TRAIN_FUSED_MIN_BYTES)
+    if (fused and not half and packed is not None and x_amax is not None and not graph.weighted_shard
+            and n == graph.num_other_nodes and ops.fused_supported(r, d_in, d_out)):
+        agg = torch.empty(n, r * d_in, dtype=torch.float32, device=x.device)
+        out = ops.layer_fwd_fused(graph, x, packed, bias, relu, x_amax, amax_out, inline_limit=_EVAL_INLINE_LIMIT,
+                                  agg_out=agg)
+        return agg, out
+    agg = ops.aggregate(graph, _table(x, gather_dtype))
+    out = ops.transform_fwd(agg, x, weight, root, bias, relu=relu, graph=graph, half=half, amax=(x_amax, x_amax),
+                            amax_out=amax_out, packed=packed)
+    return agg, out
+
+
 class _RGCNConvFunction(torch.autograd.Function):
     """x, weight[R, d_in, d_out], root, bias -> out (optionally relu(out)), on a bucketed graph."""
 
@@ -137,9 +164,8 @@ class _RGCNConvFunction(torch.autograd.Function):
         scales = _Scales(x, slots=1)
         x_amax = scales.first            # also the bound of agg: a mean of rows cannot exceed the table's maximum
         packed = ops.split_weights(weight, root_c)                                    # once, for forward and backward
-        agg = ops.aggregate(graph, _table(x, gather_dtype), transposed=False)          # rows A3 + A4
-        out = ops.transform_fwd(agg, x, weight, root_c, bias_c, relu=relu, graph=graph, half=half,
-                                amax=(x_amax, x_amax), packed=packed)                  # row A6 (+ fused ReLU)
+        agg, out = _layer_train_forward(graph, x, gather_dtype, weight, root_c, bias_c, relu, half, x_amax, None,
+                                        packed)                                        # rows A3 + A4, A6 (+ fused ReLU)
         ctx.graph, ctx.relu, ctx.packed = graph, relu, packed
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
         ctx.save_for_backward(x, agg, weight, root_c, out if relu else None, x_amax)
@@ -200,14 +226,11 @@ class _Encoder2Function(torch.autograd.Function):
         x_amax, h_amax = scales.first, scales.slot()
         wmax = None if scales.first is None else [(scales.extra[0], scales.extra[1]), (scales.extra[2], scales.extra[3])]
         pk1, pk2 = ops.split_weights_many([(w1, root1), (w2, root2)], amax=wmax)   # once, for forward and backward
-        agg1 = ops.aggregate(graph, _table(x, gather_dtype))
-        h = ops.transform_fwd(agg1, x, w1, root1, b1, relu=True, graph=graph, half=half, amax=(x_amax, x_amax),
-                              amax_out=h_amax, packed=pk1)
+        agg1, h = _layer_train_forward(graph, x, gather_dtype, w1, root1, b1, True, half, x_amax, h_amax, pk1)
         if p > 0:
             h = torch.native_dropout(h, p, True)[0]
             h_amax = h_amax * (1.0 / (1.0 - p)) if h_amax is not None else None     # kept units are scaled up
-        agg2 = ops.aggregate(graph, _table(h, gather_dtype))
-        out = ops.transform_fwd(agg2, h, w2, root2, b2, graph=graph, half=half, amax=(h_amax, h_amax), packed=pk2)
+        agg2, out = _layer_train_forward(graph, h, gather_dtype, w2, root2, b2, False, half, h_amax, None, pk2)
         ctx.graph, ctx.p, ctx.packed = graph, p, (pk1, pk2)
         ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
         ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax)

@@ -118,6 +118,18 @@ __global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
     const int c0 = __ffsll((long long)todo) - 1;
     if (c0 < R) fetch_ids(c0);
   }
+  if (STORE_AGG) {                               // relations no row of this block has: their aggregate rows are zero
+    unsigned long long absent = ~todo & ((1ull << R) - 1ull);
+    while (absent) {
+      const int c = __ffsll((long long)absent) - 1;
+      absent &= absent - 1ull;
+#pragma unroll
+      for (int q = 0; q < RPG; ++q) {
+        const int node = m0 + grp * RPG + q;
+        if (node < N) *reinterpret_cast<float4*>(agg + ((size_t)node * R + c) * D_IN + 4 * gl) = f4zero();
+      }
+    }
+  }
 
   int parity = 0;
   while (todo) {

@@ -741,7 +741,7 @@ def layer_fwd_fused(graph: BucketedGraph, x: torch.Tensor, packed: SplitWeights,
     LDS (``rgcn_layer_fwd_fused``): no ``[N, R * d_in]`` aggregate in HBM.  Segments longer than ``inline_limit``
     edges are pre-aggregated by the ordinary gather over ``graph.fused_plan(inline_limit).hub``.  Bit-identical
     to ``aggregate`` -> ``transform_fwd(precision="split")``.  ``amax``: amax buffer of ``x``.  ``agg_out``
-    (ZEROED ``[N, R * d_in]``, optional): also receives the aggregate, for a backward that needs it."""
+    (``[N, R * d_in]``, optional): also receives the aggregate, for a backward that needs it."""
     _need_gpu("x", x, torch.float32)
     if graph.weighted_shard:
         raise ValueError("the fused layer covers mean structures only")

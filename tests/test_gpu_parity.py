@@ -1288,7 +1288,7 @@ def test_fused_layer_forward_is_bit_identical_to_gather_then_transform(n, e, r, 
     ref = agg.double() @ weight.double().reshape(r * d_in, d_out) + bias.double()
     assert float((got.double() - ref).abs().max()) <= FWD_ATOL * max(1.0, float(ref.abs().max()))
     # STORE mode: the aggregate the kernel formed, written out as well (a training forward keeps it)
-    kept = torch.zeros(n, r * d_in, device=dev)
+    kept = torch.full((n, r * d_in), float("nan"), device=dev)      # every row is written
     again = ops.layer_fwd_fused(graph, x, packed, bs, relu, x_amax, None, inline_limit=limit, agg_out=kept)
     assert torch.equal(again, got) and torch.equal(kept, agg)
     with pytest.raises(ValueError):
@@ -1357,3 +1357,36 @@ def test_transforms_return_the_same_bits_every_run(d_in, d_out, precision):
             torch.randn(1 << 22, device=dev)                 # other traffic between the launches
         for name, a, b in zip(("fwd", "bwd_input", "grad_weight", "grad_root", "grad_bias"), got, want):
             assert torch.equal(a, b), (name, it)
+
+
+@pytest.mark.gpu
+def test_training_forward_through_the_fused_layer_changes_no_bit(monkeypatch):
+    """RGCN_TRAIN_FUSED=1 (the default once the aggregate outgrows the Infinity Cache): the training forward runs
+    each layer as the one-kernel layer in STORE mode - the aggregate it formed in LDS is written once, for the
+    parameter gradients, and not read back.  Output, every gradient and the kept aggregate equal the two-launch
+    path's bit for bit (two-layer node with dropout 0, and the single-layer node)."""
+    from primekg_rgcn_linkprediction_amd import conv as C
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=250000, seed=21)
+    eid, etd = ei.to(dev), et.to(dev)
+    torch.manual_seed(8)
+    emb = torch.nn.init.xavier_uniform_(torch.empty(n, 64)).to(dev)
+    convs = [RGCNConv(64, 128, r).to(dev), RGCNConv(128, 128, r).to(dev)]
+    for c in convs:
+        c.bias.data.uniform_(-0.1, 0.1)
+    cot = torch.randn(n, 128, device=dev)
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setattr(C, "_TRAIN_FUSED", mode)
+        events = []
+        monkeypatch.setattr(ops, "FUSED_EVENTS", events)
+        e = emb.clone().requires_grad_(True)
+        for c in convs:
+            c.zero_grad()
+        out = rgcn_encoder2(e, eid, etd, convs[0], convs[1])
+        (out * cot).sum().backward()
+        single = convs[0](e.detach(), eid, etd, activation="relu")
+        assert len(events) == (3 if mode == "1" else 0)        # the path was taken (two layers + the single layer)
+        results[mode] = [out.detach(), e.grad.clone(), single.detach()] + [p.grad.clone() for c in convs for p in c.parameters()]
+    for a, b in zip(results["0"], results["1"]):
+        assert torch.equal(a, b)
