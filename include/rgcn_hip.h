@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 11
+#define RGCN_ABI_VERSION 12
 
 enum {
   RGCN_OK = 0,
@@ -337,6 +337,22 @@ int rgcn_layer_fwd_fused(const int32_t* rowptr, const int32_t* col, const uint32
                          int64_t num_relations, const float* hub_agg, const float* x, const void* packed,
                          int has_root, const float* bias, int relu, int64_t d_in, int64_t d_out,
                          const float* x_amax, float* out, float* out_amax, float* agg, void* stream);
+
+/* The input gradient of one layer the same way (row A7's dense half + the autograd of A3 + A4):
+ *   grad_x = [transposed-aggregate(g) | g] * [W_r^T ; root^T]  (* (relu_mask > 0))
+ * with the 1/cnt-weighted sums over out-edges formed in LDS - no [N, R * d_out] tensor in HBM.  rowptr_t / col_t /
+ * w_t: the CSR of the TRANSPOSED structure (rgcn_graph_export(transposed = 1): segments (source, relation), ids =
+ * destinations, w_t = 1 / cnt[destination, relation]) with the same convention for long segments: ONE entry, id =
+ * -(row + 1) of hub_agg, weight 1, the row pre-aggregated by rgcn_aggregate over a weighted structure of the long
+ * segments.  g_amax: amax buffer of g; gagg_amax_mul: rgcn_graph_weight_bound(g, 1) (the bound that scales the
+ * weighted sums).  Shapes: d_out in {64, 128, 256}, d_in in {64, 128, 256}, num_relations < d_out / 2 and <= 32.
+ * Bit-identical to rgcn_aggregate(transposed) -> rgcn_transform_bwd_input_split. */
+int rgcn_layer_bwd_input_fused_supported(int64_t num_relations, int64_t d_in, int64_t d_out);
+int rgcn_layer_bwd_input_fused(const int32_t* rowptr_t, const int32_t* col_t, const float* w_t,
+                               const uint32_t* tile_mask_t, int64_t num_nodes, int64_t num_relations,
+                               const float* hub_agg, const float* g, const void* packed, int has_root,
+                               const float* relu_mask, int64_t d_in, int64_t d_out, const float* g_amax,
+                               float gagg_amax_mul, float* grad_x, float* grad_x_amax, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * DistMult head (rows C1 + C2; rgcn.py:325-326 row gathers + rgcn.py:207-211):

@@ -13,7 +13,7 @@ from ctypes import c_float, POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -82,6 +82,9 @@ PROTOTYPES = {
                                                       _P, _P, _P, _P, c_size_t, _P, POINTER(SlabJob)]),
     "rgcn_layer_fwd_fused_supported": (c_int, [_I64, _I64, _I64]),
     "rgcn_layer_fwd_fused": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, c_int, _P, c_int, _I64, _I64, _P, _P, _P, _P, _P]),
+    "rgcn_layer_bwd_input_fused_supported": (c_int, [_I64, _I64, _I64]),
+    "rgcn_layer_bwd_input_fused": (c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, c_int, _P, _I64, _I64, _P, c_float, _P, _P,
+                                           _P]),
     "distmult_fwd": (c_int, [_P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P]),
     "rgcn_index_error_fetch": (c_int, [POINTER(c_int), _P]),
     "distmult_bwd_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),

@@ -92,6 +92,14 @@ import os as _os
 _TRANSFORM_FIRST_RATIO = float(_os.environ.get("RGCN_TRANSFORM_FIRST_RATIO", "4"))   # A/B switch, see _input_grad
 
 
+def _fused_backward(graph, g, r, d_in, d_out, g_amax, packed, precision) -> bool:
+    """the one-kernel input gradient (ops.layer_bwd_input_fused) under the policy of _layer_train_forward: where
+    the transposed aggregate [N, R * d_out] would no longer fit the Infinity Cache (or RGCN_TRAIN_FUSED=1)"""
+    fused = _TRAIN_FUSED == "1" or (_TRAIN_FUSED == "auto" and g.size(0) * r * d_out * 4 >= _TRAIN_FUSED_MIN_BYTES)
+    return (fused and precision is None and packed is not None and g_amax is not None and not graph.bipartite
+            and ops.GEMM_PRECISION == "split" and ops.fused_bwd_supported(r, d_in, d_out))
+
+
 def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Optional[Tensor],
                 tail: Optional["ops.PendingParamGrads"] = None, g_amax: Optional[Tensor] = None,
                 scales: Optional[_Scales] = None, packed: Optional["ops.SplitWeights"] = None,
@@ -111,6 +119,8 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
               if (d_out >= _TRANSFORM_FIRST_RATIO * d_in and root is not None and not graph.bipartite) else None)
     # `tail`: the pending slab reduction of this layer's parameter gradients rides in the gather launch
     if merged is None:
+        if _fused_backward(graph, g, r, d_in, d_out, g_amax, packed, precision):
+            return ops.layer_bwd_input_fused(graph, g, packed, None, g_amax, inline_limit=_EVAL_INLINE_LIMIT, tail=tail)
         gagg = ops.aggregate(graph, g, transposed=True, tail=tail)       # autograd of A3 + A4 (fp32 grads)
         # |gagg| <= (largest sum of 1/cnt weights over a node's out-edges of one relation) * max |g|
         return ops.transform_bwd_input(gagg, g, weight, root, graph=graph, amax=(g_amax, g_amax),
@@ -250,13 +260,17 @@ class _Encoder2Function(torch.autograd.Function):
         prec = ctx.bwd_precision
         red2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2, graph=graph,
                                         defer=True, amax=(h_amax, h_amax, g_amax), precision=prec)
-        gagg2 = ops.aggregate(graph, g, transposed=True, tail=red2)
         if ctx.p > 0:
             scale = 1.0 / (1.0 - ctx.p)
             w2, root2 = w2 * scale, (root2 * scale if root2 is not None else None)
             pk2 = None                                                      # split for the unscaled weights
-        gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph, amax=(g_amax, g_amax),
-                                     amax_mul=wb, amax_out=gz_amax, packed=pk2, precision=prec)   # d loss / d (pre-ReLU of conv1)
+        if _fused_backward(graph, g, r, w2.size(1), w2.size(2), g_amax, pk2, prec):
+            gz = ops.layer_bwd_input_fused(graph, g, pk2, h, g_amax, amax_out=gz_amax, inline_limit=_EVAL_INLINE_LIMIT,
+                                           tail=red2)
+        else:
+            gagg2 = ops.aggregate(graph, g, transposed=True, tail=red2)
+            gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph, amax=(g_amax, g_amax),
+                                         amax_mul=wb, amax_out=gz_amax, packed=pk2, precision=prec)   # d loss / d (pre-ReLU of conv1)
         red1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1, graph=graph,
                                         defer=True, amax=(x_amax, x_amax, gz_amax), precision=prec)
         gx = None

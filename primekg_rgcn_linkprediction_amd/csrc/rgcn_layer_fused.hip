@@ -41,16 +41,28 @@ constexpr int kThreads = 256, kRows = 32, kInFlight = 8;
 
 __device__ inline float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ inline void f4add(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ inline void f4fma(float4& a, const float4& b, float s) {   // explicit fma: one rounding, in every build
+  a.x = fmaf(b.x, s, a.x); a.y = fmaf(b.y, s, a.y); a.z = fmaf(b.z, s, a.z); a.w = fmaf(b.w, s, a.w);
+}
 
-template <int G, int TNW, bool RELU, bool WIDE, bool STORE_AGG>
-__global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
+// EPI: 0 none, 1 ReLU, 2 multiply by (mask > 0).  NT: 32-column tiles of the output; wave w owns tiles
+// [w TNW, (w + 1) TNW) - with NT = 2 (a 64-wide output: the input gradient of a 64 -> 128 layer) waves 2 and 3
+// gather but do not multiply.  WEIGHTED: the transposed structure - a segment's rows are summed with per-edge
+// weights (fma, edge order, no division: k_aggregate<., true>'s arithmetic), the chunks of the weighted sums are
+// scaled by the bound a1_mul * max |table| and the accumulators re-expressed once in the table's own scale before
+// the last chunk (the rows themselves), exactly as k_gemm_nt_split hands over from A1 to A2.
+template <int G, int TNW, int NT, int EPI, bool WIDE, bool STORE_AGG, bool WEIGHTED>
+__global__ __launch_bounds__(kThreads) void k_layer_fused(
     const float* __restrict__ x, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-    const float* __restrict__ hub_agg, const __half* __restrict__ Fh, const __half* __restrict__ Fl, const float* __restrict__ b_inv_scale,
-    const float* __restrict__ x_amax, const float* __restrict__ bias, float* __restrict__ out,
-    float* __restrict__ agg, int N, int R, int chunks, const uint32_t* __restrict__ tile_mask, unsigned* __restrict__ amax_out) {
+    const float* __restrict__ wts, const float* __restrict__ hub_agg, const __half* __restrict__ Fh,
+    const __half* __restrict__ Fl, const float* __restrict__ b_inv_scale, const float* __restrict__ x_amax,
+    float a1_mul, const float* __restrict__ bias, const float* __restrict__ mask, float* __restrict__ out,
+    float* __restrict__ agg, int N, int R, int chunks, const uint32_t* __restrict__ tile_mask,
+    unsigned* __restrict__ amax_out) {
   constexpr int D_IN = 4 * G, KS = D_IN / 16, NG = kThreads / G, RPG = kRows / NG;
   constexpr int ROWB = D_IN * 2 + 16;            // bytes of one A row per image: + 16 keeps the fragment reads conflict-free
-  constexpr int NT = 4 * TNW, D_OUT = 32 * NT;
+  constexpr int D_OUT = 32 * NT;
+  static_assert(NT == 4 * TNW || (NT == 2 && TNW == 1), "column tiles per wave");
   // k-steps the B fragments are loaded ahead: registers decide (4 waves per SIMD need VGPRs + AGPRs <= 128)
   constexpr int kAhead = G == 16 ? 2 : RGCN_FUSED_AHEAD_WIDE;
   // two A buffers (hi and lo image each): a chunk is gathered into the one the previous chunk's multiply does not
@@ -80,8 +92,10 @@ __global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
   const unsigned seen = rgcn_amax_peek(amax_out);
   unsigned rel_mask = tile_mask ? tile_mask[blockIdx.x] : 0xffffffffu;
   rel_mask = __builtin_amdgcn_readfirstlane(rel_mask);
-  const int ea = scale_exponent(rgcn_amax_value(x_amax, lane));
-  const float sa = pow2f(ea);
+  const float xmax = rgcn_amax_value(x_amax, lane);
+  const int ea2 = scale_exponent(xmax);                        // the table's own scale (last chunk; every chunk of a mean)
+  const int ea1 = WEIGHTED ? scale_exponent(xmax * a1_mul) : ea2;
+  const bool has_cols = NT == 4 * TNW || wave * TNW < NT;      // this wave multiplies (always, unless the output is 64 wide)
 
   floatx16 acc[TNW];
 #pragma unroll
@@ -101,14 +115,21 @@ __global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
   // j).  An id < 0 is row -id - 1 of hub_agg: the plan replaces every segment longer than its inline limit by ONE
   // such entry (mean of one row = the row), and keeps every segment within G entries; a longer one (a caller's own
   // CSR) is finished by the slow loop below.
-  constexpr int U = kInFlight / RPG;             // row loads in flight per lane: U per row, all rows of the group at once
+  // Row loads in flight per lane: U per row, all rows of the group at once.  The gather runs at the rate
+  // (waves per SIMD) x (loads in flight per lane) allows; a variant whose other registers already cost it a wave or
+  // two (the weights; the kept aggregate's stores at 128-wide rows) spends the registers those slots leave on more
+  // loads.
+  constexpr int kLoads = TNW > 1 ? kInFlight : (WEIGHTED ? 2 * kInFlight : ((STORE_AGG && G == 32) ? kInFlight * 3 / 2 : kInFlight));
+  constexpr int U = kLoads / RPG > 0 ? kLoads / RPG : 1;
   int beg[RPG], len[RPG], idw[RPG];
+  float wdw[WEIGHTED ? RPG : 1];
   auto fetch_ids = [&](int c) {                  // c < R, uniform: entry c sits in lane c % G of register c / G
 #pragma unroll
     for (int q = 0; q < RPG; ++q) {
       beg[q] = __shfl(rp[q][WIDE && c >= G], c & (G - 1), G);
       len[q] = __shfl(rp[q][WIDE && c + 1 >= G], (c + 1) & (G - 1), G) - beg[q];
       idw[q] = gl < len[q] ? col[beg[q] + gl] : 0;
+      if (WEIGHTED) wdw[q] = gl < len[q] ? wts[beg[q] + gl] : 0.f;
     }
   };
   auto row_of = [&](int id) -> const float* {    // a table row, or a pre-aggregated one
@@ -142,6 +163,7 @@ __global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
     uint4 qh[kAhead + 1][TNW], ql[kAhead + 1][TNW];
     const size_t fbase = ((size_t)c * KS * NT + wave * TNW) * 64 + lane;
     auto load_b = [&](int s, int slot) {
+      if (!has_cols) return;
 #pragma unroll
       for (int b = 0; b < TNW; ++b) {
         const size_t f = fbase + ((size_t)s * NT + b) * 64;
@@ -180,18 +202,28 @@ __global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
 #pragma unroll
         for (int q = 0; q < RPG; ++q)
 #pragma unroll
-          for (int u = 0; u < U; ++u) f4add(a[q], v[q][u]);
+          for (int u = 0; u < U; ++u) {
+            if (WEIGHTED) f4fma(a[q], v[q][u], __shfl(wdw[q], (p + u) & (G - 1), G));   // padding: row 0, weight 0
+            else f4add(a[q], v[q][u]);
+          }
       }
 #pragma unroll
       for (int q = 0; q < RPG; ++q) {
-        if (len[q] <= 1) continue;                           // sum / 1 = sum
+        if (len[q] <= (WEIGHTED ? G : 1)) continue;          // nothing beyond the window; sum / 1 = sum
         for (int w0 = beg[q] + G; w0 < beg[q] + len[q]; w0 += G) {   // beyond the plan's limit: G ids at a time
           const int wn = min(G, beg[q] + len[q] - w0);
           const int ids = gl < wn ? col[w0 + gl] : 0;
-          for (int p = 0; p < wn; ++p) f4add(a[q], *reinterpret_cast<const float4*>(row_of(__shfl(ids, p, G))));
+          const float ws = (WEIGHTED && gl < wn) ? wts[w0 + gl] : 0.f;
+          for (int p = 0; p < wn; ++p) {
+            const float4 row = *reinterpret_cast<const float4*>(row_of(__shfl(ids, p, G)));
+            if (WEIGHTED) f4fma(a[q], row, __shfl(ws, p, G));
+            else f4add(a[q], row);
+          }
         }
-        const float cq = (float)len[q];                      // true division, as `sum / count` does
-        a[q].x /= cq; a[q].y /= cq; a[q].z /= cq; a[q].w /= cq;
+        if (!WEIGHTED) {
+          const float cq = (float)len[q];                    // true division, as `sum / count` does
+          a[q].x /= cq; a[q].y /= cq; a[q].z /= cq; a[q].w /= cq;
+        }
       }
     }
 #pragma unroll
@@ -203,7 +235,7 @@ __global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
       const float av[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float v = av[k] * sa;
+        const float v = av[k] * pow2f(c < R ? ea1 : ea2);
         h[k] = (_Float16)v;
         l[k] = (_Float16)(v - (float)h[k]);
       }
@@ -217,6 +249,14 @@ __global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
     __syncthreads();
 
     // ---- multiply: KS k-steps of this chunk ----
+    if (WEIGHTED && c == R) {                    // sums so far -> the table's own scale (two exact power-of-two factors)
+      const float down = pow2f(-ea1), up = pow2f(ea2);
+#pragma unroll
+      for (int b = 0; b < TNW; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = acc[b][r] * down * up;
+    }
+    if (has_cols)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       if (s + kAhead < KS) load_b(s + kAhead, (s + kAhead) % (kAhead + 1));
@@ -234,86 +274,142 @@ __global__ __launch_bounds__(kThreads) void k_layer_fwd_fused(
   }
 
   // C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const float ia = pow2f(-ea), ib = b_inv_scale[0];
+  const float ia = pow2f(chunks > R ? -ea2 : -ea1), ib = b_inv_scale[0];
   float cmax = 0.f;
+  if (has_cols) {
+    float mk[TNW][16];
+    if (EPI == 2) {                              // all mask loads in flight together (rows past N: a valid row)
 #pragma unroll
-  for (int b = 0; b < TNW; ++b) {
-    const int n = (wave * TNW + b) * 32 + li;
-    const float bv = bias ? bias[n] : 0.f;
+      for (int b = 0; b < TNW; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m < N) {
+        for (int r = 0; r < 16; ++r) {
+          const int m = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * lh, N - 1);
+          mk[b][r] = mask[(size_t)m * D_OUT + (wave * TNW + b) * 32 + li];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < TNW; ++b) {
+      const int n = (wave * TNW + b) * 32 + li;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         float v = acc[b][r] * ia * ib + bv;
-        if (RELU) v = fmaxf(v, 0.f);
-        cmax = fmaxf(cmax, fabsf(v));
-        out[(size_t)m * D_OUT + n] = v;
+        if (EPI == 1) v = fmaxf(v, 0.f);
+        if (EPI == 2) v = mk[b][r] > 0.f ? v : 0.f;
+        if (m < N) {
+          cmax = fmaxf(cmax, fabsf(v));
+          out[(size_t)m * D_OUT + n] = v;
+        }
       }
     }
   }
   if (amax_out) rgcn_amax_publish(amax_out, cmax, seen);
 }
 
-bool supported(int64_t R, int64_t d_in, int64_t d_out) {
-  if (!(d_in == 64 || d_in == 128 || d_in == 256)) return false;
-  if (!(d_out == 128 || d_out == 256)) return false;
-  return R >= 1 && R < d_in / 2 && R <= 32;                  // a lane group holds a row's R + 1 segment bounds in <= 2 registers
+// dk: width of the gathered rows (= k per chunk), dn: output width
+bool supported(int64_t R, int64_t dk, int64_t dn, bool weighted) {
+  if (!(dk == 64 || dk == 128 || dk == 256)) return false;
+  if (!(dn == 128 || dn == 256 || (weighted && dn == 64))) return false;
+  return R >= 1 && R < dk / 2 && R <= 32;                    // a lane group holds a row's R + 1 segment bounds in <= 2 registers
+}
+
+struct fused_args {
+  const float* x;
+  const int32_t *rowptr, *col;
+  const float *wts, *hub_agg;
+  const __half *Fh, *Fl;
+  const float *b_inv, *x_amax;
+  float a1_mul;
+  const float *bias, *mask;
+  float *out, *agg;
+  int N, R, chunks;
+  const uint32_t* tile_mask;
+  unsigned* amax_out;
+};
+
+template <int G, int TNW, int NT, int EPI, bool WIDE, bool STORE, bool WEIGHTED>
+void launch_one(const fused_args& a, hipStream_t stream) {
+  k_layer_fused<G, TNW, NT, EPI, WIDE, STORE, WEIGHTED><<<(unsigned)ceil_div64(a.N, kRows), kThreads, 0, stream>>>(
+      a.x, a.rowptr, a.col, a.wts, a.hub_agg, a.Fh, a.Fl, a.b_inv, a.x_amax, a.a1_mul, a.bias, a.mask, a.out, a.agg, a.N,
+      a.R, a.chunks, a.tile_mask, a.amax_out);
+}
+
+// forward (mean): EPI in {none, ReLU}, optional STORE; input gradient (weighted): EPI in {none, mask}
+template <int G, int TNW, int NT, bool WEIGHTED>
+void launch_shape(const fused_args& a, int epi, hipStream_t stream) {
+  const bool wide = a.R >= G;
+  if constexpr (WEIGHTED) {
+    if (epi == 2) wide ? launch_one<G, TNW, NT, 2, true, false, true>(a, stream) : launch_one<G, TNW, NT, 2, false, false, true>(a, stream);
+    else wide ? launch_one<G, TNW, NT, 0, true, false, true>(a, stream) : launch_one<G, TNW, NT, 0, false, false, true>(a, stream);
+  } else if (a.agg) {
+    if (epi == 1) wide ? launch_one<G, TNW, NT, 1, true, true, false>(a, stream) : launch_one<G, TNW, NT, 1, false, true, false>(a, stream);
+    else wide ? launch_one<G, TNW, NT, 0, true, true, false>(a, stream) : launch_one<G, TNW, NT, 0, false, true, false>(a, stream);
+  } else {
+    if (epi == 1) wide ? launch_one<G, TNW, NT, 1, true, false, false>(a, stream) : launch_one<G, TNW, NT, 1, false, false, false>(a, stream);
+    else wide ? launch_one<G, TNW, NT, 0, true, false, false>(a, stream) : launch_one<G, TNW, NT, 0, false, false, false>(a, stream);
+  }
+}
+
+template <bool WEIGHTED>
+int launch_fused(const fused_args& a, int64_t dk, int64_t dn, int epi, hipStream_t stream) {
+#define RGCN_FUSED_DK(TNW_, NT_)                                              \
+  do {                                                                        \
+    if (dk == 64) launch_shape<16, TNW_, NT_, WEIGHTED>(a, epi, stream);      \
+    else if (dk == 128) launch_shape<32, TNW_, NT_, WEIGHTED>(a, epi, stream); \
+    else launch_shape<64, TNW_, NT_, WEIGHTED>(a, epi, stream);               \
+  } while (0)
+  if (dn == 128) RGCN_FUSED_DK(1, 4);
+  else if (dn == 256) RGCN_FUSED_DK(2, 8);
+  else if constexpr (WEIGHTED) RGCN_FUSED_DK(1, 2);
+  else return RGCN_ERR_UNSUPPORTED;
+#undef RGCN_FUSED_DK
+  RGCN_HIP_TRY(hipGetLastError());
+  return RGCN_OK;
 }
 
 }  // namespace
 
 extern "C" {
 
-int rgcn_layer_fwd_fused_supported(int64_t R, int64_t d_in, int64_t d_out) { return supported(R, d_in, d_out) ? 1 : 0; }
+int rgcn_layer_fwd_fused_supported(int64_t R, int64_t d_in, int64_t d_out) { return supported(R, d_in, d_out, false) ? 1 : 0; }
+int rgcn_layer_bwd_input_fused_supported(int64_t R, int64_t d_in, int64_t d_out) { return supported(R, d_out, d_in, true) ? 1 : 0; }
 
 int rgcn_layer_fwd_fused(const int32_t* rowptr, const int32_t* col, const uint32_t* tile_mask, int64_t N, int64_t R,
                          const float* hub_agg, const float* x, const void* packed, int has_root,
                          const float* bias, int relu, int64_t d_in, int64_t d_out, const float* x_amax, float* out,
                          float* out_amax, float* agg, void* stream_) {
   if (N < 0 || !rowptr || !x || !packed || !x_amax || !out) return RGCN_ERR_ARG;
-  if (!supported(R, d_in, d_out)) return RGCN_ERR_UNSUPPORTED;
+  if (!supported(R, d_in, d_out, false)) return RGCN_ERR_UNSUPPORTED;
   if (N == 0) return RGCN_OK;
   if (N > INT32_MAX / 2) return RGCN_ERR_UNSUPPORTED;
-  const rgcn_split_fwd_view v = rgcn_split_forward_images(packed, R, d_in, d_out);
-  const __half* Fh = v.Fh;
-  const __half* Fl = v.Fl;
-  const int chunks = (int)R + (has_root ? 1 : 0);
-  const unsigned grid = (unsigned)ceil_div64(N, kRows);
-  const uint32_t* tmask = tile_mask;
-  unsigned* amax_out = reinterpret_cast<unsigned*>(out_amax);
-  hipStream_t stream = (hipStream_t)stream_;
-#define RGCN_FUSED_LAUNCH2(G_, TNW_, RELU_, WIDE_, STORE_)                                                          \
-  k_layer_fwd_fused<G_, TNW_, RELU_, WIDE_, STORE_><<<grid, kThreads, 0, stream>>>(                                    \
-      x, rowptr, col, hub_agg, Fh, Fl, v.inv_scale, x_amax, bias, out, agg, (int)N, (int)R, chunks, tmask, amax_out)
-#define RGCN_FUSED_LAUNCH(G_, TNW_, RELU_, WIDE_)             \
-  do {                                                         \
-    if (agg) RGCN_FUSED_LAUNCH2(G_, TNW_, RELU_, WIDE_, true); \
-    else RGCN_FUSED_LAUNCH2(G_, TNW_, RELU_, WIDE_, false);    \
-  } while (0)
-#define RGCN_FUSED(G_, TNW_)                                   \
-  do {                                                         \
-    if (R >= G_) {                                             \
-      if (relu) RGCN_FUSED_LAUNCH(G_, TNW_, true, true);       \
-      else RGCN_FUSED_LAUNCH(G_, TNW_, false, true);           \
-    } else {                                                   \
-      if (relu) RGCN_FUSED_LAUNCH(G_, TNW_, true, false);      \
-      else RGCN_FUSED_LAUNCH(G_, TNW_, false, false);          \
-    }                                                          \
-  } while (0)
-  if (d_out == 128) {
-    if (d_in == 64) RGCN_FUSED(16, 1);
-    else if (d_in == 128) RGCN_FUSED(32, 1);
-    else RGCN_FUSED(64, 1);
-  } else {
-    if (d_in == 64) RGCN_FUSED(16, 2);
-    else if (d_in == 128) RGCN_FUSED(32, 2);
-    else RGCN_FUSED(64, 2);
-  }
-#undef RGCN_FUSED
-#undef RGCN_FUSED_LAUNCH
-#undef RGCN_FUSED_LAUNCH2
-  RGCN_HIP_TRY(hipGetLastError());
-  return RGCN_OK;
+  const rgcn_split_frag_view v = rgcn_split_fragment_images(packed, R, d_in, d_out);
+  fused_args a{};
+  a.x = x; a.rowptr = rowptr; a.col = col; a.hub_agg = hub_agg;
+  a.Fh = v.Fh_f; a.Fl = v.Fl_f; a.b_inv = v.inv_scale; a.x_amax = x_amax; a.a1_mul = 1.f;
+  a.bias = bias; a.out = out; a.agg = agg;
+  a.N = (int)N; a.R = (int)R; a.chunks = (int)R + (has_root ? 1 : 0);
+  a.tile_mask = tile_mask; a.amax_out = reinterpret_cast<unsigned*>(out_amax);
+  return launch_fused<false>(a, d_in, d_out, relu ? 1 : 0, (hipStream_t)stream_);
+}
+
+int rgcn_layer_bwd_input_fused(const int32_t* rowptr_t, const int32_t* col_t, const float* w_t,
+                               const uint32_t* tile_mask_t, int64_t N, int64_t R, const float* hub_agg, const float* g,
+                               const void* packed, int has_root, const float* relu_mask, int64_t d_in, int64_t d_out,
+                               const float* g_amax, float gagg_amax_mul, float* grad_x, float* grad_x_amax,
+                               void* stream_) {
+  if (N < 0 || !rowptr_t || !g || !packed || !g_amax || !grad_x || !(gagg_amax_mul > 0.f)) return RGCN_ERR_ARG;
+  if (!supported(R, d_out, d_in, true)) return RGCN_ERR_UNSUPPORTED;
+  if (N == 0) return RGCN_OK;
+  if (N > INT32_MAX / 2) return RGCN_ERR_UNSUPPORTED;
+  const rgcn_split_frag_view v = rgcn_split_fragment_images(packed, R, d_in, d_out);
+  fused_args a{};
+  a.x = g; a.rowptr = rowptr_t; a.col = col_t; a.wts = w_t; a.hub_agg = hub_agg;
+  a.Fh = v.Fh_b; a.Fl = v.Fl_b; a.b_inv = v.inv_scale; a.x_amax = g_amax; a.a1_mul = gagg_amax_mul;
+  a.mask = relu_mask; a.out = grad_x;
+  a.N = (int)N; a.R = (int)R; a.chunks = (int)R + (has_root ? 1 : 0);
+  a.tile_mask = tile_mask_t; a.amax_out = reinterpret_cast<unsigned*>(grad_x_amax);
+  return launch_fused<true>(a, d_out, d_in, relu_mask ? 2 : 0, (hipStream_t)stream_);
 }
 
 }  // extern "C"

@@ -30,12 +30,13 @@ __device__ __host__ inline float pow2f(int s) {
   return f;
 }
 
-// The forward-orientation images of a layer's split weights (rgcn_weights_split_pack) in MFMA B-fragment order
-// (element ((s * NT + nt) * 64 + lane) * 8 + j = image[n = 32 nt + (lane & 31)][k = 16 s + 8 (lane >> 5) + j],
-// K = (R + 1) * d_in) and the inverse of their common scale.  Defined in rgcn_transform_split.hip.
-struct rgcn_split_fwd_view {
-  const __half *Fh, *Fl;
+// The images of a layer's split weights (rgcn_weights_split_pack) in MFMA B-fragment order - element
+// ((s * NT + nt) * 64 + lane) * 8 + j = image[n = 32 nt + (lane & 31)][k = 16 s + 8 (lane >> 5) + j] - in the forward
+// orientation (n < d_out, k = r * d_in + i) and in the input-gradient orientation (n < d_in, k = r * d_out + o), and
+// the inverse of their common scale.  Defined in rgcn_transform_split.hip.
+struct rgcn_split_frag_view {
+  const __half *Fh_f, *Fl_f, *Fh_b, *Fl_b;
   const float* inv_scale;
 };
-rgcn_split_fwd_view rgcn_split_forward_images(const void* packed, int64_t R, int64_t d_in, int64_t d_out);
+rgcn_split_frag_view rgcn_split_fragment_images(const void* packed, int64_t R, int64_t d_in, int64_t d_out);
 size_t rgcn_split_packed_bytes(int64_t R, int64_t d_in, int64_t d_out);

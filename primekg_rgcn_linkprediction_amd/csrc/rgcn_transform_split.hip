@@ -105,7 +105,7 @@ struct pack_job {
   int R, d_in, d_out;
   const float *w_amax, *r_amax;                  // amax buffers of W and root (rgcn_absmax_multi), or NULL: scan here
   __half *Bh_f, *Bl_f, *Bh_b, *Bl_b;
-  __half *Fh_f, *Fl_f;                           // the forward image in MFMA B-fragment order (see k_pack_split)
+  __half *Fh_f, *Fl_f, *Fh_b, *Fl_b;             // the same two images in MFMA B-fragment order (see k_pack_split)
   float* scale_out;
 };
 struct pack_jobs {
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ)
   }
   // Fragment order (widths that are multiples of 32 / 16 only): element ((s * NT + nt) * 64 + lane) * 8 + j is
   // image[n = 32 nt + (lane & 31)][k = 16 s + 8 (lane >> 5) + j] - a wave's B operand of one
-  // v_mfma_f32_32x32x16_f16 is ONE coalesced 16-byte-per-lane read, no LDS staging (the fused no-grad layer
-  // keeps these fragments in registers).
+  // v_mfma_f32_32x32x16_f16 is ONE coalesced 16-byte-per-lane read, no LDS staging (the fused layer kernels
+  // keep these fragments in registers).
   if ((d_in % 32) || (d_out % 32)) return;
   __half* __restrict__ Fh_f = J.Fh_f;
   __half* __restrict__ Fl_f = J.Fl_f;
@@ -199,6 +199,16 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ)
       const __half h = __float2half_rn(v);
       Fh_f[e] = h;
       Fl_f[e] = __float2half_rn(v - __half2float(h));
+    }
+    {                                                           // backward image: n = i, k = r * d_out + o
+      const int NT = d_in / 32;
+      const int nt = (int)((e >> 9) % NT), st = (int)((e >> 9) / NT);
+      const int i = 32 * nt + (lane & 31), k = 16 * st + 8 * (lane >> 5) + j;
+      const int r = k / d_out, o = k - r * d_out;
+      const float v = (r < R ? W[((size_t)r * d_in + i) * d_out + o] : Rt[(size_t)i * d_out + o]) * sb;
+      const __half h = __float2half_rn(v);
+      J.Fh_b[e] = h;
+      J.Fl_b[e] = __float2half_rn(v - __half2float(h));
     }
   }
 }
@@ -717,15 +727,15 @@ size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // The split weights of one layer (rgcn_weights_split_pack):
 //   [ Bh_f ][ Bl_f ][ Bh_b ][ Bl_b ]  four fp16 images of (R+1)*d_in*d_out elements each (256-aligned), k contiguous
-//   [ Fh_f ][ Fl_f ]                  the forward pair in MFMA B-fragment order (the fused no-grad layer)
+//   [ Fh_f ][ Fl_f ][ Fh_b ][ Fl_b ]  the same four in MFMA B-fragment order (the fused layer kernels)
 //   [ inv_scale: 64 floats ][ partial maxima of W and root: 2 * kMaxSlots floats ]
 struct PackedWeights {
   __half *Bh_f, *Bl_f, *Bh_b, *Bl_b;
-  __half *Fh_f, *Fl_f;
+  __half *Fh_f, *Fl_f, *Fh_b, *Fl_b;
   float *inv_scale, *partials;
 };
 size_t packed_bytes(int64_t R, int64_t d_in, int64_t d_out) {
-  return 6 * align256((size_t)(R + 1) * d_in * d_out * sizeof(__half)) + 256 + 2 * kMaxSlots * sizeof(float);
+  return 8 * align256((size_t)(R + 1) * d_in * d_out * sizeof(__half)) + 256 + 2 * kMaxSlots * sizeof(float);
 }
 PackedWeights packed_view(void* base, int64_t R, int64_t d_in, int64_t d_out) {
   const size_t img = align256((size_t)(R + 1) * d_in * d_out * sizeof(__half));
@@ -737,7 +747,9 @@ PackedWeights packed_view(void* base, int64_t R, int64_t d_in, int64_t d_out) {
   v.Bl_b = (__half*)(p + 3 * img);
   v.Fh_f = (__half*)(p + 4 * img);
   v.Fl_f = (__half*)(p + 5 * img);
-  v.inv_scale = (float*)(p + 6 * img);
+  v.Fh_b = (__half*)(p + 6 * img);
+  v.Fl_b = (__half*)(p + 7 * img);
+  v.inv_scale = (float*)(p + 8 * img);
   v.partials = v.inv_scale + 64;
   return v;
 }
@@ -751,7 +763,7 @@ pack_job make_pack_job(const float* weight, const float* root, int64_t R, int64_
   j.w_amax = w_amax; j.r_amax = root ? r_amax : nullptr;
   if (root && !r_amax) j.w_amax = nullptr;                     // both maxima or none
   j.Bh_f = v.Bh_f; j.Bl_f = v.Bl_f; j.Bh_b = v.Bh_b; j.Bl_b = v.Bl_b;
-  j.Fh_f = v.Fh_f; j.Fl_f = v.Fl_f;
+  j.Fh_f = v.Fh_f; j.Fl_f = v.Fl_f; j.Fh_b = v.Fh_b; j.Fl_b = v.Fl_b;
   j.scale_out = v.inv_scale;
   return j;
 }
@@ -862,9 +874,9 @@ size_t tn_workspace_bytes(int64_t N, int64_t R, int64_t d_in, int64_t d_out) {
 
 }  // namespace
 
-rgcn_split_fwd_view rgcn_split_forward_images(const void* packed, int64_t R, int64_t d_in, int64_t d_out) {
+rgcn_split_frag_view rgcn_split_fragment_images(const void* packed, int64_t R, int64_t d_in, int64_t d_out) {
   const PackedWeights v = packed_view(const_cast<void*>(packed), R, d_in, d_out);
-  return rgcn_split_fwd_view{v.Fh_f, v.Fl_f, v.inv_scale};
+  return rgcn_split_frag_view{v.Fh_f, v.Fl_f, v.Fh_b, v.Fl_b, v.inv_scale};
 }
 size_t rgcn_split_packed_bytes(int64_t R, int64_t d_in, int64_t d_out) { return packed_bytes(R, d_in, d_out); }
 

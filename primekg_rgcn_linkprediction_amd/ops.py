@@ -246,13 +246,13 @@ def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
 # bucketed graph (row A2) + cache
 # ----------------------------------------------------------------------------------
 class FusedPlan:
-    """``BucketedGraph.fused_plan``: the CSR the one-kernel layer walks - ``rowptr`` int32[N * R + 1] / ``col`` int32 in
-    the forward structure's segment order, a segment longer than ``inline_limit`` edges replaced by ONE entry
-    ``-(row + 1)`` naming its row of the pre-aggregated table - and ``hub``, the gather structure of those long
-    segments (None if there is none)."""
+    """``BucketedGraph.fused_plan``: the CSR the one-kernel layer walks - ``rowptr`` int32[N * R + 1] / ``col`` int32
+    (/ ``weight`` float32 for the transposed structure) in the structure's segment order, a segment longer than
+    ``inline_limit`` edges replaced by ONE entry ``-(row + 1)`` (weight 1) naming its row of the pre-aggregated
+    table - and ``hub``, the gather structure of those long segments (None if there is none)."""
 
-    def __init__(self, inline_limit: int, rowptr, col, hub, hub_rows: int, hub_edges: int):
-        self.inline_limit, self.rowptr, self.col, self.hub = inline_limit, rowptr, col, hub
+    def __init__(self, inline_limit: int, rowptr, col, weight, hub, hub_rows: int, hub_edges: int):
+        self.inline_limit, self.rowptr, self.col, self.weight, self.hub = inline_limit, rowptr, col, weight, hub
         self.hub_rows, self.hub_edges = hub_rows, hub_edges
 
 
@@ -456,43 +456,51 @@ class BucketedGraph:
             cache[block_rows] = blocks
         return cache[block_rows]
 
-    def fused_plan(self, inline_limit: int = 16) -> "FusedPlan":
-        """What the one-kernel layer forward (``layer_fwd_fused``) needs beside this structure: which
-        (node, relation) segments it walks itself (at most ``inline_limit`` <= 64 edges) and, for the longer
+    def fused_plan(self, inline_limit: int = 16, transposed: bool = False) -> "FusedPlan":
+        """What the one-kernel layer (``layer_fwd_fused`` / ``layer_bwd_input_fused``) needs beside this structure:
+        which (node, relation) segments it walks itself (at most ``inline_limit`` <= 64 edges) and, for the longer
         ones, a gather structure of their own (one segment per long segment, one relation, key = row of the
-        pre-aggregated ``hub`` table) - built once per limit from the bucketed arrays; a long segment keeps its
-        edge order, run / pack cuts and hub reduce, so its mean has the bits the whole-graph aggregate gives it."""
+        pre-aggregated ``hub`` table; weighted for the transposed direction) - built once per limit and direction
+        from the bucketed arrays; a long segment keeps its edge order, run / pack cuts and hub reduce, so its
+        aggregate has the bits the whole-graph gather gives it."""
         if self.weighted_shard:
-            raise ValueError("the fused layer covers mean structures only")
+            raise ValueError("the fused layer covers whole graphs and mean shards only")
+        if transposed and self.bipartite:
+            raise ValueError("a shard structure has one direction only (transposed=False)")
         limit = int(inline_limit)
         if not 1 <= limit <= 64:
             raise ValueError("inline_limit must be in [1, 64] (a longer walk is cut into runs by the gather)")
         cache = self.__dict__.setdefault("_fused_plans", {})
-        if limit not in cache:
-            rowptr, col, _, _ = self.arrays(False)
+        key = (limit, bool(transposed))
+        if key not in cache:
+            rowptr, col, _, val = self.arrays(transposed)
+            weight = val if transposed else None
             rp = rowptr.long()
             lens = rp[1:] - rp[:-1]
             long_seg = lens > limit
             hubs = int(long_seg.sum())
             if hubs == 0:
-                cache[limit] = FusedPlan(limit, rowptr, col, None, 0, 0)
+                cache[key] = FusedPlan(limit, rowptr, col, weight, None, 0, 0)
             else:
                 hub_row = torch.cumsum(long_seg.long(), 0) - 1                  # of a long segment
                 seg_of_edge = torch.repeat_interleave(torch.arange(lens.numel(), device=self.device), lens)
                 in_hub = long_seg[seg_of_edge]
                 hub = BucketedGraph.from_shard(hub_row[seg_of_edge[in_hub]], col[in_hub].long(),
                                                torch.zeros(int(in_hub.sum()), dtype=torch.int64, device=self.device),
-                                               hubs, self.num_other_nodes, 1)
+                                               hubs, self.num_other_nodes, 1,
+                                               edge_weight=weight[in_hub].contiguous() if transposed else None)
                 # the walked CSR: short segments as they are, a long one as the single entry -(hub row + 1)
                 first = torch.zeros_like(in_hub)
                 first[rp[:-1][long_seg]] = True
                 keep = ~in_hub | first
                 new_col = torch.where(in_hub, -(hub_row[seg_of_edge] + 1), col.long())[keep].int()
+                new_w = torch.where(in_hub, torch.ones_like(weight), weight)[keep].contiguous() if transposed else None
                 new_lens = torch.where(long_seg, torch.ones_like(lens), lens)
                 new_rowptr = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=self.device)
                 new_rowptr[1:] = torch.cumsum(new_lens, 0)
-                cache[limit] = FusedPlan(limit, new_rowptr.int(), new_col.contiguous(), hub, hubs, int(in_hub.sum()))
-        return cache[limit]
+                cache[key] = FusedPlan(limit, new_rowptr.int(), new_col.contiguous(), new_w, hub, hubs,
+                                       int(in_hub.sum()))
+        return cache[key]
 
     def merged_transposed(self) -> Optional["BucketedGraph"]:
         """The out-edges of every node across ALL relations as one weighted gather structure over
@@ -730,6 +738,11 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
     return out
 
 
+def fused_bwd_supported(num_relations: int, d_in: int, d_out: int) -> bool:
+    """does the one-kernel input gradient cover this layer shape (in split precision)?"""
+    return GEMM_PRECISION != "fp32" and bool(_lib.load().rgcn_layer_bwd_input_fused_supported(num_relations, d_in, d_out))
+
+
 FUSED_EVENTS = None      # bench / probes: list that receives (rows, edges, d_in, d_out, begin, end) per fused launch
 
 
@@ -783,6 +796,51 @@ def layer_fwd_fused(graph: BucketedGraph, x: torch.Tensor, packed: SplitWeights,
             FUSED_EVENTS.append((graph.num_nodes, graph.num_edges - plan.hub_edges, d_in, d_out, beg, end))
     _lib.check(rc, "rgcn_layer_fwd_fused")
     return out
+
+
+def layer_bwd_input_fused(graph: BucketedGraph, g: torch.Tensor, packed: SplitWeights,
+                          relu_mask: Optional[torch.Tensor], amax: torch.Tensor,
+                          amax_out: Optional[torch.Tensor] = None, inline_limit: int = 16,
+                          tail: Optional["PendingParamGrads"] = None) -> torch.Tensor:
+    """``grad_x = [transposed-aggregate(g) | g] @ [W_r^T ; root^T]`` (``* (relu_mask > 0)``) in ONE kernel
+    (``rgcn_layer_bwd_input_fused``): the weighted sums over out-edges are formed in LDS, no ``[N, R * d_out]``
+    tensor in HBM.  Bit-identical to ``aggregate(transposed=True)`` -> ``transform_bwd_input(precision="split")``.
+    ``amax``: amax buffer of ``g``; ``tail``: a pending parameter-gradient reduction that rides in the gather of
+    the long segments (or is launched by itself if there is none)."""
+    _need_gpu("g", g, torch.float32)
+    if graph.bipartite:
+        raise ValueError("the fused input gradient needs the transposed structure of a whole graph")
+    r, d_in, d_out = packed.shape
+    if g.dim() != 2 or tuple(g.shape) != (graph.num_nodes, d_out) or g.device != graph.device or r != graph.num_relations:
+        raise ValueError(f"g must be [{graph.num_nodes}, {d_out}] on the graph's device with {r} relations")
+    if relu_mask is not None:
+        _need_gpu("relu_mask", relu_mask, torch.float32)
+        if tuple(relu_mask.shape) != (graph.num_nodes, d_in) or not relu_mask.is_contiguous():
+            raise ValueError(f"relu_mask must be a contiguous [{graph.num_nodes}, {d_in}]")
+    _check_amax("amax", amax, g.device)
+    if amax is None:
+        raise ValueError("amax (the amax buffer of g) is required")
+    _check_amax("amax_out", amax_out, g.device)
+    plan = graph.fused_plan(min(int(inline_limit), d_out // 4), transposed=True)
+    hub_agg = aggregate(plan.hub, g, tail=tail) if plan.hub is not None else None   # a pending slab reduction rides along
+    if tail is not None and not tail.done:
+        tail.finish()
+    tile_mask = graph.tile_mask_ptr(True) if graph.num_relations <= 32 else None
+    lib = _lib.load()
+    with _on(g.device):
+        gx = torch.empty(graph.num_nodes, d_in, dtype=torch.float32, device=g.device)
+        if FUSED_EVENTS is not None:
+            beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            beg.record()
+        rc = lib.rgcn_layer_bwd_input_fused(_ptr(plan.rowptr), _ptr(plan.col), _ptr(plan.weight), tile_mask,
+                                            graph.num_nodes, r, _ptr(hub_agg), _ptr(g), _ptr(packed.buf),
+                                            int(packed.has_root), _ptr(relu_mask), d_in, d_out, _ptr(amax),
+                                            float(graph.weight_bound(True)), _ptr(gx), _ptr(amax_out), _stream())
+        if FUSED_EVENTS is not None:
+            end.record()
+            FUSED_EVENTS.append((graph.num_nodes, graph.num_edges - plan.hub_edges, d_out, d_in, beg, end))
+    _lib.check(rc, "rgcn_layer_bwd_input_fused")
+    return gx
 
 
 # ----------------------------------------------------------------------------------

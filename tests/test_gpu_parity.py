@@ -1363,8 +1363,9 @@ def test_transforms_return_the_same_bits_every_run(d_in, d_out, precision):
 def test_training_forward_through_the_fused_layer_changes_no_bit(monkeypatch):
     """RGCN_TRAIN_FUSED=1 (the default once the aggregate outgrows the Infinity Cache): the training forward runs
     each layer as the one-kernel layer in STORE mode - the aggregate it formed in LDS is written once, for the
-    parameter gradients, and not read back.  Output, every gradient and the kept aggregate equal the two-launch
-    path's bit for bit (two-layer node with dropout 0, and the single-layer node)."""
+    parameter gradients, and not read back - and each input gradient as the one-kernel transposed layer (weighted
+    sums over out-edges formed in LDS).  Output and every gradient equal the two-launch path's bit for bit
+    (two-layer node with dropout 0, and the single-layer node)."""
     from primekg_rgcn_linkprediction_amd import conv as C
     dev = need_gpu()
     ei, et, n, r = synth.primekg_like(num_edges=250000, seed=21)
@@ -1386,7 +1387,55 @@ def test_training_forward_through_the_fused_layer_changes_no_bit(monkeypatch):
         out = rgcn_encoder2(e, eid, etd, convs[0], convs[1])
         (out * cot).sum().backward()
         single = convs[0](e.detach(), eid, etd, activation="relu")
-        assert len(events) == (3 if mode == "1" else 0)        # the path was taken (two layers + the single layer)
+        assert len(events) == (5 if mode == "1" else 0)        # taken: 2 forward + 2 input-gradient layers, the single layer
         results[mode] = [out.detach(), e.grad.clone(), single.detach()] + [p.grad.clone() for c in convs for p in c.parameters()]
     for a, b in zip(results["0"], results["1"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,e,r,d_in,d_out,limit,masked", [
+    (1000, 20000, 3, 64, 128, 16, False), (30926, 849456, 3, 128, 128, 16, True), (2049, 60000, 16, 64, 64, 8, False),
+    (777, 30000, 5, 256, 256, 64, True), (500, 9000, 3, 128, 64, 1, True), (4097, 90000, 20, 128, 128, 16, False),
+    (33, 40, 3, 64, 128, 16, True), (5000, 300000, 3, 256, 128, 24, False)])
+def test_fused_input_gradient_is_bit_identical_to_gather_then_transform(n, e, r, d_in, d_out, limit, masked):
+    """rgcn_layer_bwd_input_fused (the 1/cnt-weighted sums over out-edges formed in LDS as the transform's A operand,
+    scaled by the structure's weight bound, handed over to the gradient's own scale before the root chunk) against
+    rgcn_aggregate(transposed) -> rgcn_transform_bwd_input_split: every bit equal - hub-heavy graphs (long segments
+    pre-aggregated by a weighted structure), 64-wide outputs (two of the four waves multiply), ReLU mask, no root."""
+    dev = need_gpu()
+    if (n, e) == (30926, 849456):
+        ei, et, n, r = synth.primekg_like(seed=42)
+    else:
+        gen = torch.Generator().manual_seed(n + e)
+        src = (torch.rand(e, generator=gen) ** 3 * n).long().clamp_(max=n - 1)       # skewed: a few hub SOURCES
+        dst = torch.randint(0, n, (e,), generator=gen)
+        et = torch.randint(0, r, (e,), generator=gen)
+        et[src < n // 3] = 0
+        ei = torch.stack([src, dst])
+    graph = ops.bucket(ei.to(dev), et.to(dev), n, r)
+    assert ops.fused_bwd_supported(r, d_in, d_out)
+    torch.manual_seed(e)
+    g = torch.randn(n, d_out, device=dev) * 1e-3
+    weight = torch.randn(r, d_in, d_out, device=dev) / d_in ** 0.5
+    root = torch.randn(d_in, d_out, device=dev) / d_in ** 0.5
+    mask = torch.randn(n, d_in, device=dev) if masked else None
+    plan = graph.fused_plan(min(limit, d_out // 4), transposed=True)
+    lens = graph.arrays(True)[0].long().diff()
+    cut = min(limit, d_out // 4)
+    assert plan.hub_rows == int((lens > cut).sum()) and plan.hub_edges == int(lens[lens > cut].sum())
+    gagg = ops.aggregate(graph, g, transposed=True)
+    for rt in (root, None):
+        g_amax = ops.absmax(g)
+        packed = ops.split_weights(weight, rt)
+        want_amax, got_amax = ops.amax_buffer(dev), ops.amax_buffer(dev)
+        want = ops.transform_bwd_input(gagg, g, weight, rt, relu_mask=mask, graph=graph, amax=(g_amax, g_amax),
+                                       amax_mul=graph.weight_bound(True), amax_out=want_amax, packed=packed,
+                                       precision="split")
+        got = ops.layer_bwd_input_fused(graph, g, packed, mask, g_amax, got_amax, inline_limit=limit)
+        assert torch.equal(got, want), rt is None
+        assert float(ops.amax_value(got_amax)) == float(ops.amax_value(want_amax)) == float(want.abs().max())
+    ref = gagg.double() @ weight.double().permute(0, 2, 1).reshape(r * d_out, d_in)
+    if masked:
+        ref = ref * (mask > 0)
+    assert float((got.double() - ref).abs().max()) <= GRAD_RTOL * float(ref.abs().max())
