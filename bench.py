@@ -305,7 +305,7 @@ def main():
     # step (events cannot be read back from inside a captured graph).  (At N > 1 every rank runs
     # the pass - the exchanges are collective - and rank 0 reports its own shard.)
     event_steps = min(args.steps, 20)
-    ops.GATHER_EVENTS, ops.GEMM_EVENTS = [], []
+    ops.GATHER_EVENTS, ops.GEMM_EVENTS, ops.FUSED_EVENTS = [], [], []
     for _ in range(event_steps):
         # a short device-side spin first, so that the host has queued the step's launches
         # before they execute: the events then bracket back-to-back kernels, not launch gaps
@@ -315,6 +315,7 @@ def main():
     sync()
     events, ops.GATHER_EVENTS = ops.GATHER_EVENTS, None
     gemm_events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
+    fused_events, ops.FUSED_EVENTS = ops.FUSED_EVENTS, None
     # what an empty bracket costs on this stream (two event records, nothing between): reported, not
     # subtracted - the profiler's kernel-only durations in profiles/ are shorter by about this much
     if world == 1:
@@ -354,7 +355,30 @@ def main():
     if world > 1:
         result["exchange_rank0"] = summ          # rows received per exchange as a fraction of the rows rank 0 does not own
 
-    if events:
+    fused_kernels = []
+    if fused_events:
+        # the one-kernel layers (gather into LDS + transform): algorithmic bytes = what the gather and the rows in /
+        # out cost - there is no aggregate write + read; "+store": the kept aggregate's one write
+        per, shape = {}, {}
+        for kind, rows, rels, edges, hub_rows, dk, dn, beg, end in fused_events:
+            per.setdefault((kind, dk, dn), []).append(beg.elapsed_time(end) * 1e-3)
+            shape[(kind, dk, dn)] = (rows, rels, edges, hub_rows)
+        for (kind, dk, dn), ts in sorted(per.items()):
+            rows, rels, edges, hub_rows = shape[(kind, dk, dn)]
+            avg = sum(ts) / len(ts)
+            weighted = kind.startswith("bwd")
+            ids = edges * (8 if weighted else 4) + 4 * (rows * rels + 1)
+            dense = 4 * rows * (dk + dn) + (4 * rows * dn if kind.endswith("mask") else 0) \
+                + (4 * rows * rels * dk if kind.endswith("store") else 0)
+            nbytes = edges * 4 * dk + hub_rows * 4 * dk + ids + dense
+            comp = 4 * rows * dk + ids + dense                  # the table once instead of once per edge
+            fused_kernels.append({"kernel": f"k_layer_fused<{kind}, {dk}->{dn}>", "d": dk, "transposed": weighted,
+                                  "launches_per_step": len(ts) // event_steps, "avg_us": avg * 1e6, "bytes": nbytes,
+                                  "gbs": nbytes / avg / 1e9, "compulsory_hbm_bytes": comp, "table_bytes": 4 * rows * dk,
+                                  "total_us_per_step": sum(ts) / event_steps * 1e6,
+                                  "flops": 2.0 * rows * (rels + 1) * dk * dn})
+
+    if events or fused_kernels:
         # per instantiation of the gather kernel: average duration from the live HIP events
         per, shape = {}, {}
         for transposed, d, edges, segments, beg, end in events:
@@ -371,6 +395,7 @@ def main():
                             "avg_us": avg * 1e6, "bytes": nbytes, "gbs": nbytes / avg / 1e9,
                             "compulsory_hbm_bytes": comp, "table_bytes": 4 * (segments // r) * d,
                             "total_us_per_step": sum(ts) / event_steps * 1e6})
+        kernels += fused_kernels
         dom = max(kernels, key=lambda k: k["total_us_per_step"])
         traffic, traffic_source = pmc_traffic(dom["kernel"]) if (world == 1 and headline) else (None, "not applicable")
         cache_resident = dom["table_bytes"] <= 200e6          # fits the 256 MiB Infinity Cache beside the streams

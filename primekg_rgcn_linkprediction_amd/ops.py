@@ -743,7 +743,8 @@ def fused_bwd_supported(num_relations: int, d_in: int, d_out: int) -> bool:
     return GEMM_PRECISION != "fp32" and bool(_lib.load().rgcn_layer_bwd_input_fused_supported(num_relations, d_in, d_out))
 
 
-FUSED_EVENTS = None      # bench / probes: list that receives (rows, edges, d_in, d_out, begin, end) per fused launch
+FUSED_EVENTS = None      # bench / probes: list that receives (kind, rows, relations, inline edges, pre-aggregated rows,
+                         # gathered width, output width, begin, end) per fused launch
 
 
 def layer_fwd_fused(graph: BucketedGraph, x: torch.Tensor, packed: SplitWeights, bias: Optional[torch.Tensor],
@@ -793,7 +794,8 @@ def layer_fwd_fused(graph: BucketedGraph, x: torch.Tensor, packed: SplitWeights,
                                       _stream())
         if FUSED_EVENTS is not None:
             end.record()
-            FUSED_EVENTS.append((graph.num_nodes, graph.num_edges - plan.hub_edges, d_in, d_out, beg, end))
+            FUSED_EVENTS.append(("fwd+store" if agg_out is not None else "fwd", graph.num_nodes, graph.num_relations,
+                                 graph.num_edges - plan.hub_edges, plan.hub_rows, d_in, d_out, beg, end))
     _lib.check(rc, "rgcn_layer_fwd_fused")
     return out
 
@@ -838,7 +840,8 @@ def layer_bwd_input_fused(graph: BucketedGraph, g: torch.Tensor, packed: SplitWe
                                             float(graph.weight_bound(True)), _ptr(gx), _ptr(amax_out), _stream())
         if FUSED_EVENTS is not None:
             end.record()
-            FUSED_EVENTS.append((graph.num_nodes, graph.num_edges - plan.hub_edges, d_out, d_in, beg, end))
+            FUSED_EVENTS.append(("bwd_input+mask" if relu_mask is not None else "bwd_input", graph.num_nodes,
+                                 graph.num_relations, graph.num_edges - plan.hub_edges, plan.hub_rows, d_out, d_in, beg, end))
     _lib.check(rc, "rgcn_layer_bwd_input_fused")
     return gx
 

@@ -44,7 +44,7 @@ def run(tag):
             rgcn_encoder2(emb, eid, etd, convs[0], convs[1])
             torch.cuda.synchronize()
             line += "; fused launches " + ", ".join(f"{d_in}->{d_out}: {b.elapsed_time(e) * 1e3:.1f} us"
-                                                    for _, _, d_in, d_out, b, e in ops.FUSED_EVENTS)
+                                                    for _, _, _, _, _, d_in, d_out, b, e in ops.FUSED_EVENTS)
             ops.FUSED_EVENTS = None
     print(line, flush=True)
     return out

@@ -17,6 +17,7 @@ RGCN_GEMM_PRECISION=fp32 stats c2_fp32
 stats c2_fp16 --fp16-gather
 stats c3 --workload c3
 stats c4_1gpu --workload c4-1gpu --steps 10 --warmup 3
+RGCN_TRAIN_FUSED=0 stats c4_1gpu_unfused --workload c4-1gpu --steps 10 --warmup 3
 stats c2_e1677772 --edges 1677772
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TA_TA_BUSY_sum" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"; do
@@ -32,7 +33,7 @@ print("C2", r["ms_per_step"], r["value"], r["config"]["launch"])
 print("roofline", {k: r["roofline"][k] for k in ("kernel", "avg_us", "achieved", "frac", "frac_compulsory", "frac_of_l2_ceiling")})
 print("mfma", {k: r["roofline_mfma"][k] for k in ("call", "arithmetic", "avg_us", "achieved", "frac", "executed_tflops", "sum_transform_us_per_step")})
 print("cpu", r["cpu_baseline"]["value"], r["cpu_baseline"]["cores"], r["gpu_over_cpu"])
-for n in ("c2_fp32", "c2_fp16", "c3", "c4_1gpu", "c2_e1677772"):
+for n in ("c2_fp32", "c2_fp16", "c3", "c4_1gpu", "c4_1gpu_unfused", "c2_e1677772"):
     q = json.load(open(f"$out/${tag}_{n}_prof_bench.json"))
     print(n, q["ms_per_step"], q["value"], q.get("roofline", {}).get("frac"), q.get("roofline", {}).get("kernel"))
 PY
