@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 12
+#define RGCN_ABI_VERSION 13
 
 enum {
   RGCN_OK = 0,
@@ -284,6 +284,13 @@ int rgcn_weights_split_pack_multi(int count, const float* const* weights, const 
                                   const int64_t* num_relations, const int64_t* d_in, const int64_t* d_out,
                                   const float* const* w_amax, const float* const* r_amax, void* const* packed,
                                   const size_t* packed_bytes, void* stream);
+/* The first launch of a forward pass, as ONE launch: max |x| of the pass's input table into x_amax (zero_buffers /
+ * zero_count as in rgcn_absmax) AND the split weights of up to 4 layers (as rgcn_weights_split_pack_multi without
+ * given maxima: the kernel scans the weights itself).  Array arguments: HOST arrays of `count` entries. */
+int rgcn_absmax_pack(const float* x, int64_t numel, float* x_amax, float* zero_buffers, int zero_count, int count,
+                     const float* const* weights, const float* const* roots, const int64_t* num_relations,
+                     const int64_t* d_in, const int64_t* d_out, void* const* packed, const size_t* packed_bytes,
+                     void* stream);
 size_t rgcn_transform_split_workspace_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
 int rgcn_transform_fwd_split(const float* agg, const float* x, const float* weight, const float* root,
                              const void* packed, const float* bias, int relu, const uint32_t* tile_mask,

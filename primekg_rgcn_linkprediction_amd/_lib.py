@@ -13,7 +13,7 @@ from ctypes import c_float, POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -69,6 +69,7 @@ PROTOTYPES = {
     "rgcn_aggregate_amax": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, POINTER(SlabJob), _P, _P]),
     "rgcn_absmax": (c_int, [_P, _I64, _P, _P, c_int, _P]),
     "rgcn_absmax_multi": (c_int, [c_int, _P, _P, _P, _P, c_int, _P]),
+    "rgcn_absmax_pack": (c_int, [_P, _I64, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rgcn_weights_split_pack_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "rgcn_weights_split_bytes": (c_size_t, [_I64, _I64, _I64]),
     "rgcn_weights_split_pack": (c_int, [_P, _P, _I64, _I64, _I64, _P, c_size_t, _P]),

@@ -65,21 +65,21 @@ class _Scales:
     device allocation of amax buffers (``ops.amax_buffer`` layout).  Buffer 0 receives ``max |t|`` of the
     pass's external tensor ``t`` (the embedding table / the incoming gradient) and the SAME launch clears
     the others, which the pass's kernels then publish their results' maxima into, handed out slot by
-    slot.  In fp32 mode nothing is allocated and every slot is None."""
+    slot - and, in a forward pass, splits the layers' weights.  In fp32 mode nothing is allocated and every
+    slot is None."""
 
-    def __init__(self, t: Tensor, slots: int = 2, weights=()):
-        """``weights``: further tensors (a layer's ``weight`` / ``root``) whose maxima the same first launch
-        takes - ``self.extra[i]`` (None for a None tensor) - so that splitting them needs no scan of its own"""
+    def __init__(self, t: Tensor, slots: int = 2, layers=()):
+        """``layers``: ``[(weight, root | None), ...]`` of the pass (forward passes): their split images are made
+        by the SAME first launch - ``self.packed[i]`` (None for widths the split kernels do not tile)"""
         self._buf, self._next, self.first = None, 1, None
-        self.extra = [None] * len(weights)
+        self.packed = [None] * len(layers)
         if ops.GEMM_PRECISION == "split":
-            present = [i for i, w in enumerate(weights) if w is not None]
-            self._buf = torch.empty(slots + len(present), ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
+            self._buf = torch.empty(slots, ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
             self.first = self._buf[0]
-            for j, i in enumerate(present):
-                self.extra[i] = self._buf[slots + j]
-            ops.absmax_many([t] + [weights[i] for i in present], [self.first] + [self.extra[i] for i in present],
-                            clear=self._buf[1:slots])
+            if layers:
+                self.packed = ops.absmax_and_split(t, self.first, self._buf[1:slots], list(layers))
+            else:
+                ops.absmax(t, self.first, self._buf[1:slots])
 
     def slot(self) -> Optional[Tensor]:
         if self._buf is None:
@@ -171,9 +171,9 @@ class _RGCNConvFunction(torch.autograd.Function):
         ctx.gather_dtype = gather_dtype
         half = gather_dtype == torch.float16
         ctx.bwd_precision = "half" if (half and half_backward and ops.GEMM_PRECISION == "split") else None
-        scales = _Scales(x, slots=1)
+        scales = _Scales(x, slots=1, layers=[(weight, root_c)])          # ONE launch: max |x| and the split weights
         x_amax = scales.first            # also the bound of agg: a mean of rows cannot exceed the table's maximum
-        packed = ops.split_weights(weight, root_c)                                    # once, for forward and backward
+        packed = scales.packed[0]                                                     # once, for forward and backward
         agg, out = _layer_train_forward(graph, x, gather_dtype, weight, root_c, bias_c, relu, half, x_amax, None,
                                         packed)                                        # rows A3 + A4, A6 (+ fused ReLU)
         ctx.graph, ctx.relu, ctx.packed = graph, relu, packed
@@ -222,6 +222,8 @@ class _Encoder2Function(torch.autograd.Function):
     def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph, gather_dtype=None, p: float = 0.0,
                 half_backward: bool = False):
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
+        root1 = root1.contiguous() if root1 is not None else None
+        root2 = root2.contiguous() if root2 is not None else None
         ctx.gather_dtype = gather_dtype
         half = gather_dtype == torch.float16          # configs[4]: fp16 operands on the fp16 matrix cores too
         # configs[4] backward: the three gradient GEMMs per layer in ONE fp16 pass (operands rounded under their
@@ -232,10 +234,9 @@ class _Encoder2Function(torch.autograd.Function):
         # A dense tensor's maximum is left behind by the launch that produces it (the first launch of the pass
         # for x, the epilogue of conv1's transform for h); an aggregate is scaled by the bound its table's
         # maximum gives (a mean of rows cannot exceed it), so the gathers publish nothing.
-        scales = _Scales(x, weights=(w1, root1, w2, root2))          # ONE launch: max |x|, the weights' maxima, cleared slots
+        scales = _Scales(x, layers=[(w1, root1), (w2, root2)])       # ONE launch: max |x|, cleared slots, both layers' split weights
         x_amax, h_amax = scales.first, scales.slot()
-        wmax = None if scales.first is None else [(scales.extra[0], scales.extra[1]), (scales.extra[2], scales.extra[3])]
-        pk1, pk2 = ops.split_weights_many([(w1, root1), (w2, root2)], amax=wmax)   # once, for forward and backward
+        pk1, pk2 = scales.packed                                      # once, for forward and backward
         agg1, h = _layer_train_forward(graph, x, gather_dtype, w1, root1, b1, True, half, x_amax, h_amax, pk1)
         if p > 0:
             h = torch.native_dropout(h, p, True)[0]
@@ -329,11 +330,12 @@ def _layer_eval_blocked(graph: "ops.BucketedGraph", x: Tensor, table: Tensor, we
 def encoder2_eval(x: Tensor, graph: "ops.BucketedGraph", w1, root1, b1, w2, root2, b2, gather_dtype=None) -> Tensor:
     """conv2(relu(conv1(x))) with nothing kept for a backward and no whole-graph aggregate (see above)"""
     x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
+    root1 = root1.contiguous() if root1 is not None else None
+    root2 = root2.contiguous() if root2 is not None else None
     half = gather_dtype == torch.float16
-    scales = _Scales(x, weights=(w1, root1, w2, root2))
+    scales = _Scales(x, layers=[(w1, root1), (w2, root2)])
     x_amax, h_amax = scales.first, scales.slot()
-    wmax = None if scales.first is None else [(scales.extra[0], scales.extra[1]), (scales.extra[2], scales.extra[3])]
-    pk1, pk2 = ops.split_weights_many([(w1, root1), (w2, root2)], amax=wmax)
+    pk1, pk2 = scales.packed
     h = _layer_eval_blocked(graph, x, _table(x, gather_dtype), w1, root1, b1, True, half, (x_amax, x_amax), h_amax, pk1)
     return _layer_eval_blocked(graph, h, _table(h, gather_dtype), w2, root2, b2, False, half, (h_amax, h_amax), None, pk2)
 

@@ -112,9 +112,7 @@ struct pack_jobs {
   pack_job j[kPackJobs];
 };
 
-__global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ) {
-  __shared__ float red[kPackThreads / 64];
-  const pack_job& J = JJ.j[blockIdx.y];          // one layer per grid row
+__device__ inline void pack_body(const pack_job& J, float* red, int nblocks) {   // nblocks workgroups share the job
   const float* __restrict__ W = J.W;
   const float* __restrict__ Rt = J.Rt;
   const int R = J.R, d_in = J.d_in, d_out = J.d_out;
@@ -161,7 +159,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ)
   const int64_t total = (int64_t)blocks * d_in * d_out;
   // two passes so that the STORES of each image are contiguous (2-byte stores a whole row apart cost this
   // launch twice its time); the strided side is a 4-byte read of L2-resident weights
-  for (int64_t e = (int64_t)blockIdx.x * kPackThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kPackThreads) {
+  for (int64_t e = (int64_t)blockIdx.x * kPackThreads + threadIdx.x; e < total; e += (int64_t)nblocks * kPackThreads) {
     const int o = (int)(e % d_out);                       // o fastest: the backward image's k
     const int i = (int)((e / d_out) % d_in);
     const int r = (int)(e / ((int64_t)d_out * d_in));
@@ -171,7 +169,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ)
     Bh_b[bk] = h;
     Bl_b[bk] = __float2half_rn(v - __half2float(h));
   }
-  for (int64_t e = (int64_t)blockIdx.x * kPackThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kPackThreads) {
+  for (int64_t e = (int64_t)blockIdx.x * kPackThreads + threadIdx.x; e < total; e += (int64_t)nblocks * kPackThreads) {
     const int i = (int)(e % d_in);                        // i fastest: the forward image's k
     const int r = (int)((e / d_in) % blocks);
     const int o = (int)(e / ((int64_t)d_in * blocks));
@@ -188,7 +186,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ)
   if ((d_in % 32) || (d_out % 32)) return;
   __half* __restrict__ Fh_f = J.Fh_f;
   __half* __restrict__ Fl_f = J.Fl_f;
-  for (int64_t e = (int64_t)blockIdx.x * kPackThreads + threadIdx.x; e < total; e += (int64_t)gridDim.x * kPackThreads) {
+  for (int64_t e = (int64_t)blockIdx.x * kPackThreads + threadIdx.x; e < total; e += (int64_t)nblocks * kPackThreads) {
     const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
     {                                                           // forward image: n = o, k = r * d_in + i
       const int NT = d_out / 32;
@@ -211,6 +209,11 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ)
       J.Fl_b[e] = __float2half_rn(v - __half2float(h));
     }
   }
+}
+
+__global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ) {
+  __shared__ float red[kPackThreads / 64];
+  pack_body(JJ.j[blockIdx.y], red, (int)gridDim.x);   // one layer per grid row
 }
 
 // ---------------------------------------------------------------------------------------
@@ -482,16 +485,15 @@ struct absmax_multi_job {
   int count;
 };
 
-__global__ __launch_bounds__(kThreads) void k_absmax_multi(const absmax_multi_job J, float* __restrict__ zero,
-                                                           int zero_count) {
-  __shared__ float red[kThreads / 64];
+template <int THREADS>
+__device__ inline void absmax_body(const absmax_multi_job& J, float* __restrict__ zero, int zero_count, float* red) {
   for (int t = 0; t < J.count; ++t) {
     const float* __restrict__ p = J.p[t];
     const int64_t n = J.n[t], n4 = n >> 2;
     const float4* p4 = reinterpret_cast<const float4*>(p);
     float m = 0.f;
-    const int64_t stride = (int64_t)gridDim.x * kThreads;
-    for (int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+    const int64_t stride = (int64_t)gridDim.x * THREADS;
+    for (int64_t i0 = (int64_t)blockIdx.x * THREADS + threadIdx.x; i0 < n4; i0 += 4 * stride) {
       float4 v[4];                               // four independent loads per thread and round
 #pragma unroll
       for (int u = 0; u < 4; ++u) v[u] = (i0 + u * stride < n4) ? p4[i0 + u * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -504,10 +506,31 @@ __global__ __launch_bounds__(kThreads) void k_absmax_multi(const absmax_multi_jo
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) J.out[t][blockIdx.x * RGCN_AMAX_HEAD_STRIDE] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) {
+      float mm = red[0];
+#pragma unroll
+      for (int w = 1; w < THREADS / 64; ++w) mm = fmaxf(mm, red[w]);
+      J.out[t][blockIdx.x * RGCN_AMAX_HEAD_STRIDE] = mm;
+    }
     __syncthreads();
   }
   if ((int)threadIdx.x < zero_count) zero[(size_t)threadIdx.x * RGCN_AMAX_FLOATS + blockIdx.x * RGCN_AMAX_HEAD_STRIDE] = 0.f;
+}
+
+__global__ __launch_bounds__(kThreads) void k_absmax_multi(const absmax_multi_job J, float* __restrict__ zero,
+                                                           int zero_count) {
+  __shared__ float red[kThreads / 64];
+  absmax_body<kThreads>(J, zero, zero_count, red);
+}
+
+// The first launch of a forward pass: grid row 0 takes max |x| of the pass's input table (and clears the amax buffers
+// the pass's kernels publish into), rows 1.. split one layer's weights each (scanning them for their maximum
+// themselves: they are L2 resident) - one launch instead of k_absmax_multi + k_pack_split.
+__global__ __launch_bounds__(kPackThreads) void k_absmax_pack(const absmax_multi_job J, float* __restrict__ zero,
+                                                              int zero_count, const pack_jobs JJ, int pack_blocks) {
+  __shared__ float red[kPackThreads / 64];
+  if (blockIdx.y == 0) absmax_body<kPackThreads>(J, zero, zero_count, red);
+  else if ((int)blockIdx.x < pack_blocks) pack_body(JJ.j[blockIdx.y - 1], red, pack_blocks);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -894,6 +917,33 @@ int rgcn_absmax_multi(int count, const float* const* tensors, const int64_t* num
     J.p[t] = tensors[t]; J.n[t] = numels[t]; J.out[t] = outs[t];
   }
   k_absmax_multi<<<RGCN_AMAX_HEADS, kThreads, 0, (hipStream_t)stream_>>>(J, zero_buffers, zero_count);
+  RGCN_HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+int rgcn_absmax_pack(const float* x, int64_t numel, float* x_amax, float* zero_buffers, int zero_count, int count,
+                     const float* const* weights, const float* const* roots, const int64_t* R, const int64_t* d_in,
+                     const int64_t* d_out, void* const* packed, const size_t* packed_bytes_, void* stream_) {
+  if (numel < 0 || !x_amax || (numel > 0 && !x) || zero_count < 0 || zero_count > kPackThreads ||
+      (zero_count > 0 && !zero_buffers))
+    return RGCN_ERR_ARG;
+  if (count < 1 || count > kPackJobs || !weights || !roots || !R || !d_in || !d_out || !packed || !packed_bytes_)
+    return RGCN_ERR_ARG;
+  absmax_multi_job J{};
+  J.count = 1;
+  J.p[0] = x; J.n[0] = numel; J.out[0] = x_amax;
+  pack_jobs JJ{};
+  int64_t most = 0;
+  for (int l = 0; l < count; ++l) {
+    if (R[l] <= 0 || d_in[l] <= 0 || d_out[l] <= 0 || (d_out[l] & 3) || !weights[l]) return RGCN_ERR_ARG;
+    if ((R[l] + 1) * d_in[l] > (1 << 24) || (R[l] + 1) * d_out[l] > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
+    if (!packed[l] || packed_bytes_[l] < packed_bytes(R[l], d_in[l], d_out[l])) return RGCN_ERR_WORKSPACE;
+    JJ.j[l] = make_pack_job(weights[l], roots[l], R[l], d_in[l], d_out[l], packed[l], nullptr, nullptr);
+    most = std::max<int64_t>(most, (R[l] + (roots[l] ? 1 : 0)) * d_in[l] * d_out[l]);
+  }
+  const int pack_blocks = (int)std::min<int64_t>(64, ceil_div64(most, kPackThreads));
+  dim3 grid(RGCN_AMAX_HEADS, (unsigned)(1 + count));
+  k_absmax_pack<<<grid, kPackThreads, 0, (hipStream_t)stream_>>>(J, zero_buffers, zero_count, JJ, pack_blocks);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

@@ -236,6 +236,56 @@ def split_weights_many(layers, amax=None):
     return out
 
 
+def absmax_and_split(x: torch.Tensor, out: torch.Tensor, clear: Optional[torch.Tensor], layers):
+    """The first launch of a forward pass as ONE launch (``rgcn_absmax_pack``): ``absmax(x, out, clear)`` and
+    ``split_weights_many(layers)`` together -> ``[SplitWeights | None, ...]``.  Layers the split kernels do not
+    tile (and fp32 mode) get None; if none is left this is ``absmax`` alone."""
+    if not layers or len(layers) > 4:
+        raise ValueError("1..4 layers")
+    _need_gpu("x", x, torch.float32)
+    if not x.is_contiguous():
+        raise ValueError("x must be contiguous")
+    _check_amax("out", out, x.device)
+    todo, packs = [], [None] * len(layers)
+    for i, (weight, root) in enumerate(layers):
+        _need_gpu("weight", weight, torch.float32)
+        if weight.dim() != 3 or not weight.is_contiguous():
+            raise ValueError("weight must be a contiguous [R, d_in, d_out]")
+        r, d_in, d_out = weight.shape
+        if root is not None:
+            _need_gpu("root", root, torch.float32)
+            if tuple(root.shape) != (d_in, d_out) or not root.is_contiguous():
+                raise ValueError(f"root must be a contiguous [{d_in}, {d_out}]")
+        if GEMM_PRECISION != "fp32" and d_in % 32 == 0 and d_out % 32 == 0:
+            todo.append(i)
+    if not todo:
+        absmax(x, out, clear)
+        return packs
+    count = 0
+    if clear is not None:
+        _need_gpu("clear", clear, torch.float32)
+        if clear.numel() % AMAX_FLOATS or clear.device != x.device:
+            raise ValueError("clear must hold whole amax buffers on x's device")
+        count = clear.numel() // AMAX_FLOATS
+    lib = _lib.load()
+    n = len(todo)
+    with _on(x.device):
+        sizes = [lib.rgcn_weights_split_bytes(*layers[i][0].shape) for i in todo]
+        bufs = [torch.empty(sz, dtype=torch.uint8, device=x.device) for sz in sizes]
+        arr, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)                                   # noqa: E731
+        rc = lib.rgcn_absmax_pack(
+            _ptr(x), x.numel(), _ptr(out), _ptr(clear), count, n,
+            cast(arr(*[_ptr(layers[i][0]) for i in todo])), cast(arr(*[_ptr(layers[i][1]) for i in todo])),
+            cast(i64(*[layers[i][0].size(0) for i in todo])), cast(i64(*[layers[i][0].size(1) for i in todo])),
+            cast(i64(*[layers[i][0].size(2) for i in todo])), cast(arr(*[_ptr(b) for b in bufs])),
+            cast((ctypes.c_size_t * n)(*sizes)), _stream())
+    _lib.check(rc, "rgcn_absmax_pack")
+    for i, b in zip(todo, bufs):
+        packs[i] = SplitWeights(b, layers[i][0], layers[i][1])
+    return packs
+
+
 def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     if nbytes <= 0:
         return None
