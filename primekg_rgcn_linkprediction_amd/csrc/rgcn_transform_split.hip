@@ -112,7 +112,7 @@ struct pack_jobs {
   pack_job j[kPackJobs];
 };
 
-__device__ inline void pack_body(const pack_job& J, float* red, int nblocks) {   // nblocks workgroups share the job
+__device__ inline void pack_body(const pack_job& J, float* red, int nblocks, int bid) {   // workgroup bid of the nblocks that share the job
   const float* __restrict__ W = J.W;
   const float* __restrict__ Rt = J.Rt;
   const int R = J.R, d_in = J.d_in, d_out = J.d_out;
@@ -149,7 +149,7 @@ __device__ inline void pack_body(const pack_job& J, float* red, int nblocks) {  
   }
   const int eb = scale_exponent(m);
   const float sb = pow2f(eb);
-  if (blockIdx.x == 0 && threadIdx.x == 0) J.scale_out[0] = pow2f(-eb);
+  if (bid == 0 && threadIdx.x == 0) J.scale_out[0] = pow2f(-eb);
   __half* __restrict__ Bh_f = J.Bh_f;
   __half* __restrict__ Bl_f = J.Bl_f;
   __half* __restrict__ Bh_b = J.Bh_b;
@@ -157,63 +157,50 @@ __device__ inline void pack_body(const pack_job& J, float* red, int nblocks) {  
   const int blocks = R + (Rt ? 1 : 0);
   const int Kf = blocks * d_in, Kb = blocks * d_out;
   const int64_t total = (int64_t)blocks * d_in * d_out;
-  // two passes so that the STORES of each image are contiguous (2-byte stores a whole row apart cost this
-  // launch twice its time); the strided side is a 4-byte read of L2-resident weights
-  for (int64_t e = (int64_t)blockIdx.x * kPackThreads + threadIdx.x; e < total; e += (int64_t)nblocks * kPackThreads) {
-    const int o = (int)(e % d_out);                       // o fastest: the backward image's k
-    const int i = (int)((e / d_out) % d_in);
-    const int r = (int)(e / ((int64_t)d_out * d_in));
-    const float v = (r < R ? W[e] : Rt[(size_t)i * d_out + o]) * sb;
-    const __half h = __float2half_rn(v);
-    const size_t bk = (size_t)i * Kb + (size_t)r * d_out + o;
-    Bh_b[bk] = h;
-    Bl_b[bk] = __float2half_rn(v - __half2float(h));
-  }
-  for (int64_t e = (int64_t)blockIdx.x * kPackThreads + threadIdx.x; e < total; e += (int64_t)nblocks * kPackThreads) {
-    const int i = (int)(e % d_in);                        // i fastest: the forward image's k
-    const int r = (int)((e / d_in) % blocks);
-    const int o = (int)(e / ((int64_t)d_in * blocks));
-    const float v = (r < R ? W[((size_t)r * d_in + i) * d_out + o] : Rt[(size_t)i * d_out + o]) * sb;
-    const __half h = __float2half_rn(v);
-    const size_t f = (size_t)o * Kf + (size_t)r * d_in + i;
-    Bh_f[f] = h;
-    Bl_f[f] = __float2half_rn(v - __half2float(h));
-  }
-  // Fragment order (widths that are multiples of 32 / 16 only): element ((s * NT + nt) * 64 + lane) * 8 + j is
+  // Element e of EACH image in one trip: the stores of every image are contiguous over e (2-byte stores a whole row
+  // apart cost this launch twice its time), the strided side is a 4-byte read of L2-resident weights - and the
+  // four reads of a trip are issued together (separate passes per image made this a chain of four round trips).
+  // Fragment order (widths that are multiples of 32 only): element ((s * NT + nt) * 64 + lane) * 8 + j is
   // image[n = 32 nt + (lane & 31)][k = 16 s + 8 (lane >> 5) + j] - a wave's B operand of one
-  // v_mfma_f32_32x32x16_f16 is ONE coalesced 16-byte-per-lane read, no LDS staging (the fused layer kernels
-  // keep these fragments in registers).
-  if ((d_in % 32) || (d_out % 32)) return;
-  __half* __restrict__ Fh_f = J.Fh_f;
-  __half* __restrict__ Fl_f = J.Fl_f;
-  for (int64_t e = (int64_t)blockIdx.x * kPackThreads + threadIdx.x; e < total; e += (int64_t)nblocks * kPackThreads) {
-    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
-    {                                                           // forward image: n = o, k = r * d_in + i
-      const int NT = d_out / 32;
-      const int nt = (int)((e >> 9) % NT), st = (int)((e >> 9) / NT);
-      const int o = 32 * nt + (lane & 31), k = 16 * st + 8 * (lane >> 5) + j;
-      const int r = k / d_in, i = k - r * d_in;
-      const float v = (r < R ? W[((size_t)r * d_in + i) * d_out + o] : Rt[(size_t)i * d_out + o]) * sb;
-      const __half h = __float2half_rn(v);
-      Fh_f[e] = h;
-      Fl_f[e] = __float2half_rn(v - __half2float(h));
+  // v_mfma_f32_32x32x16_f16 is ONE coalesced 16-byte-per-lane read, no LDS staging (the fused layer kernels keep
+  // these fragments in registers).
+  const bool frag = !((d_in % 32) || (d_out % 32));
+  auto source = [&](int r, int i, int o) -> const float* {
+    return r < R ? W + ((size_t)r * d_in + i) * d_out + o : Rt + (size_t)i * d_out + o;
+  };
+  auto split = [&](float raw, __half* __restrict__ hi, __half* __restrict__ lo, size_t at) {
+    const float v = raw * sb;
+    const __half h = __float2half_rn(v);
+    hi[at] = h;
+    lo[at] = __float2half_rn(v - __half2float(h));
+  };
+  for (int64_t e = (int64_t)bid * kPackThreads + threadIdx.x; e < total; e += (int64_t)nblocks * kPackThreads) {
+    // backward image, o fastest (its k): element e is (r, i, o) of [W ; root] itself
+    const int ob = (int)(e % d_out), ib = (int)((e / d_out) % d_in), rb = (int)(e / ((int64_t)d_out * d_in));
+    // forward image, i fastest (its k)
+    const int i_f = (int)(e % d_in), r_f = (int)((e / d_in) % blocks), o_f = (int)(e / ((int64_t)d_in * blocks));
+    const float vb = *source(rb, ib, ob), vf = *source(r_f, i_f, o_f);
+    float vff = 0.f, vfb = 0.f;
+    if (frag) {
+      const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+      const int NTf = d_out / 32, NTb = d_in / 32;
+      const int kf = 16 * (int)((e >> 9) / NTf) + 8 * (lane >> 5) + j, of = 32 * (int)((e >> 9) % NTf) + (lane & 31);
+      const int kb = 16 * (int)((e >> 9) / NTb) + 8 * (lane >> 5) + j, nb = 32 * (int)((e >> 9) % NTb) + (lane & 31);
+      vff = *source(kf / d_in, kf % d_in, of);                  // forward fragments: n = o, k = r * d_in + i
+      vfb = *source(kb / d_out, nb, kb % d_out);                // backward fragments: n = i, k = r * d_out + o
     }
-    {                                                           // backward image: n = i, k = r * d_out + o
-      const int NT = d_in / 32;
-      const int nt = (int)((e >> 9) % NT), st = (int)((e >> 9) / NT);
-      const int i = 32 * nt + (lane & 31), k = 16 * st + 8 * (lane >> 5) + j;
-      const int r = k / d_out, o = k - r * d_out;
-      const float v = (r < R ? W[((size_t)r * d_in + i) * d_out + o] : Rt[(size_t)i * d_out + o]) * sb;
-      const __half h = __float2half_rn(v);
-      J.Fh_b[e] = h;
-      J.Fl_b[e] = __float2half_rn(v - __half2float(h));
+    split(vb, Bh_b, Bl_b, (size_t)ib * Kb + (size_t)rb * d_out + ob);
+    split(vf, Bh_f, Bl_f, (size_t)o_f * Kf + (size_t)r_f * d_in + i_f);
+    if (frag) {
+      split(vff, J.Fh_f, J.Fl_f, (size_t)e);
+      split(vfb, J.Fh_b, J.Fl_b, (size_t)e);
     }
   }
 }
 
 __global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ) {
   __shared__ float red[kPackThreads / 64];
-  pack_body(JJ.j[blockIdx.y], red, (int)gridDim.x);   // one layer per grid row
+  pack_body(JJ.j[blockIdx.y], red, (int)gridDim.x, (int)blockIdx.x);   // one layer per grid row
 }
 
 // ---------------------------------------------------------------------------------------
@@ -486,14 +473,15 @@ struct absmax_multi_job {
 };
 
 template <int THREADS>
-__device__ inline void absmax_body(const absmax_multi_job& J, float* __restrict__ zero, int zero_count, float* red) {
+__device__ inline void absmax_body(const absmax_multi_job& J, float* __restrict__ zero, int zero_count, float* red,
+                                   int bid, int nblocks) {      // workgroup bid of nblocks = RGCN_AMAX_HEADS
   for (int t = 0; t < J.count; ++t) {
     const float* __restrict__ p = J.p[t];
     const int64_t n = J.n[t], n4 = n >> 2;
     const float4* p4 = reinterpret_cast<const float4*>(p);
     float m = 0.f;
-    const int64_t stride = (int64_t)gridDim.x * THREADS;
-    for (int64_t i0 = (int64_t)blockIdx.x * THREADS + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+    const int64_t stride = (int64_t)nblocks * THREADS;
+    for (int64_t i0 = (int64_t)bid * THREADS + threadIdx.x; i0 < n4; i0 += 4 * stride) {
       float4 v[4];                               // four independent loads per thread and round
 #pragma unroll
       for (int u = 0; u < 4; ++u) v[u] = (i0 + u * stride < n4) ? p4[i0 + u * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -501,7 +489,7 @@ __device__ inline void absmax_body(const absmax_multi_job& J, float* __restrict_
       for (int u = 0; u < 4; ++u)
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(p[n4 * 4 + threadIdx.x]));
+    if (bid == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(p[n4 * 4 + threadIdx.x]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
@@ -510,27 +498,31 @@ __device__ inline void absmax_body(const absmax_multi_job& J, float* __restrict_
       float mm = red[0];
 #pragma unroll
       for (int w = 1; w < THREADS / 64; ++w) mm = fmaxf(mm, red[w]);
-      J.out[t][blockIdx.x * RGCN_AMAX_HEAD_STRIDE] = mm;
+      J.out[t][bid * RGCN_AMAX_HEAD_STRIDE] = mm;
     }
     __syncthreads();
   }
-  if ((int)threadIdx.x < zero_count) zero[(size_t)threadIdx.x * RGCN_AMAX_FLOATS + blockIdx.x * RGCN_AMAX_HEAD_STRIDE] = 0.f;
+  if ((int)threadIdx.x < zero_count) zero[(size_t)threadIdx.x * RGCN_AMAX_FLOATS + bid * RGCN_AMAX_HEAD_STRIDE] = 0.f;
 }
 
-__global__ __launch_bounds__(kThreads) void k_absmax_multi(const absmax_multi_job J, float* __restrict__ zero,
-                                                           int zero_count) {
-  __shared__ float red[kThreads / 64];
-  absmax_body<kThreads>(J, zero, zero_count, red);
+// (1024 threads per workgroup: 4 M floats are then ONE round of four loads per thread instead of four)
+__global__ __launch_bounds__(kPackThreads) void k_absmax_multi(const absmax_multi_job J, float* __restrict__ zero,
+                                                               int zero_count) {
+  __shared__ float red[kPackThreads / 64];
+  absmax_body<kPackThreads>(J, zero, zero_count, red, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // The first launch of a forward pass: grid row 0 takes max |x| of the pass's input table (and clears the amax buffers
 // the pass's kernels publish into), rows 1.. split one layer's weights each (scanning them for their maximum
 // themselves: they are L2 resident) - one launch instead of k_absmax_multi + k_pack_split.
 __global__ __launch_bounds__(kPackThreads) void k_absmax_pack(const absmax_multi_job J, float* __restrict__ zero,
-                                                              int zero_count, const pack_jobs JJ, int pack_blocks) {
+                                                              int zero_count, const pack_jobs JJ, int pack_blocks,
+                                                              int layers) {
   __shared__ float red[kPackThreads / 64];
-  if (blockIdx.y == 0) absmax_body<kPackThreads>(J, zero, zero_count, red);
-  else if ((int)blockIdx.x < pack_blocks) pack_body(JJ.j[blockIdx.y - 1], red, pack_blocks);
+  // a flat grid: pack_blocks workgroups per layer first (their chain is the longer one), then the scan's
+  const int b = (int)blockIdx.x, npack = pack_blocks * layers;
+  if (b < npack) pack_body(JJ.j[b / pack_blocks], red, pack_blocks, b % pack_blocks);
+  else absmax_body<kPackThreads>(J, zero, zero_count, red, b - npack, RGCN_AMAX_HEADS);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -907,7 +899,7 @@ extern "C" {
 
 int rgcn_absmax_multi(int count, const float* const* tensors, const int64_t* numels, float* const* outs,
                       float* zero_buffers, int zero_count, void* stream_) {
-  if (count < 1 || count > kPrepTensors || !tensors || !numels || !outs || zero_count < 0 || zero_count > kThreads ||
+  if (count < 1 || count > kPrepTensors || !tensors || !numels || !outs || zero_count < 0 || zero_count > kPackThreads ||
       (zero_count > 0 && !zero_buffers))
     return RGCN_ERR_ARG;
   absmax_multi_job J{};
@@ -916,7 +908,7 @@ int rgcn_absmax_multi(int count, const float* const* tensors, const int64_t* num
     if (numels[t] < 0 || !outs[t] || (numels[t] > 0 && !tensors[t])) return RGCN_ERR_ARG;
     J.p[t] = tensors[t]; J.n[t] = numels[t]; J.out[t] = outs[t];
   }
-  k_absmax_multi<<<RGCN_AMAX_HEADS, kThreads, 0, (hipStream_t)stream_>>>(J, zero_buffers, zero_count);
+  k_absmax_multi<<<RGCN_AMAX_HEADS, kPackThreads, 0, (hipStream_t)stream_>>>(J, zero_buffers, zero_count);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -942,8 +934,8 @@ int rgcn_absmax_pack(const float* x, int64_t numel, float* x_amax, float* zero_b
     most = std::max<int64_t>(most, (R[l] + (roots[l] ? 1 : 0)) * d_in[l] * d_out[l]);
   }
   const int pack_blocks = (int)std::min<int64_t>(64, ceil_div64(most, kPackThreads));
-  dim3 grid(RGCN_AMAX_HEADS, (unsigned)(1 + count));
-  k_absmax_pack<<<grid, kPackThreads, 0, (hipStream_t)stream_>>>(J, zero_buffers, zero_count, JJ, pack_blocks);
+  k_absmax_pack<<<(unsigned)(pack_blocks * count + RGCN_AMAX_HEADS), kPackThreads, 0, (hipStream_t)stream_>>>(
+      J, zero_buffers, zero_count, JJ, pack_blocks, count);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
