@@ -1439,3 +1439,45 @@ def test_fused_input_gradient_is_bit_identical_to_gather_then_transform(n, e, r,
     if masked:
         ref = ref * (mask > 0)
     assert float((got.double() - ref).abs().max()) <= GRAD_RTOL * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_fused_layers_on_degenerate_graphs(monkeypatch):
+    """the one-kernel layers where little is left to gather: no edges at all, a single relation, fewer rows than a
+    block, a graph whose every segment is long (all pre-aggregated), dropout between the layers (the second
+    layer's input gradient then keeps the separate kernels: its weights are rescaled) - forced on for training,
+    results equal to the separate kernels bit for bit"""
+    from primekg_rgcn_linkprediction_amd import conv as C
+    dev = need_gpu()
+    gen = torch.Generator().manual_seed(1)
+    cases = {
+        "no edges": (torch.zeros(2, 0, dtype=torch.int64), torch.zeros(0, dtype=torch.int64), 40, 3),
+        "one relation": (torch.randint(0, 100, (2, 900), generator=gen), torch.zeros(900, dtype=torch.int64), 100, 1),
+        "five rows": (torch.randint(0, 5, (2, 60), generator=gen), torch.randint(0, 2, (60,), generator=gen), 5, 2),
+        "all long": (torch.stack([torch.randint(0, 64, (6000,), generator=gen), torch.randint(0, 2, (6000,), generator=gen)]),
+                     torch.zeros(6000, dtype=torch.int64), 64, 1),
+    }
+    for name, (ei, et, n, r) in cases.items():
+        eid, etd = ei.to(dev), et.to(dev)
+        torch.manual_seed(4)
+        emb = torch.randn(n, 64, device=dev)
+        convs = [RGCNConv(64, 128, r).to(dev), RGCNConv(128, 128, r).to(dev)]
+        cot = torch.randn(n, 128, device=dev)
+        for p_drop in (0.0, 0.5):
+            res = {}
+            for mode in ("0", "1"):
+                monkeypatch.setattr(C, "_TRAIN_FUSED", mode)
+                e = emb.clone().requires_grad_(True)
+                for c in convs:
+                    c.zero_grad()
+                torch.manual_seed(11)                             # the same dropout mask in both runs
+                out = rgcn_encoder2(e, eid, etd, convs[0], convs[1], dropout_p=p_drop)
+                (out * cot).sum().backward()
+                res[mode] = [out.detach(), e.grad.clone()] + [p.grad.clone() for c in convs for p in c.parameters()]
+            for a, b in zip(res["0"], res["1"]):
+                assert torch.equal(a, b), (name, p_drop)
+        with torch.no_grad():                                     # and the no-grad encoder (fused by default)
+            monkeypatch.setattr(C, "_EVAL_FUSED", True)
+            got = rgcn_encoder2(emb, eid, etd, convs[0], convs[1])
+            monkeypatch.setattr(C, "_EVAL_FUSED", False)
+            assert torch.equal(got, rgcn_encoder2(emb, eid, etd, convs[0], convs[1])), name
