@@ -236,6 +236,9 @@ def split_weights_many(layers, amax=None):
     return out
 
 
+_MERGED_PACK_MAX = 1 << 17      # elements of [W ; root] up to which the merged first launch scans the weights per workgroup
+
+
 def absmax_and_split(x: torch.Tensor, out: torch.Tensor, clear: Optional[torch.Tensor], layers):
     """The first launch of a forward pass as ONE launch (``rgcn_absmax_pack``): ``absmax(x, out, clear)`` and
     ``split_weights_many(layers)`` together -> ``[SplitWeights | None, ...]``.  Layers the split kernels do not
@@ -260,6 +263,25 @@ def absmax_and_split(x: torch.Tensor, out: torch.Tensor, clear: Optional[torch.T
             todo.append(i)
     if not todo:
         absmax(x, out, clear)
+        return packs
+    if max(layers[i][0].numel() + (layers[i][1].numel() if layers[i][1] is not None else 0) for i in todo) > _MERGED_PACK_MAX:
+        # large weights (hidden 256: 1 MB per layer): in the merged launch every one of a layer's 64 workgroups
+        # scans all of them for the maximum (35 us at C3); here one launch takes the maxima, a second one splits
+        tensors, outs, wam = [x], [out], {}
+        with _on(x.device):
+            allbufs = torch.empty(2 * len(todo), AMAX_FLOATS, dtype=torch.float32, device=x.device)   # every head is written
+        for k, i in enumerate(todo):
+            bufs = allbufs[2 * k: 2 * k + 2]
+            wam[i] = (bufs[0], bufs[1] if layers[i][1] is not None else None)
+            tensors.append(layers[i][0])
+            outs.append(bufs[0])
+            if layers[i][1] is not None:
+                tensors.append(layers[i][1])
+                outs.append(bufs[1])
+        absmax_many(tensors, outs, clear)
+        sub = split_weights_many([layers[i] for i in todo], amax=[wam[i] for i in todo])
+        for i, pk in zip(todo, sub):
+            packs[i] = pk
         return packs
     count = 0
     if clear is not None:
