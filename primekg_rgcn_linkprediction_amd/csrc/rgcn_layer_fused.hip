@@ -1,31 +1,38 @@
-// One R-GCN layer forward as ONE kernel: the neighbour mean of a block of 32 destination rows is formed in
-// LDS, as the A operand of the transform, and never exists in HBM.
+// One R-GCN layer as ONE kernel: the neighbour aggregate of a block of 32 rows is formed in LDS, as the A operand
+// of the transform, and is not read back from HBM (the no-grad forward never writes it either).
 //
-// Replaces, for the no-grad (evaluation / inference) encoder, the pair rgcn_aggregate -> rgcn_transform_fwd_split
-// (SURVEY.md section 8a rows A3 + A4 + A6; reference call sites src/models/rgcn.py:123,128 under
-// evaluate.py's torch.no_grad()): the [N, R * d_in] aggregate costs a write and a read of N * R * d_in * 4 bytes
-// per layer (4.1 GB at BASELINE configs[3]'s single-GPU size) that this kernel does not make.
+// Replaces the pair rgcn_aggregate -> rgcn_transform_*_split (SURVEY.md section 8a rows A3 + A4 + A6 and the input
+// gradient of A7; reference call sites src/models/rgcn.py:123,128, under evaluate.py's torch.no_grad() and in
+// training): the [N, R * d] aggregate costs a write and a read of N * R * d * 4 bytes per layer and direction
+// (4.1 GB at BASELINE configs[3]'s single-GPU size).  Three uses of the same kernel:
+//   forward, no grad      rgcn_layer_fwd_fused(agg = NULL)   mean aggregate, never in HBM
+//   forward, training     rgcn_layer_fwd_fused(agg != NULL)  the aggregate is also WRITTEN (the parameter gradients
+//                                                            need it); only its read is saved
+//   input gradient        rgcn_layer_bwd_input_fused         the transposed structure: 1/cnt-weighted sums over
+//                                                            out-edges, [gagg | g] * [W_r^T ; root^T] (* ReLU mask)
 //
-// Work decomposition.  One 256-thread workgroup owns 32 destination rows and all d_out columns.  The K
-// dimension of out = [agg | x] * [W ; root] is walked in R + 1 chunks of d_in: chunk r < R is relation r's
-// mean, chunk R the rows themselves.  Per chunk:
-//   gather   lane groups of G = d_in / 4 lanes (one float4 column slice per lane, as in k_aggregate) each take
-//            32 / (256 / G) of the rows: a SHORT segment (at most the plan's inline limit of edges) is summed right here in
-//            edge order, eight row loads in flight, and divided by its count - the same adds in the same order
-//            as k_aggregate, so the row is bit-identical to the unfused aggregate's; a LONG segment's mean was
-//            formed beforehand by the ordinary gather over a structure that holds only the long segments
+// Work decomposition.  One 256-thread workgroup owns 32 rows and all output columns.  The K dimension of
+// out = [agg | x] * B is walked in R + 1 chunks of the gathered row width d: chunk r < R is relation r's
+// aggregate, chunk R the rows themselves.  Per chunk:
+//   gather   lane groups of G = d / 4 lanes (one float4 column slice per lane, as in k_aggregate) each take
+//            32 / (256 / G) of the rows and gather them all at once (8 to 16 row loads in flight per lane): a SHORT
+//            segment (at most the plan's inline limit of edges) is summed right here in edge order and divided by
+//            its count (weighted mode: fma with the edge's weight, no division) - the same arithmetic in the same
+//            order as k_aggregate, so the row is bit-identical to the unfused aggregate's; a LONG segment's row
+//            was formed beforehand by the ordinary gather over a structure that holds only the long segments
 //            (ops.BucketedGraph.fused_plan: runs, packs and the hub reduce keep the launch free of stragglers)
 //            and is one row read here: the CSR this kernel walks holds ONE entry for it, a negative id that
-//            names the pre-aggregated row.  The group gathers all its rows of the chunk at once (kInFlight row
-//            loads per lane), the ids of the next chunk are fetched behind the multiply of this one.  The lane splits its four values (v * 2^e = hi + lo, fp16 each, e from
-//            the table's maximum: a mean cannot exceed it, and chunk R IS the table) and writes them to the two
-//            fp16 A images in LDS - no other lane repeats the split, unlike the stand-alone transform where
-//            every wave that shares an A tile splits it again.
+//            names the pre-aggregated row.  The ids of the next chunk are fetched behind the multiply of this
+//            one.  The lane splits its four values (v * 2^e = hi + lo, fp16 each; e from the table's maximum -
+//            a mean cannot exceed it, and chunk R IS the table -, in weighted mode from weight_bound * that
+//            maximum for the chunks of sums) and writes them to the two fp16 A images in LDS - no other lane
+//            repeats the split, unlike the stand-alone transform where every wave that shares an A tile splits
+//            it again.
 //   multiply wave w owns columns [32 TNW w, 32 TNW (w + 1)): A fragments are two ds_read_b128 (hi, lo), B
-//            fragments come straight from L2 in MFMA register order (k_pack_split's fragment images: one coalesced
-//            1 KB read per wave, fragment and part; no LDS staging: no two waves of the workgroup share a B column), two
-//            k-steps ahead; three v_mfma_f32_32x32x16_f16 per fragment pair, small terms first, exactly the
-//            stand-alone kernel's order - outputs are bit-identical to the unfused pair's.
+//            fragments come straight from L2 in MFMA register order (k_pack_split's fragment images: one
+//            coalesced 1 KB read per wave, fragment and part; no LDS staging: no two waves of the workgroup share
+//            a B column), one or two k-steps ahead; three v_mfma_f32_32x32x16_f16 per fragment pair, small terms
+//            first, exactly the stand-alone kernel's order - outputs are bit-identical to the unfused pair's.
 // Chunks whose relation no row of the block has (tile_mask) are skipped whole.
 #include <algorithm>
 
