@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 13
+#define RGCN_ABI_VERSION 14
 
 enum {
   RGCN_OK = 0,
@@ -272,7 +272,7 @@ int rgcn_absmax_multi(int count, const float* const* tensors, const int64_t* num
                       float* zero_buffers, int zero_count, void* stream);
 /* The weights of one layer split ONCE per step for both transforms that multiply by them ([W ; root] as fp16
  * hi / lo images in the forward and in the input-gradient orientation - each k-contiguous and in MFMA
- * B-fragment order -, one scale): pass the result as `packed`
+ * B-fragment order - and in [W ; root]'s own order, one scale): pass the result as `packed`
  * to the two calls below; with packed == NULL each call splits the weights itself (into its workspace). */
 size_t rgcn_weights_split_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
 int rgcn_weights_split_pack(const float* weight, const float* root, int64_t num_relations, int64_t d_in,
@@ -303,6 +303,13 @@ int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const floa
                                    const float* gagg_amax, float gagg_amax_mul, const float* g_amax, int half,
                                    float* grad_x, float* grad_x_amax, void* workspace, size_t workspace_bytes,
                                    void* stream);
+/* Transform-first half of the input gradient (layers with d_out >= 2 d_in): T[N, (R + 1) * d_in] =
+ * g * [W_0^T | ... | W_{R-1}^T | root^T] from the split weights' natural-order image (no concatenation, no second
+ * split); grad_x is then rgcn_aggregate over the merged transposed structure of T viewed [N * (R + 1), d_in].
+ * workspace: >= 2 KB (partial maxima when g_amax is NULL). */
+int rgcn_transform_first_split(const float* g, const void* packed, int has_root, int64_t num_nodes,
+                               int64_t num_relations, int64_t d_in, int64_t d_out, const float* g_amax, int half,
+                               float* t_out, void* workspace, size_t workspace_bytes, void* stream);
 size_t rgcn_transform_bwd_params_split_workspace_bytes(int64_t num_nodes, int64_t num_relations,
                                                        int64_t d_in, int64_t d_out);
 /* slab GEMM in split precision; the pending fixed-order reduction is consumed exactly like the one of

@@ -13,7 +13,7 @@ from ctypes import c_float, POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -78,6 +78,7 @@ PROTOTYPES = {
                                          _P, _P, _P, c_size_t, _P]),
     "rgcn_transform_bwd_input_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, c_int,
                                                _P, _P, _P, c_size_t, _P]),
+    "rgcn_transform_first_split": (c_int, [_P, _P, c_int, _I64, _I64, _I64, _I64, _P, c_int, _P, _P, c_size_t, _P]),
     "rgcn_transform_bwd_params_split_workspace_bytes": (c_size_t, [_I64, _I64, _I64, _I64]),
     "rgcn_transform_bwd_params_split_begin": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P, c_int,
                                                       _P, _P, _P, _P, c_size_t, _P, POINTER(SlabJob)]),

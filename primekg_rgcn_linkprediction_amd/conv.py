@@ -89,7 +89,7 @@ class _Scales:
 
 
 import os as _os
-_TRANSFORM_FIRST_RATIO = float(_os.environ.get("RGCN_TRANSFORM_FIRST_RATIO", "4"))   # A/B switch, see _input_grad
+_TRANSFORM_FIRST_RATIO = float(_os.environ.get("RGCN_TRANSFORM_FIRST_RATIO", "2"))   # A/B switch, see _input_grad
 
 
 def _fused_backward(graph, g, r, d_in, d_out, g_amax, packed, precision) -> bool:
@@ -108,15 +108,20 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
 
     Default: gather first (``gagg = transposed aggregate of g``, then one GEMM with
     K = (R+1) d_out) - the randomly read rows are d_out wide.
-    d_out >= 4 d_in (conv1 at hidden 256, BASELINE configs[2]): transform first -
+    d_out >= 2 d_in (conv1 at 64 -> 128 and at hidden 256, BASELINE configs[1..2]): transform first -
     ``T = g @ [W_r^T ... | root^T]`` is ``[N, (R+1) d_in]`` and the gather over the merged
-    structure reads d_in-wide rows (a quarter of the bytes per edge at 64 -> 256), adds the root
+    structure reads d_in-wide rows (half / a quarter of the bytes per edge), adds the root
     block as one more weighted row and writes ``grad_x`` directly.  Same flops.  Measured: the
-    step at 64 -> 256 -> 256 goes from 0.911 to 0.856 ms; at 64 -> 128 the short-K GEMM that writes
-    ``T`` costs what the narrower gather saves (54 us either way), so that layer keeps the default."""
+    step at 64 -> 256 -> 256 goes from 0.911 to 0.856 ms (round 1); at 64 -> 128 the short-K GEMM that writes
+    ``T`` cost what the narrower gather saved while it ran at the fp32 MFMA rate and split its own copy of the
+    weights - in split precision, from the step's split weights (``ops.transform_first``: their natural-order
+    image, no concatenation, no second split) the C2 step goes from 0.298 to 0.287 ms.  The fp32 and one-pass fp16
+    modes keep the threshold 4."""
     r, d_in, d_out = weight.shape
+    from_packed = packed is not None and ops.GEMM_PRECISION == "split" and precision is None and d_out % 32 == 0
+    ratio = _TRANSFORM_FIRST_RATIO if from_packed else max(_TRANSFORM_FIRST_RATIO, 4.0)
     merged = (graph.merged_transposed()
-              if (d_out >= _TRANSFORM_FIRST_RATIO * d_in and root is not None and not graph.bipartite) else None)
+              if (d_out >= ratio * d_in and root is not None and not graph.bipartite) else None)
     # `tail`: the pending slab reduction of this layer's parameter gradients rides in the gather launch
     if merged is None:
         if _fused_backward(graph, g, r, d_in, d_out, g_amax, packed, precision):
@@ -126,8 +131,11 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
         return ops.transform_bwd_input(gagg, g, weight, root, graph=graph, amax=(g_amax, g_amax),
                                        amax_mul=graph.weight_bound(True), packed=packed,
                                        precision=precision)                               # autograd of A6 wrt x
-    wcat = torch.cat([weight.reshape(r * d_in, d_out), root]).view(1, (r + 1) * d_in, d_out)
-    t = ops.transform_bwd_input(g, g, wcat, None, amax=(g_amax, None), precision=precision)   # [N, (R+1) d_in] = g @ wcat^T
+    if from_packed:
+        t = ops.transform_first(g.contiguous(), packed, g_amax)                   # from the step's split weights: no cat, no second split
+    else:
+        wcat = torch.cat([weight.reshape(r * d_in, d_out), root]).view(1, (r + 1) * d_in, d_out)
+        t = ops.transform_bwd_input(g, g, wcat, None, amax=(g_amax, None), precision=precision)   # [N, (R+1) d_in] = g @ wcat^T
     return ops.aggregate(merged, t.view(-1, d_in), tail=tail)
 
 

@@ -106,6 +106,7 @@ struct pack_job {
   const float *w_amax, *r_amax;                  // amax buffers of W and root (rgcn_absmax_multi), or NULL: scan here
   __half *Bh_f, *Bl_f, *Bh_b, *Bl_b;
   __half *Fh_f, *Fl_f, *Fh_b, *Fl_b;             // the same two images in MFMA B-fragment order (see k_pack_split)
+  __half *Bh_n, *Bl_n;                           // [W ; root] in its own order [(r, i)][o]: the transform-first image
   float* scale_out;
 };
 struct pack_jobs {
@@ -190,6 +191,7 @@ __device__ inline void pack_body(const pack_job& J, float* red, int nblocks, int
       vfb = *source(kb / d_out, nb, kb % d_out);                // backward fragments: n = i, k = r * d_out + o
     }
     split(vb, Bh_b, Bl_b, (size_t)ib * Kb + (size_t)rb * d_out + ob);
+    split(vb, J.Bh_n, J.Bl_n, (size_t)e);        // natural order: n = r * d_in + i, k = o (T = g * [W_r^T | root^T])
     split(vf, Bh_f, Bl_f, (size_t)o_f * Kf + (size_t)r_f * d_in + i_f);
     if (frag) {
       split(vff, J.Fh_f, J.Fl_f, (size_t)e);
@@ -743,14 +745,16 @@ size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // The split weights of one layer (rgcn_weights_split_pack):
 //   [ Bh_f ][ Bl_f ][ Bh_b ][ Bl_b ]  four fp16 images of (R+1)*d_in*d_out elements each (256-aligned), k contiguous
 //   [ Fh_f ][ Fl_f ][ Fh_b ][ Fl_b ]  the same four in MFMA B-fragment order (the fused layer kernels)
+//   [ Bh_n ][ Bl_n ]                  [W ; root] in its own order [(r, i)][o], o contiguous (transform-first input gradient)
 //   [ inv_scale: 64 floats ][ partial maxima of W and root: 2 * kMaxSlots floats ]
 struct PackedWeights {
   __half *Bh_f, *Bl_f, *Bh_b, *Bl_b;
   __half *Fh_f, *Fl_f, *Fh_b, *Fl_b;
+  __half *Bh_n, *Bl_n;
   float *inv_scale, *partials;
 };
 size_t packed_bytes(int64_t R, int64_t d_in, int64_t d_out) {
-  return 8 * align256((size_t)(R + 1) * d_in * d_out * sizeof(__half)) + 256 + 2 * kMaxSlots * sizeof(float);
+  return 10 * align256((size_t)(R + 1) * d_in * d_out * sizeof(__half)) + 256 + 2 * kMaxSlots * sizeof(float);
 }
 PackedWeights packed_view(void* base, int64_t R, int64_t d_in, int64_t d_out) {
   const size_t img = align256((size_t)(R + 1) * d_in * d_out * sizeof(__half));
@@ -764,7 +768,9 @@ PackedWeights packed_view(void* base, int64_t R, int64_t d_in, int64_t d_out) {
   v.Fl_f = (__half*)(p + 5 * img);
   v.Fh_b = (__half*)(p + 6 * img);
   v.Fl_b = (__half*)(p + 7 * img);
-  v.inv_scale = (float*)(p + 8 * img);
+  v.Bh_n = (__half*)(p + 8 * img);
+  v.Bl_n = (__half*)(p + 9 * img);
+  v.inv_scale = (float*)(p + 10 * img);
   v.partials = v.inv_scale + 64;
   return v;
 }
@@ -779,6 +785,7 @@ pack_job make_pack_job(const float* weight, const float* root, int64_t R, int64_
   if (root && !r_amax) j.w_amax = nullptr;                     // both maxima or none
   j.Bh_f = v.Bh_f; j.Bl_f = v.Bl_f; j.Bh_b = v.Bh_b; j.Bl_b = v.Bl_b;
   j.Fh_f = v.Fh_f; j.Fl_f = v.Fl_f; j.Fh_b = v.Fh_b; j.Fl_b = v.Fl_b;
+  j.Bh_n = v.Bh_n; j.Bl_n = v.Bl_n;
   j.scale_out = v.inv_scale;
   return j;
 }
@@ -1032,6 +1039,22 @@ int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const floa
   return launch_nt_split(gagg, K1, g, K2, v.Bh_b, v.Bl_b, v.inv_scale, nullptr, relu_mask,
                          relu_mask ? EPI_MASK : EPI_NONE, grad_x, (int)N, (int)d_in, tile_mask, (int)d_out, gagg_amax,
                          gagg_amax_mul, g_amax, grad_x_amax, scan, half != 0, stream);
+}
+
+int rgcn_transform_first_split(const float* g, const void* packed, int has_root, int64_t N, int64_t R, int64_t d_in,
+                               int64_t d_out, const float* g_amax, int half, float* t_out, void* workspace,
+                               size_t workspace_bytes, void* stream_) {
+  if (bad_dims(N, R, d_in, d_out) || !t_out || !packed) return RGCN_ERR_ARG;
+  if (N == 0) return RGCN_OK;
+  if (!g) return RGCN_ERR_ARG;
+  if (d_out % BK) return RGCN_ERR_UNSUPPORTED;
+  const int64_t cols = (R + (has_root ? 1 : 0)) * d_in;
+  if (N > INT32_MAX / 2 || cols > (1 << 24) || d_out > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < 2 * kMaxSlots * sizeof(float)) return RGCN_ERR_WORKSPACE;
+  const PackedWeights v = packed_view(const_cast<void*>(packed), R, d_in, d_out);
+  return launch_nt_split(g, (int)d_out, nullptr, 0, v.Bh_n, v.Bl_n, v.inv_scale, nullptr, nullptr, EPI_NONE, t_out, (int)N,
+                         (int)cols, nullptr, 0, g_amax, 1.f, nullptr, nullptr, (float*)workspace, half != 0,
+                         (hipStream_t)stream_);
 }
 
 size_t rgcn_transform_bwd_params_split_workspace_bytes(int64_t N, int64_t R, int64_t d_in, int64_t d_out) {

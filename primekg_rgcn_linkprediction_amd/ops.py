@@ -1080,6 +1080,31 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
     return gx
 
 
+def transform_first(g: torch.Tensor, packed: SplitWeights, amax: Optional[torch.Tensor] = None,
+                    precision: Optional[str] = None) -> torch.Tensor:
+    """``T = g @ [W_0^T | ... | W_{R-1}^T | root^T]`` -> ``[N, (R + 1) * d_in]`` (``R * d_in`` without a root) from
+    the split weights' natural-order image (``rgcn_transform_first_split``): the dense half of the transform-first
+    input gradient, without concatenating or splitting the weights again.  ``amax``: amax buffer of ``g``."""
+    _need_gpu("g", g, torch.float32)
+    r, d_in, d_out = packed.shape
+    if g.dim() != 2 or g.size(1) != d_out or not g.is_contiguous() or g.device != packed.buf.device:
+        raise ValueError(f"g must be a contiguous [N, {d_out}] on the weights' device")
+    split = _use_split(precision, d_out, 32)
+    if not split:
+        raise ValueError("transform_first runs in split precision only")
+    _check_amax("amax", amax, g.device)
+    lib = _lib.load()
+    n = g.size(0)
+    with _on(g.device):
+        t = torch.empty(n, (r + int(packed.has_root)) * d_in, dtype=torch.float32, device=g.device)
+        ws = _workspace(2048, g.device)
+        with _GemmBracket("bwd_input", n, d_out, t.size(1), "split" if split == 1 else "half"):
+            rc = lib.rgcn_transform_first_split(_ptr(g), _ptr(packed.buf), int(packed.has_root), n, r, d_in, d_out,
+                                                _ptr(amax), int(split == 2), _ptr(t), _ptr(ws), 2048, _stream())
+    _lib.check(rc, "rgcn_transform_first_split")
+    return t
+
+
 def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, want_bias: bool = True,
                          graph: Optional[BucketedGraph] = None, defer: bool = False, amax=None,
                          precision: Optional[str] = None, amax_mul: float = 1.0):

@@ -1376,21 +1376,25 @@ def test_training_forward_through_the_fused_layer_changes_no_bit(monkeypatch):
     for c in convs:
         c.bias.data.uniform_(-0.1, 0.1)
     cot = torch.randn(n, 128, device=dev)
-    results = {}
-    for mode in ("0", "1"):
-        monkeypatch.setattr(C, "_TRAIN_FUSED", mode)
-        events = []
-        monkeypatch.setattr(ops, "FUSED_EVENTS", events)
-        e = emb.clone().requires_grad_(True)
-        for c in convs:
-            c.zero_grad()
-        out = rgcn_encoder2(e, eid, etd, convs[0], convs[1])
-        (out * cot).sum().backward()
-        single = convs[0](e.detach(), eid, etd, activation="relu")
-        assert len(events) == (5 if mode == "1" else 0)        # taken: 2 forward + 2 input-gradient layers, the single layer
-        results[mode] = [out.detach(), e.grad.clone(), single.detach()] + [p.grad.clone() for c in convs for p in c.parameters()]
-    for a, b in zip(results["0"], results["1"]):
-        assert torch.equal(a, b)
+    # conv1's input gradient (64 -> 128) goes transform-first by default (threshold 2: no fused kernel there); with
+    # the threshold at 4 it is the fused kernel with a 64-wide output
+    for ratio, launches in ((2.0, 4), (4.0, 5)):
+        monkeypatch.setattr(C, "_TRANSFORM_FIRST_RATIO", ratio)
+        results = {}
+        for mode in ("0", "1"):
+            monkeypatch.setattr(C, "_TRAIN_FUSED", mode)
+            events = []
+            monkeypatch.setattr(ops, "FUSED_EVENTS", events)
+            e = emb.clone().requires_grad_(True)
+            for c in convs:
+                c.zero_grad()
+            out = rgcn_encoder2(e, eid, etd, convs[0], convs[1])
+            (out * cot).sum().backward()
+            single = convs[0](e.detach(), eid, etd, activation="relu")
+            assert len(events) == (launches if mode == "1" else 0)    # taken: 2 forward + 1 or 2 input-gradient layers, the single layer
+            results[mode] = [out.detach(), e.grad.clone(), single.detach()] + [p.grad.clone() for c in convs for p in c.parameters()]
+        for a, b in zip(results["0"], results["1"]):
+            assert torch.equal(a, b), ratio
 
 
 @pytest.mark.gpu
