@@ -6,8 +6,9 @@ tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out
 python3 bench.py > $out/${tag}_c2_bench.json 2> $out/${tag}_c2_bench.err
-stats() {  # name, extra bench args ...
+stats() {  # name, extra bench args ...: the line itself first (no profiler attached), then the same command under rocprofv3
   local name=$1; shift
+  [ "$name" = c2 ] || python3 bench.py --no-cpu-baseline "$@" > $out/${tag}_${name}_bench.json 2> $out/${tag}_${name}_bench.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag}_$name -o p -- python3 bench.py --no-cpu-baseline "$@" \
       > $out/${tag}_${name}_prof_bench.json 2> $out/${tag}_${name}_prof.err
   cp "$(find $out/prof_${tag}_$name -name '*kernel_stats.csv' | head -1)" $out/${tag}_${name}_kernel_stats.csv
@@ -34,6 +35,6 @@ print("roofline", {k: r["roofline"][k] for k in ("kernel", "avg_us", "achieved",
 print("mfma", {k: r["roofline_mfma"][k] for k in ("call", "arithmetic", "avg_us", "achieved", "frac", "executed_tflops", "sum_transform_us_per_step")})
 print("cpu", r["cpu_baseline"]["value"], r["cpu_baseline"]["cores"], r["gpu_over_cpu"])
 for n in ("c2_fp32", "c2_fp16", "c3", "c4_1gpu", "c4_1gpu_unfused", "c2_e1677772"):
-    q = json.load(open(f"$out/${tag}_{n}_prof_bench.json"))
+    q = json.load(open(f"$out/${tag}_{n}_bench.json"))
     print(n, q["ms_per_step"], q["value"], q.get("roofline", {}).get("frac"), q.get("roofline", {}).get("kernel"))
 PY
