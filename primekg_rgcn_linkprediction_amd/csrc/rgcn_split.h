@@ -38,5 +38,7 @@ struct rgcn_split_frag_view {
   const __half *Fh_f, *Fl_f, *Fh_b, *Fl_b;
   const float* inv_scale;
 };
-rgcn_split_frag_view rgcn_split_fragment_images(const void* packed, int64_t R, int64_t d_in, int64_t d_out);
-size_t rgcn_split_packed_bytes(int64_t R, int64_t d_in, int64_t d_out);
+// (shared between the library's translation units, not part of the C ABI)
+__attribute__((visibility("hidden"))) rgcn_split_frag_view rgcn_split_fragment_images(const void* packed, int64_t R,
+                                                                                    int64_t d_in, int64_t d_out);
+__attribute__((visibility("hidden"))) size_t rgcn_split_packed_bytes(int64_t R, int64_t d_in, int64_t d_out);
