@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 14
+#define RGCN_ABI_VERSION 15
 
 enum {
   RGCN_OK = 0,
@@ -170,6 +170,14 @@ int rgcn_aggregate_f16(const rgcn_graph* g, int transposed, const void* x_f16, i
 int rgcn_aggregate_amax(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
                         void* workspace, size_t workspace_bytes, const rgcn_slab_job* job, float* amax,
                         void* stream);
+/* The gather WITHOUT its hub-tail launch: segments longer than 256 edges are left as partial rows in `workspace`
+ * (which the caller keeps alive), to be summed by the split-precision transform that consumes the aggregate
+ * (hub_graph / hub_partial arguments of rgcn_transform_fwd_split / _bwd_input_split) - one launch less per
+ * gather.  deferrable: 1 if the structure has exactly one reduce level (every segment <= 131,072 edges) and d is
+ * 64, 128 or 256.  job: as rgcn_aggregate_and_reduce (NULL: none). */
+int rgcn_aggregate_deferrable(const rgcn_graph* g, int transposed, int64_t d);
+int rgcn_aggregate_deferred(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
+                            void* workspace, size_t workspace_bytes, const rgcn_slab_job* job, void* stream);
 /* One launch of the above (level in [0, rgcn_graph_num_levels)); calling the levels in order
  * equals rgcn_aggregate.  Lets a profiler bracket the level-0 gather kernel by itself. */
 int rgcn_aggregate_level(const rgcn_graph* g, int transposed, int level, const float* x, int64_t d,
@@ -292,17 +300,24 @@ int rgcn_absmax_pack(const float* x, int64_t numel, float* x_amax, float* zero_b
                      const int64_t* d_in, const int64_t* d_out, void* const* packed, const size_t* packed_bytes,
                      void* stream);
 size_t rgcn_transform_split_workspace_bytes(int64_t num_relations, int64_t d_in, int64_t d_out);
+/* hub_graph / hub_transposed / hub_partial (NULL / 0 / NULL: the aggregate operand is complete): the operand came
+ * from rgcn_aggregate_deferred over that structure and direction, with hub_partial its workspace - the transform
+ * finishes the hub rows of each 64-row tile itself before reading it (and writes them into the aggregate, which
+ * is therefore complete once the call has run).  Needs agg_amax / gagg_amax (an unfinished operand cannot be
+ * scanned). */
 int rgcn_transform_fwd_split(const float* agg, const float* x, const float* weight, const float* root,
                              const void* packed, const float* bias, int relu, const uint32_t* tile_mask,
                              int64_t num_nodes, int64_t num_relations, int64_t d_in, int64_t d_out,
                              const float* agg_amax, float agg_amax_mul, const float* x_amax, int half,
-                             float* out, float* out_amax, void* workspace, size_t workspace_bytes, void* stream);
+                             float* out, float* out_amax, void* workspace, size_t workspace_bytes, void* stream,
+                             const rgcn_graph* hub_graph, int hub_transposed, float* hub_partial);
 int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const float* weight, const float* root,
                                    const void* packed, const float* relu_mask, const uint32_t* tile_mask,
                                    int64_t num_nodes, int64_t num_relations, int64_t d_in, int64_t d_out,
                                    const float* gagg_amax, float gagg_amax_mul, const float* g_amax, int half,
                                    float* grad_x, float* grad_x_amax, void* workspace, size_t workspace_bytes,
-                                   void* stream);
+                                   void* stream, const rgcn_graph* hub_graph, int hub_transposed,
+                                   float* hub_partial);
 /* Transform-first half of the input gradient (layers with d_out >= 2 d_in): T[N, (R + 1) * d_in] =
  * g * [W_0^T | ... | W_{R-1}^T | root^T] from the split weights' natural-order image (no concatenation, no second
  * split); grad_x is then rgcn_aggregate over the merged transposed structure of T viewed [N * (R + 1), d_in].

@@ -126,11 +126,14 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
     if merged is None:
         if _fused_backward(graph, g, r, d_in, d_out, g_amax, packed, precision):
             return ops.layer_bwd_input_fused(graph, g, packed, None, g_amax, inline_limit=_EVAL_INLINE_LIMIT, tail=tail)
-        gagg = ops.aggregate(graph, g, transposed=True, tail=tail)       # autograd of A3 + A4 (fp32 grads)
+        if _defer_hubs(False, packed, g_amax, d_out) and precision in (None, "half") and not graph.bipartite:
+            gagg, hubs = ops.aggregate_deferred(graph, g, transposed=True, tail=tail)
+        else:
+            gagg, hubs = ops.aggregate(graph, g, transposed=True, tail=tail), None       # autograd of A3 + A4 (fp32 grads)
         # |gagg| <= (largest sum of 1/cnt weights over a node's out-edges of one relation) * max |g|
         return ops.transform_bwd_input(gagg, g, weight, root, graph=graph, amax=(g_amax, g_amax),
                                        amax_mul=graph.weight_bound(True), packed=packed,
-                                       precision=precision)                               # autograd of A6 wrt x
+                                       precision=precision, hubs=hubs)                    # autograd of A6 wrt x
     if from_packed:
         t = ops.transform_first(g.contiguous(), packed, g_amax)                   # from the step's split weights: no cat, no second split
     else:
@@ -149,6 +152,16 @@ _TRAIN_FUSED = _os.environ.get("RGCN_TRAIN_FUSED", "auto")
 _TRAIN_FUSED_MIN_BYTES = 256 << 20
 
 
+def _defer_hubs(half: bool, packed, amax, k: int) -> bool:
+    """may a gather leave its hub tails to the transform that follows it?  (split precision with the operand's
+    scale known beforehand; RGCN_DEFER_HUBS=0 keeps the separate launch)"""
+    return (_DEFER_HUBS and not half and packed is not None and amax is not None and ops.GEMM_PRECISION == "split"
+            and k % 32 == 0)
+
+
+_DEFER_HUBS = _os.environ.get("RGCN_DEFER_HUBS", "1") == "1"
+
+
 def _layer_train_forward(graph: "ops.BucketedGraph", x: Tensor, gather_dtype, weight, root, bias, relu: bool,
                          half: bool, x_amax, amax_out, packed):
     """-> (agg, out) of one layer's training forward"""
@@ -160,9 +173,13 @@ def _layer_train_forward(graph: "ops.BucketedGraph", x: Tensor, gather_dtype, we
         out = ops.layer_fwd_fused(graph, x, packed, bias, relu, x_amax, amax_out, inline_limit=_EVAL_INLINE_LIMIT,
                                   agg_out=agg)
         return agg, out
-    agg = ops.aggregate(graph, _table(x, gather_dtype))
+    if _defer_hubs(half, packed, x_amax, d_in):
+        # the gather leaves its hub tails to the transform (one launch less); `agg` is complete once that has run
+        agg, hubs = ops.aggregate_deferred(graph, x)
+    else:
+        agg, hubs = ops.aggregate(graph, _table(x, gather_dtype)), None
     out = ops.transform_fwd(agg, x, weight, root, bias, relu=relu, graph=graph, half=half, amax=(x_amax, x_amax),
-                            amax_out=amax_out, packed=packed)
+                            amax_out=amax_out, packed=packed, hubs=hubs)
     return agg, out
 
 
@@ -277,9 +294,12 @@ class _Encoder2Function(torch.autograd.Function):
             gz = ops.layer_bwd_input_fused(graph, g, pk2, h, g_amax, amax_out=gz_amax, inline_limit=_EVAL_INLINE_LIMIT,
                                            tail=red2)
         else:
-            gagg2 = ops.aggregate(graph, g, transposed=True, tail=red2)
+            if _defer_hubs(False, pk2, g_amax, w2.size(2)) and not graph.bipartite:
+                gagg2, hubs2 = ops.aggregate_deferred(graph, g, transposed=True, tail=red2)
+            else:
+                gagg2, hubs2 = ops.aggregate(graph, g, transposed=True, tail=red2), None
             gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph, amax=(g_amax, g_amax),
-                                         amax_mul=wb, amax_out=gz_amax, packed=pk2, precision=prec)   # d loss / d (pre-ReLU of conv1)
+                                         amax_mul=wb, amax_out=gz_amax, packed=pk2, precision=prec, hubs=hubs2)   # d loss / d (pre-ReLU of conv1)
         red1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1, graph=graph,
                                         defer=True, amax=(x_amax, x_amax, gz_amax), precision=prec)
         gx = None

@@ -23,6 +23,7 @@
 
 #include "rgcn_common.h"
 #include "rgcn_slab_reduce.h"
+#include "rgcn_hub_finish.h"
 
 namespace {
 
@@ -31,7 +32,6 @@ constexpr int kUnroll = RGCN_HEAD;   // rows in flight per lane group = ids that
 #ifndef RGCN_REDUCE_UNROLL
 #define RGCN_REDUCE_UNROLL 16
 #endif
-constexpr int kReduceUnroll = RGCN_REDUCE_UNROLL;   // contiguous partial rows in flight per slot of the hub reduce
 
 __device__ inline float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ inline float f4amax(const float4& a) { return fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))); }
@@ -310,43 +310,11 @@ __global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* _
                                                               const float* __restrict__ cnt,
                                                               float* __restrict__ agg, float* partial, int d,
                                                               unsigned* __restrict__ amax_out) {
-  constexpr int SLOTS = kThreads / G;
   __shared__ float4 red[kThreads];
-  const rgcn_item it = items[blockIdx.x];
-  const int gl = (int)threadIdx.x % G, slot = (int)threadIdx.x / G;
-  const int c4 = (gl + (int)blockIdx.y * G) * 4;
-  const bool live = c4 < d;
-  float4 acc = f4zero();
-  if (live) {
-    for (int r0 = it.begin + slot; r0 < it.end; r0 += SLOTS * kReduceUnroll) {
-      float4 v[kReduceUnroll];
-#pragma unroll
-      for (int u = 0; u < kReduceUnroll; ++u) {
-        const int row = r0 + u * SLOTS;
-        v[u] = f4zero();
-        if (row < it.end) v[u] = *reinterpret_cast<const float4*>(partial + (size_t)row * d + c4);
-      }
-#pragma unroll
-      for (int u = 0; u < kReduceUnroll; ++u) f4add(acc, v[u]);
-    }
-  }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  if (slot == 0 && live) {
-    float4 s = red[gl];
-#pragma unroll
-    for (int k = 1; k < SLOTS; ++k) f4add(s, red[k * G + gl]);
-    if (it.flags & RGCN_ITEM_FINAL) {
-      if (cnt) {
-        const float c = cnt[it.dst];
-        s.x /= c; s.y /= c; s.z /= c; s.w /= c;
-      }
-      *reinterpret_cast<float4*>(agg + (size_t)it.dst * d + c4) = s;
-      if (amax_out) rgcn_amax_publish(amax_out, f4amax(s));
-    } else {
-      *reinterpret_cast<float4*>(partial + (size_t)it.dst * d + c4) = s;
-    }
-  }
+  const float lmax = rgcn_reduce_item<G>(items[blockIdx.x], cnt, agg, partial, d, (int)blockIdx.y * G, red);
+  if (amax_out && (int)threadIdx.x < G && (((int)threadIdx.x + (int)blockIdx.y * G) * 4 < d) &&
+      (items[blockIdx.x].flags & RGCN_ITEM_FINAL))
+    rgcn_amax_publish(amax_out, lmax);
 }
 
 template <int G>
@@ -457,6 +425,18 @@ int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t 
   if (!g) return RGCN_ERR_ARG;
   return aggregate_levels(g, transposed, 0, g->dir[transposed ? 1 : 0].num_levels, x, d, agg, workspace,
                           workspace_bytes, stream);
+}
+
+int rgcn_aggregate_deferrable(const rgcn_graph* g, int transposed, int64_t d) {
+  if (!g) return 0;
+  const rgcn_csr& c = g->dir[transposed ? 1 : 0];
+  return (c.num_levels == 2 && c.fin_ptr && (d == 64 || d == 128 || d == 256)) ? 1 : 0;
+}
+
+int rgcn_aggregate_deferred(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
+                            void* workspace, size_t workspace_bytes, const rgcn_slab_job* job, void* stream) {
+  if (!rgcn_aggregate_deferrable(g, transposed, d)) return RGCN_ERR_UNSUPPORTED;
+  return aggregate_levels(g, transposed, 0, 1, x, d, agg, workspace, workspace_bytes, stream, false, job);
 }
 
 int rgcn_aggregate_and_reduce(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,

@@ -63,6 +63,13 @@ struct rgcn_csr {
   // disease row): the transforms skip the all-zero k/m-tiles these bits expose.  NULL if R > 32.
   uint32_t* tile_mask = nullptr;
   int64_t num_row_tiles = 0;
+  // Deferred hub tails: when the plan has exactly ONE reduce level (every segment <= RGCN_CHUNK * RGCN_PACK *
+  // RGCN_CHUNK_UP = 131,072 edges), its items are ordered by the 32-row tile of their destination row and
+  // fin_ptr[t] .. fin_ptr[t + 1] are the items of tile t: a consumer that reads the aggregate tile by tile (the
+  // split-precision NT transforms) can finish the hub rows of its own tile itself - the same sums in the same
+  // order as k_reduce_partials - and the separate reduce launch disappears.  NULL otherwise.
+  int32_t* fin_ptr = nullptr;   // [num_fin_tiles + 1]
+  int64_t num_fin_tiles = 0;
   // max over segments of sum of |weights| (weighted mode; 1 in mean mode): |agg row| <= weight_bound * max |x|.
   // The split-precision transforms scale the aggregate operand by this bound instead of scanning it.
   float weight_bound = 1.f;

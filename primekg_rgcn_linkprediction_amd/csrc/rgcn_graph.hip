@@ -89,7 +89,7 @@ inline unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, ceil
 // of <= RGCN_CHUNK_UP (a workgroup per run) until one row is left.  Order inside level 0: packs first
 // (by descending edge count), then the single items by descending length, so the lane groups of a
 // wavefront finish together and long items start first; packs occupy RGCN_PACK-aligned slots.
-int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, rgcn_csr* csr) {
+int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, int64_t R, rgcn_csr* csr) {
   struct Pending { int32_t seg, begin, end; };
   struct Pack { int32_t begin, end, dst, final_row; };
   std::vector<std::vector<rgcn_item>> levels;
@@ -171,6 +171,18 @@ int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, rgcn_csr* csr) {
   }
   if (partial_rows > INT32_MAX) return RGCN_ERR_UNSUPPORTED;
 
+  // exactly one reduce level: its items by destination tile, so that a tile-wise consumer can finish them itself
+  std::vector<int32_t> fin_ptr;
+  if (levels.size() == 2 && !levels[1].empty() && R > 0) {
+    const int64_t tiles = ceil_div64(csr->n_key, 32);
+    auto tile_of = [&](const rgcn_item& it) { return (int64_t)(it.dst / R) >> 5; };
+    std::stable_sort(levels[1].begin(), levels[1].end(),
+                     [&](const rgcn_item& a, const rgcn_item& b) { return tile_of(a) < tile_of(b); });
+    fin_ptr.assign((size_t)tiles + 1, 0);
+    for (const rgcn_item& it : levels[1]) ++fin_ptr[(size_t)tile_of(it) + 1];
+    for (int64_t t = 0; t < tiles; ++t) fin_ptr[(size_t)t + 1] += fin_ptr[(size_t)t];
+  }
+
   csr->num_levels = (int)levels.size();
   csr->num_partials = partial_rows;
   for (int l = 0; l < csr->num_levels; ++l) {
@@ -179,6 +191,11 @@ int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, rgcn_csr* csr) {
     if (v.empty()) continue;
     RGCN_HIP_TRY(hipMalloc((void**)&csr->items[l], v.size() * sizeof(rgcn_item)));
     RGCN_HIP_TRY(hipMemcpy(csr->items[l], v.data(), v.size() * sizeof(rgcn_item), hipMemcpyHostToDevice));
+  }
+  if (!fin_ptr.empty()) {
+    RGCN_HIP_TRY(hipMalloc((void**)&csr->fin_ptr, fin_ptr.size() * sizeof(int32_t)));
+    RGCN_HIP_TRY(hipMemcpy(csr->fin_ptr, fin_ptr.data(), fin_ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    csr->num_fin_tiles = (int64_t)fin_ptr.size() - 1;
   }
   return RGCN_OK;
 }
@@ -189,6 +206,7 @@ void free_csr(rgcn_csr* c) {
   (void)hipFree(c->perm);
   (void)hipFree(c->val);
   (void)hipFree(c->tile_mask);
+  (void)hipFree(c->fin_ptr);
   (void)hipFree(c->head_col);
   (void)hipFree(c->head_w);
   for (int l = 0; l < RGCN_MAX_LEVELS; ++l) (void)hipFree(c->items[l]);
@@ -289,7 +307,7 @@ int plan_structure(rgcn_csr* c, int64_t R, hipStream_t stream) {
     RGCN_HIP_TRY(hipMalloc((void**)&c->tile_mask, mask.size() * sizeof(uint32_t)));
     RGCN_HIP_TRY(hipMemcpy(c->tile_mask, mask.data(), mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
-  TRY_PLAN(build_plan(rp, NR, c));
+  TRY_PLAN(build_plan(rp, NR, R, c));
   c->weight_bound = 1.f;
   if (c->weighted && NR > 0 && rp[(size_t)NR] > 0) {      // one-time, on the host: max over segments of sum |w|
     std::vector<float> w((size_t)rp[(size_t)NR]);

@@ -30,6 +30,7 @@
 
 #include "rgcn_common.h"
 #include "rgcn_slab_reduce.h"
+#include "rgcn_hub_finish.h"
 #include "rgcn_split.h"
 
 namespace {
@@ -217,6 +218,17 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ)
 // the same 256 KB for every workgroup - is two thirds of the 64-row tile's traffic: 128 rows halve it.
 // LO = false: ONE pass on the hi parts only - operands rounded to fp16 (under their per-tensor power-of-two
 // scales, which is loss scaling per tensor), fp32 accumulate: BASELINE configs[4]'s gradient GEMMs.
+// Hub tails left to the consumer (rgcn_common.h, fin_ptr): the level-1 items of the structure A1 was gathered over,
+// by 32-row tile, the partial rows the gather left, the counts of a mean structure, the row width.  ptr == NULL:
+// A1 is complete.
+struct hub_fin {
+  const int32_t* ptr;
+  const rgcn_item* items;
+  const float* cnt;
+  float* partial;
+  int d, tiles;
+};
+
 template <int WM, int TN, int EPI, bool LO>
 __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restrict__ A1, int K1,
                                                             const float* __restrict__ A2, int K2,
@@ -227,7 +239,8 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ mask, float* __restrict__ C,
                                                             int M, int N, const uint32_t* __restrict__ tile_mask,
-                                                            int kseg, unsigned* __restrict__ amax_out) {
+                                                            int kseg, unsigned* __restrict__ amax_out,
+                                                            const hub_fin fin) {
   constexpr int BM = 32 * WM, BN = 64 * TN, NBUF = WM == 2 ? 3 : 4, D = NBUF - 1;   // D k-tiles in flight
   constexpr int PARTS = LO ? 2 : 1;              // B images staged: hi (and lo)
   constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + PARTS * B_BYTES;
@@ -243,6 +256,29 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
+
+  // Hub rows of this workgroup's row tiles whose partial rows the gather left unsummed: summed here, by the whole
+  // workgroup, exactly as k_reduce_partials would (same function), written to A1 and only then read back by the
+  // DMAs below.  Workgroups of other column blocks of the same rows write the same values.
+  if (WM == 2 && fin.ptr) {
+    const int t32 = m0 >> 5;
+    const int jb = __builtin_amdgcn_readfirstlane(fin.ptr[min(t32, fin.tiles)]);
+    const int je = __builtin_amdgcn_readfirstlane(fin.ptr[min(t32 + WM, fin.tiles)]);
+    if (je > jb) {
+      float4* red = reinterpret_cast<float4*>(lds);
+      float* agg = const_cast<float*>(A1);
+      for (int j = jb; j < je; ++j) {
+        const rgcn_item it = fin.items[j];
+        if (fin.d == 64) rgcn_reduce_item<16>(it, fin.cnt, agg, fin.partial, 64, 0, red);
+        else if (fin.d == 128) rgcn_reduce_item<32>(it, fin.cnt, agg, fin.partial, 128, 0, red);
+        else rgcn_reduce_item<64>(it, fin.cnt, agg, fin.partial, 256, 0, red);
+        __syncthreads();                                         // `red` is the next item's, then the ring's
+      }
+      __threadfence_block();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the rows are in L2 before this workgroup's DMAs ask for them
+      __syncthreads();
+    }
+  }
 
   floatx16 acc[TN];
 #pragma unroll
@@ -818,7 +854,10 @@ size_t nt_workspace_bytes(int64_t R, int64_t d_in, int64_t d_out) {
 int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __half* Bh, const __half* Bl,
                     const float* b_inv, const float* bias, const float* mask, int epi, float* C, int M, int N,
                     const uint32_t* tile_mask, int kseg, const float* a1_amax, float a1_mul, const float* a2_amax,
-                    float* c_amax, float* scan_slots, bool half, hipStream_t stream) {
+                    float* c_amax, float* scan_slots, bool half, hipStream_t stream, const hub_fin* hubs = nullptr) {
+  const hub_fin fin = hubs ? *hubs : hub_fin{};
+  if (fin.ptr && (nt_rows() != 64 || (fin.d != 64 && fin.d != 128 && fin.d != 256))) return RGCN_ERR_UNSUPPORTED;
+  if (fin.ptr && (!a1_amax || fin.d != kseg)) return RGCN_ERR_ARG;   // an unfinished A1 cannot be scanned for its maximum
   const int K = K1 + K2;
   if (K1 % BK || K2 % BK || K <= 0) return RGCN_ERR_UNSUPPORTED;
   // maxima of the A operands: from their producers, or scanned here (one launch over what is missing)
@@ -837,7 +876,8 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
   unsigned* amax_out = reinterpret_cast<unsigned*>(c_amax);
 #define RGCN_NT_LAUNCH(WM_, TN_, EPI_, LO_)                                                                          \
   k_gemm_nt_split<WM_, TN_, EPI_, LO_><<<grid, 128 * WM_, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, \
-                                                                        bias, mask, C, M, N, tile_mask, kseg, amax_out)
+                                                                        bias, mask, C, M, N, tile_mask, kseg, amax_out, \
+                                                                        fin)
 #define RGCN_NT_SPLIT(WM_, TN_, EPI_)        \
   do {                                       \
     if (half) RGCN_NT_LAUNCH(WM_, TN_, EPI_, false); \
@@ -863,6 +903,23 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
 #undef RGCN_NT_SPLIT
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
+}
+
+// the hub tails a gather left to this transform (rgcn_aggregate_deferred): 0 = none, < 0 = error code
+int make_hub_fin(const rgcn_graph* g, int transposed, float* partial, int64_t N, int64_t R, int64_t d, hub_fin* out) {
+  *out = hub_fin{};
+  if (!g) return 0;
+  const rgcn_csr& c = g->dir[transposed ? 1 : 0];
+  if (!c.rowptr || c.n_key != N || g->R != R) return RGCN_ERR_ARG;
+  if (c.num_levels < 2) return 0;                              // nothing was deferred
+  if (!c.fin_ptr || c.num_levels != 2 || !partial) return RGCN_ERR_ARG;
+  out->ptr = c.fin_ptr;
+  out->items = c.items[1];
+  out->cnt = c.weighted ? nullptr : c.val;
+  out->partial = partial;
+  out->d = (int)d;
+  out->tiles = (int)c.num_fin_tiles;
+  return 1;
 }
 
 bool bad_dims(int64_t n, int64_t r, int64_t di, int64_t dout) {
@@ -995,7 +1052,8 @@ int rgcn_transform_fwd_split(const float* agg, const float* x, const float* weig
                              const void* packed, const float* bias, int relu, const uint32_t* tile_mask, int64_t N,
                              int64_t R, int64_t d_in, int64_t d_out, const float* agg_amax, float agg_amax_mul,
                              const float* x_amax, int half, float* out, float* out_amax, void* workspace,
-                             size_t workspace_bytes, void* stream_) {
+                             size_t workspace_bytes, void* stream_, const rgcn_graph* hub_graph, int hub_transposed,
+                             float* hub_partial) {
   if (bad_dims(N, R, d_in, d_out) || !out) return RGCN_ERR_ARG;
   if (N == 0) return RGCN_OK;
   if (!agg || !x || !weight) return RGCN_ERR_ARG;
@@ -1011,16 +1069,20 @@ int rgcn_transform_fwd_split(const float* agg, const float* x, const float* weig
   const PackedWeights v = packed_view(const_cast<void*>(packed), R, d_in, d_out);
   float* scan = (float*)((char*)workspace + packed_bytes(R, d_in, d_out));
   const int K1 = (int)(R * d_in), K2 = root ? (int)d_in : 0;
+  hub_fin fin;
+  const int hrc = make_hub_fin(hub_graph, hub_transposed, hub_partial, N, R, d_in, &fin);
+  if (hrc < 0) return hrc;
   return launch_nt_split(agg, K1, x, K2, v.Bh_f, v.Bl_f, v.inv_scale, bias, nullptr, relu ? EPI_RELU : EPI_NONE, out,
                          (int)N, (int)d_out, tile_mask, (int)d_in, agg_amax, agg_amax_mul, x_amax, out_amax, scan, half != 0,
-                         stream);
+                         stream, hrc ? &fin : nullptr);
 }
 
 int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const float* weight, const float* root,
                                    const void* packed, const float* relu_mask, const uint32_t* tile_mask, int64_t N,
                                    int64_t R, int64_t d_in, int64_t d_out, const float* gagg_amax,
                                    float gagg_amax_mul, const float* g_amax, int half, float* grad_x,
-                                   float* grad_x_amax, void* workspace, size_t workspace_bytes, void* stream_) {
+                                   float* grad_x_amax, void* workspace, size_t workspace_bytes, void* stream_,
+                                   const rgcn_graph* hub_graph, int hub_transposed, float* hub_partial) {
   if (bad_dims(N, R, d_in, d_out) || !grad_x) return RGCN_ERR_ARG;
   if (N == 0) return RGCN_OK;
   if (!gagg || !g || !weight) return RGCN_ERR_ARG;
@@ -1036,9 +1098,12 @@ int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const floa
   const PackedWeights v = packed_view(const_cast<void*>(packed), R, d_in, d_out);
   float* scan = (float*)((char*)workspace + packed_bytes(R, d_in, d_out));
   const int K1 = (int)(R * d_out), K2 = root ? (int)d_out : 0;
+  hub_fin fin;
+  const int hrc = make_hub_fin(hub_graph, hub_transposed, hub_partial, N, R, d_out, &fin);
+  if (hrc < 0) return hrc;
   return launch_nt_split(gagg, K1, g, K2, v.Bh_b, v.Bl_b, v.inv_scale, nullptr, relu_mask,
                          relu_mask ? EPI_MASK : EPI_NONE, grad_x, (int)N, (int)d_in, tile_mask, (int)d_out, gagg_amax,
-                         gagg_amax_mul, g_amax, grad_x_amax, scan, half != 0, stream);
+                         gagg_amax_mul, g_amax, grad_x_amax, scan, half != 0, stream, hrc ? &fin : nullptr);
 }
 
 int rgcn_transform_first_split(const float* g, const void* packed, int has_root, int64_t N, int64_t R, int64_t d_in,

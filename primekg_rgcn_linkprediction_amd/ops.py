@@ -918,6 +918,53 @@ def layer_bwd_input_fused(graph: BucketedGraph, g: torch.Tensor, packed: SplitWe
     return gx
 
 
+class DeferredHubs:
+    """What ``aggregate_deferred`` leaves for the transform that consumes its result: the structure and direction
+    (their level-1 items by row tile) and the partial rows (kept alive here until that transform has been launched)."""
+
+    def __init__(self, graph: BucketedGraph, transposed: bool, partial: torch.Tensor):
+        self.graph, self.transposed, self.partial = graph, bool(transposed), partial
+
+
+def aggregate_deferred(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
+                       tail: Optional[PendingParamGrads] = None):
+    """``aggregate`` WITHOUT the hub-tail launch, for a result that goes straight into ``transform_fwd`` /
+    ``transform_bwd_input`` in split precision: ``(agg, hubs)`` - hand ``hubs`` to that call, which sums the partial
+    rows of the long segments tile by tile itself (same order, same bits) and completes ``agg`` in passing.
+    ``hubs`` is None (and ``agg`` complete) where nothing can be deferred: no long segment, a structure with more
+    than one reduce level, a width other than 64 / 128 / 256, an fp16 table, measurement mode."""
+    lib = _lib.load()
+    d = x.size(1) if x.dim() == 2 else 0
+    deferrable = (x.dtype == torch.float32 and GATHER_EVENTS is None and graph.num_levels(transposed) == 2
+                  and bool(lib.rgcn_aggregate_deferrable(graph.handle, int(transposed), d)))
+    if not deferrable:
+        return aggregate(graph, x, transposed, tail=tail), None
+    _need_gpu("x", x, torch.float32)
+    if graph.bipartite and transposed:
+        raise ValueError("a shard structure has one direction only (transposed=False)")
+    if x.size(0) != graph.num_other_nodes or x.device != graph.device:
+        raise ValueError(f"x must be [{graph.num_other_nodes}, d] on the graph's device, got {tuple(x.shape)}")
+    with _on(x.device):
+        out = torch.empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
+        nbytes = graph.workspace_bytes(transposed, d)
+        ws = _workspace(nbytes, x.device)
+        job = tail.job if (tail is not None and not tail.done) else None
+        rc = lib.rgcn_aggregate_deferred(graph.handle, int(transposed), _ptr(x), d, _ptr(out), _ptr(ws), nbytes,
+                                         ctypes.byref(job) if job is not None else None, _stream())
+        if rc == 0 and job is not None:
+            tail._launched()
+    _lib.check(rc, "rgcn_aggregate_deferred")
+    return out, DeferredHubs(graph, transposed, ws)
+
+
+def _hub_args(hubs: Optional[DeferredHubs], n: int, r: int):
+    if hubs is None:
+        return None, 0, None
+    if hubs.graph.num_nodes != n or hubs.graph.num_relations != r:
+        raise ValueError("hubs do not belong to this aggregate")
+    return hubs.graph.handle, int(hubs.transposed), _ptr(hubs.partial)
+
+
 # ----------------------------------------------------------------------------------
 # transform (row A6 / its autograd)
 # ----------------------------------------------------------------------------------
@@ -959,7 +1006,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
                   graph: Optional[BucketedGraph] = None, half: bool = False, amax=None,
                   amax_out: Optional[torch.Tensor] = None, precision: Optional[str] = None,
                   packed: Optional[SplitWeights] = None, amax_mul: float = 1.0,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, hubs: Optional[DeferredHubs] = None) -> torch.Tensor:
     """``sum_r agg[:, r] @ weight[r] + x @ root + bias`` as one fp32-MFMA GEMM; ``relu``
     fuses the activation that follows conv1 (``rgcn.py:124``) into the epilogue.  ``graph``
     (the structure ``agg`` was aggregated over) lets the kernel skip the k-tiles of relations
@@ -999,9 +1046,11 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
                                                   _ptr(packed.buf) if packed is not None else None, _ptr(bias),
                                                   int(relu), _mask_for(graph, False, n, r), n, r, d_in, d_out,
                                                   _ptr(a1), float(amax_mul), _ptr(a2), int(split == 2), _ptr(out),
-                                                  _ptr(amax_out), _ptr(ws), nbytes, _stream())
+                                                  _ptr(amax_out), _ptr(ws), nbytes, _stream(), *_hub_args(hubs, n, r))
         _lib.check(rc, "rgcn_transform_fwd_split")
         return out
+    if hubs is not None:
+        raise ValueError("deferred hub tails need the split-precision transform (finish them with aggregate instead)")
     if half and d_in % 32 == 0:
         with _on(x.device):
             out = given_out if given_out is not None else torch.empty(n, d_out, dtype=torch.float32, device=x.device)
@@ -1029,7 +1078,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
 def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
                         graph: Optional[BucketedGraph] = None, amax=None, amax_out: Optional[torch.Tensor] = None,
                         precision: Optional[str] = None, packed: Optional[SplitWeights] = None,
-                        amax_mul: float = 1.0) -> torch.Tensor:
+                        amax_mul: float = 1.0, hubs: Optional[DeferredHubs] = None) -> torch.Tensor:
     """``grad_x = sum_r gagg[:, r] @ weight[r]^T + g @ root^T``; with ``relu_mask`` (the
     layer's input, when that input is the output of a fused-ReLU layer) the result is
     additionally multiplied by ``relu_mask > 0``."""
@@ -1066,9 +1115,12 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
                                                         _ptr(packed.buf) if packed is not None else None,
                                                         _ptr(relu_mask), _mask_for(graph, True, n, r), n, r, d_in,
                                                         d_out, _ptr(a1), float(amax_mul), _ptr(a2), int(split == 2),
-                                                        _ptr(gx), _ptr(amax_out), _ptr(ws), nbytes, _stream())
+                                                        _ptr(gx), _ptr(amax_out), _ptr(ws), nbytes, _stream(),
+                                                        *_hub_args(hubs, n, r))
         _lib.check(rc, "rgcn_transform_bwd_input_split")
         return gx
+    if hubs is not None:
+        raise ValueError("deferred hub tails need the split-precision transform (finish them with aggregate instead)")
     with _on(g.device):
         gx = torch.empty(n, d_in, dtype=torch.float32, device=g.device)
         with _GemmBracket("bwd_input", n, (r + (root is not None)) * d_out, d_in, "fp32"):

@@ -1485,3 +1485,63 @@ def test_fused_layers_on_degenerate_graphs(monkeypatch):
             got = rgcn_encoder2(emb, eid, etd, convs[0], convs[1])
             monkeypatch.setattr(C, "_EVAL_FUSED", False)
             assert torch.equal(got, rgcn_encoder2(emb, eid, etd, convs[0], convs[1])), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d_in,d_out", [(64, 128), (128, 128), (128, 256), (256, 64)])
+def test_hub_tails_left_to_the_transform_change_no_bit(d_in, d_out, monkeypatch):
+    """rgcn_aggregate_deferred: the gather skips its hub-tail launch and the split-precision transform that reads the
+    aggregate sums the partial rows of its own row tiles (the same function k_reduce_partials runs): outputs, the
+    completed aggregate and - through the training node with the switch on and off - every gradient are bit-equal;
+    forward and transposed direction, several column blocks finishing the same rows (d_out = 256), ReLU mask."""
+    from primekg_rgcn_linkprediction_amd import conv as C
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=400000, seed=17)
+    eid, etd = ei.to(dev), et.to(dev)
+    graph = ops.bucket(eid, etd, n, r)
+    assert graph.num_levels(False) == 2 and graph.num_levels(True) == 2          # there ARE hub tails
+    torch.manual_seed(d_in)
+    x = torch.randn(n, d_in, device=dev)
+    g = torch.randn(n, d_out, device=dev) * 1e-3
+    weight = torch.randn(r, d_in, d_out, device=dev) / d_in ** 0.5
+    root = torch.randn(d_in, d_out, device=dev) / d_in ** 0.5
+    bias = torch.randn(d_out, device=dev)
+    mask = torch.randn(n, d_in, device=dev)
+    packed = ops.split_weights(weight, root)
+    x_amax, g_amax = ops.absmax(x), ops.absmax(g)
+    # forward
+    agg_full = ops.aggregate(graph, x)
+    want = ops.transform_fwd(agg_full, x, weight, root, bias, relu=True, graph=graph, amax=(x_amax, x_amax), packed=packed)
+    agg, hubs = ops.aggregate_deferred(graph, x)
+    assert hubs is not None                                                       # (the hub rows are not in agg yet)
+    got = ops.transform_fwd(agg, x, weight, root, bias, relu=True, graph=graph, amax=(x_amax, x_amax), packed=packed,
+                            hubs=hubs)
+    assert torch.equal(got, want) and torch.equal(agg, agg_full)                  # ... and are, once the transform ran
+    # input gradient (transposed structure, weighted sums, mask epilogue)
+    gagg_full = ops.aggregate(graph, g, transposed=True)
+    wb = graph.weight_bound(True)
+    want = ops.transform_bwd_input(gagg_full, g, weight, root, relu_mask=mask, graph=graph, amax=(g_amax, g_amax),
+                                   amax_mul=wb, packed=packed)
+    gagg, hubs = ops.aggregate_deferred(graph, g, transposed=True)
+    assert hubs is not None
+    got = ops.transform_bwd_input(gagg, g, weight, root, relu_mask=mask, graph=graph, amax=(g_amax, g_amax),
+                                  amax_mul=wb, packed=packed, hubs=hubs)
+    assert torch.equal(got, want) and torch.equal(gagg, gagg_full)
+    with pytest.raises(ValueError):                                               # the fp32 kernels do not finish hub rows
+        ops.transform_fwd(agg, x, weight, root, bias, graph=graph, precision="fp32", hubs=hubs)
+    if (d_in, d_out) != (64, 128):
+        return
+    # the training node, switch on / off
+    convs = [RGCNConv(64, 128, r).to(dev), RGCNConv(128, 128, r).to(dev)]
+    cot = torch.randn(n, 128, device=dev)
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(C, "_DEFER_HUBS", on)
+        e = x.clone().requires_grad_(True)
+        for c in convs:
+            c.zero_grad()
+        out = rgcn_encoder2(e, eid, etd, convs[0], convs[1])
+        (out * cot).sum().backward()
+        res[on] = [out.detach(), e.grad.clone()] + [p.grad.clone() for c in convs for p in c.parameters()]
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
