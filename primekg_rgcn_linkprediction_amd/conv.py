@@ -126,7 +126,7 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
     if merged is None:
         if _fused_backward(graph, g, r, d_in, d_out, g_amax, packed, precision):
             return ops.layer_bwd_input_fused(graph, g, packed, None, g_amax, inline_limit=_EVAL_INLINE_LIMIT, tail=tail)
-        if _defer_hubs(False, packed, g_amax, d_out) and precision in (None, "half") and not graph.bipartite:
+        if _defer_hubs(False, packed, g_amax, d_out, d_in) and precision in (None, "half") and not graph.bipartite:
             gagg, hubs = ops.aggregate_deferred(graph, g, transposed=True, tail=tail)
         else:
             gagg, hubs = ops.aggregate(graph, g, transposed=True, tail=tail), None       # autograd of A3 + A4 (fp32 grads)
@@ -152,11 +152,13 @@ _TRAIN_FUSED = _os.environ.get("RGCN_TRAIN_FUSED", "auto")
 _TRAIN_FUSED_MIN_BYTES = 256 << 20
 
 
-def _defer_hubs(half: bool, packed, amax, k: int) -> bool:
-    """may a gather leave its hub tails to the transform that follows it?  (split precision with the operand's
-    scale known beforehand; RGCN_DEFER_HUBS=0 keeps the separate launch)"""
+def _defer_hubs(half: bool, packed, amax, k: int, n_out: int) -> bool:
+    """may a gather of k-wide rows leave its hub tails to the transform (n_out columns) that follows it?  Split
+    precision with the operand's scale known beforehand; rows up to 128 wide and ONE column block of workgroups
+    (at 256 the workgroups of every column block would each finish the same rows, with four row slots: measured
+    1 % slower at C3); RGCN_DEFER_HUBS=0 keeps the separate launch."""
     return (_DEFER_HUBS and not half and packed is not None and amax is not None and ops.GEMM_PRECISION == "split"
-            and k % 32 == 0)
+            and k in (64, 128) and n_out <= 128)
 
 
 _DEFER_HUBS = _os.environ.get("RGCN_DEFER_HUBS", "1") == "1"
@@ -173,7 +175,7 @@ def _layer_train_forward(graph: "ops.BucketedGraph", x: Tensor, gather_dtype, we
         out = ops.layer_fwd_fused(graph, x, packed, bias, relu, x_amax, amax_out, inline_limit=_EVAL_INLINE_LIMIT,
                                   agg_out=agg)
         return agg, out
-    if _defer_hubs(half, packed, x_amax, d_in):
+    if _defer_hubs(half, packed, x_amax, d_in, d_out):
         # the gather leaves its hub tails to the transform (one launch less); `agg` is complete once that has run
         agg, hubs = ops.aggregate_deferred(graph, x)
     else:
@@ -294,7 +296,7 @@ class _Encoder2Function(torch.autograd.Function):
             gz = ops.layer_bwd_input_fused(graph, g, pk2, h, g_amax, amax_out=gz_amax, inline_limit=_EVAL_INLINE_LIMIT,
                                            tail=red2)
         else:
-            if _defer_hubs(False, pk2, g_amax, w2.size(2)) and not graph.bipartite:
+            if _defer_hubs(False, pk2, g_amax, w2.size(2), w2.size(1)) and not graph.bipartite:
                 gagg2, hubs2 = ops.aggregate_deferred(graph, g, transposed=True, tail=red2)
             else:
                 gagg2, hubs2 = ops.aggregate(graph, g, transposed=True, tail=red2), None
