@@ -268,11 +268,13 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
       float4* red = reinterpret_cast<float4*>(lds);
       float* agg = const_cast<float*>(A1);
       for (int j = jb; j < je; ++j) {
+        // two scratch areas in turn: the barrier inside item j + 1 is what separates item j's reads of its area
+        // from item j + 2's writes to it - one barrier per item
+        float4* scratch = red + ((j - jb) & 1) * 256;
         const rgcn_item it = fin.items[j];
-        if (fin.d == 64) rgcn_reduce_item<16>(it, fin.cnt, agg, fin.partial, 64, 0, red);
-        else if (fin.d == 128) rgcn_reduce_item<32>(it, fin.cnt, agg, fin.partial, 128, 0, red);
-        else rgcn_reduce_item<64>(it, fin.cnt, agg, fin.partial, 256, 0, red);
-        __syncthreads();                                         // `red` is the next item's, then the ring's
+        if (fin.d == 64) rgcn_reduce_item<16>(it, fin.cnt, agg, fin.partial, 64, 0, scratch);
+        else if (fin.d == 128) rgcn_reduce_item<32>(it, fin.cnt, agg, fin.partial, 128, 0, scratch);
+        else rgcn_reduce_item<64>(it, fin.cnt, agg, fin.partial, 256, 0, scratch);
       }
       __threadfence_block();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the rows are in L2 before this workgroup's DMAs ask for them
