@@ -329,17 +329,27 @@ class _Encoder2Function(torch.autograd.Function):
 _EVAL_BLOCK_BYTES = int(_os.environ.get("RGCN_EVAL_BLOCK_BYTES", str(1 << 30)))
 
 
-# RGCN_EVAL_FUSED (default 1): 1 = the one-kernel layer (ops.layer_fwd_fused: the aggregate lives in LDS only) wherever it
-# covers the shape, 0 = the two-launch path below.  RGCN_EVAL_INLINE_LIMIT: longest segment the fused kernel walks
+# RGCN_EVAL_FUSED (default auto): the one-kernel layer (ops.layer_fwd_fused: the aggregate lives in LDS only) wherever it
+# covers the shape - auto: once the aggregate would reach 256 MB, where the path is HBM-bound (C4 on one GPU: 6.0 -> 3.5
+# ms per 2-layer forward); at C2's size the two launches are as fast (0.114 against 0.118 ms) -, 1: always, 0 = the
+# two-launch path below.  RGCN_EVAL_INLINE_LIMIT: longest segment the fused kernel walks
 # itself (longer ones are pre-aggregated by the ordinary gather).
-_EVAL_FUSED = _os.environ.get("RGCN_EVAL_FUSED", "1") == "1"
+_EVAL_FUSED = _os.environ.get("RGCN_EVAL_FUSED", "auto")          # "auto" | "1" | "0" (tests also set True / False)
+
+
+def _eval_fused(n: int, r: int, d_in: int) -> bool:
+    if _EVAL_FUSED in (True, "1"):
+        return True
+    if _EVAL_FUSED in (False, "0"):
+        return False
+    return n * r * d_in * 4 >= _TRAIN_FUSED_MIN_BYTES          # the same threshold as the training layers
 _EVAL_INLINE_LIMIT = int(_os.environ.get("RGCN_EVAL_INLINE_LIMIT", "16"))
 
 
 def _layer_eval_blocked(graph: "ops.BucketedGraph", x: Tensor, table: Tensor, weight: Tensor, root, bias, relu: bool,
                         half: bool, amax, amax_out, packed) -> Tensor:
     n, r, d_in, d_out = x.size(0), graph.num_relations, x.size(1), weight.size(2)
-    if (_EVAL_FUSED and not half and packed is not None and amax[1] is not None and not graph.weighted_shard
+    if (_eval_fused(n, r, d_in) and not half and packed is not None and amax[1] is not None and not graph.weighted_shard
             and x.size(0) == graph.num_other_nodes and ops.fused_supported(r, d_in, d_out)):
         return ops.layer_fwd_fused(graph, x, packed, bias, relu, amax[1], amax_out, inline_limit=_EVAL_INLINE_LIMIT)
     rows = max(32, _EVAL_BLOCK_BYTES // max(1, r * d_in * 4))
