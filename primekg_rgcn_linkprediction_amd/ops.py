@@ -181,7 +181,7 @@ class SplitWeights:
 
 def fused_supported(num_relations: int, d_in: int, d_out: int) -> bool:
     """does the one-kernel layer forward cover this shape (in split precision)?"""
-    return GEMM_PRECISION != "fp32" and bool(_lib.load().rgcn_layer_fwd_fused_supported(num_relations, d_in, d_out))
+    return GEMM_PRECISION != "fp32" and bool(_query("rgcn_layer_fwd_fused_supported", int(num_relations), int(d_in), int(d_out)))
 
 
 def split_weights(weight: torch.Tensor, root: Optional[torch.Tensor]) -> Optional[SplitWeights]:
@@ -213,7 +213,7 @@ def split_weights_many(layers, amax=None):
     dev = layers[todo[0]][0].device
     n = len(todo)
     with _on(dev):
-        sizes = [lib.rgcn_weights_split_bytes(*layers[i][0].shape) for i in todo]
+        sizes = [_query("rgcn_weights_split_bytes", *layers[i][0].shape) for i in todo]
         bufs = [torch.empty(sz, dtype=torch.uint8, device=dev) for sz in sizes]
         arr = ctypes.c_void_p * n
         i64 = ctypes.c_int64 * n
@@ -292,7 +292,7 @@ def absmax_and_split(x: torch.Tensor, out: torch.Tensor, clear: Optional[torch.T
     lib = _lib.load()
     n = len(todo)
     with _on(x.device):
-        sizes = [lib.rgcn_weights_split_bytes(*layers[i][0].shape) for i in todo]
+        sizes = [_query("rgcn_weights_split_bytes", *layers[i][0].shape) for i in todo]
         bufs = [torch.empty(sz, dtype=torch.uint8, device=x.device) for sz in sizes]
         arr, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)                                   # noqa: E731
@@ -306,6 +306,18 @@ def absmax_and_split(x: torch.Tensor, out: torch.Tensor, clear: Optional[torch.T
     for i, b in zip(todo, bufs):
         packs[i] = SplitWeights(b, layers[i][0], layers[i][1])
     return packs
+
+
+_QUERY_CACHE = {}
+
+
+def _query(name: str, *args) -> int:
+    """a pure size / capability query of the library, memoised (each ctypes call costs 2-4 us of host time)"""
+    key = (name,) + args
+    v = _QUERY_CACHE.get(key)
+    if v is None:
+        v = _QUERY_CACHE[key] = getattr(_lib.load(), name)(*args)
+    return v
 
 
 def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
@@ -475,7 +487,20 @@ class BucketedGraph:
         return cache[key]
 
     def num_levels(self, transposed: bool) -> int:
-        return _lib.load().rgcn_graph_num_levels(self.handle, int(transposed))
+        handle = self.handle                                         # raises once the graph is destroyed
+        cache = self.__dict__.setdefault("_levels", {})              # fixed for the life of the handle
+        if transposed not in cache:
+            cache[transposed] = _lib.load().rgcn_graph_num_levels(handle, int(transposed))
+        return cache[transposed]
+
+    def deferrable(self, transposed: bool, d: int) -> bool:
+        """may ``aggregate_deferred`` leave this direction's hub tails to the transform? (memoised)"""
+        handle = self.handle
+        cache = self.__dict__.setdefault("_deferrable", {})
+        key = (bool(transposed), int(d))
+        if key not in cache:
+            cache[key] = bool(_lib.load().rgcn_aggregate_deferrable(handle, int(transposed), int(d)))
+        return cache[key]
 
     def weight_bound(self, transposed: bool) -> float:
         """``|aggregate(x) row| <= weight_bound * max |x|``: 1 for the mean structure, the largest
@@ -701,6 +726,9 @@ GEMM_EVENTS = None
 class _GemmBracket:
     """HIP events around one transform call on the launch stream, only while bench.py collects them"""
 
+    def __new__(cls, *info):
+        return _NO_GUARD if GEMM_EVENTS is None else super().__new__(cls)   # nothing to construct outside bench.py
+
     def __init__(self, kind: str, m: int, k: int, n: int, precision: str):
         self.info = (kind, m, k, n, precision)
 
@@ -812,7 +840,7 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
 
 def fused_bwd_supported(num_relations: int, d_in: int, d_out: int) -> bool:
     """does the one-kernel input gradient cover this layer shape (in split precision)?"""
-    return GEMM_PRECISION != "fp32" and bool(_lib.load().rgcn_layer_bwd_input_fused_supported(num_relations, d_in, d_out))
+    return GEMM_PRECISION != "fp32" and bool(_query("rgcn_layer_bwd_input_fused_supported", int(num_relations), int(d_in), int(d_out)))
 
 
 FUSED_EVENTS = None      # bench / probes: list that receives (kind, rows, relations, inline edges, pre-aggregated rows,
@@ -936,7 +964,7 @@ def aggregate_deferred(graph: BucketedGraph, x: torch.Tensor, transposed: bool =
     lib = _lib.load()
     d = x.size(1) if x.dim() == 2 else 0
     deferrable = (x.dtype == torch.float32 and GATHER_EVENTS is None and graph.num_levels(transposed) == 2
-                  and bool(lib.rgcn_aggregate_deferrable(graph.handle, int(transposed), d)))
+                  and graph.deferrable(transposed, d))
     if not deferrable:
         return aggregate(graph, x, transposed, tail=tail), None
     _need_gpu("x", x, torch.float32)
@@ -1039,7 +1067,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
             raise ValueError("packed does not belong to these weights")
         with _on(x.device):
             out = given_out if given_out is not None else torch.empty(n, d_out, dtype=torch.float32, device=x.device)
-            nbytes = lib.rgcn_transform_split_workspace_bytes(r, d_in, d_out)
+            nbytes = _query("rgcn_transform_split_workspace_bytes", r, d_in, d_out)
             ws = _workspace(nbytes, x.device)
             with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "split" if split == 1 else "half"):
                 rc = lib.rgcn_transform_fwd_split(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root),
@@ -1108,7 +1136,7 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
             raise ValueError("packed does not belong to these weights")
         with _on(g.device):
             gx = torch.empty(n, d_in, dtype=torch.float32, device=g.device)
-            nbytes = lib.rgcn_transform_split_workspace_bytes(r, d_in, d_out)
+            nbytes = _query("rgcn_transform_split_workspace_bytes", r, d_in, d_out)
             ws = _workspace(nbytes, g.device)
             with _GemmBracket("bwd_input", n, (r + (root is not None)) * d_out, d_in, "split" if split == 1 else "half"):
                 rc = lib.rgcn_transform_bwd_input_split(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root),
@@ -1181,7 +1209,7 @@ def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, 
             a1, a2, a3 = amax if amax is not None else (None, None, None)
             for nm, t in (("agg_amax", a1), ("x_amax", a2), ("g_amax", a3)):
                 _check_amax(nm, t, x.device)
-            nbytes = lib.rgcn_transform_bwd_params_split_workspace_bytes(n, r, d_in, d_out)
+            nbytes = _query("rgcn_transform_bwd_params_split_workspace_bytes", n, r, d_in, d_out)
             ws = _workspace(nbytes, x.device)
             job = _lib.SlabJob()
             with _GemmBracket("bwd_params", (r + want_root) * d_in, n, d_out, "split" if split == 1 else "half"):
