@@ -858,7 +858,7 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
                     const uint32_t* tile_mask, int kseg, const float* a1_amax, float a1_mul, const float* a2_amax,
                     float* c_amax, float* scan_slots, bool half, hipStream_t stream, const hub_fin* hubs = nullptr) {
   const hub_fin fin = hubs ? *hubs : hub_fin{};
-  if (fin.ptr && (nt_rows() != 64 || (fin.d != 64 && fin.d != 128 && fin.d != 256))) return RGCN_ERR_UNSUPPORTED;
+  if (fin.ptr && fin.d != 64 && fin.d != 128 && fin.d != 256) return RGCN_ERR_UNSUPPORTED;
   if (fin.ptr && (!a1_amax || fin.d != kseg)) return RGCN_ERR_ARG;   // an unfinished A1 cannot be scanned for its maximum
   const int K = K1 + K2;
   if (K1 % BK || K2 % BK || K <= 0) return RGCN_ERR_UNSUPPORTED;
@@ -890,7 +890,7 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
     if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 1, EPI_RELU);
     else if (epi == EPI_MASK) RGCN_NT_SPLIT(2, 1, EPI_MASK);
     else RGCN_NT_SPLIT(2, 1, EPI_NONE);
-  } else if (nt_rows() == 64) {
+  } else if (nt_rows() == 64 || fin.ptr) {                      // (the 64-row kernel is the one that finishes hub rows)
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 128));
     if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 2, EPI_RELU);
     else if (epi == EPI_MASK) RGCN_NT_SPLIT(2, 2, EPI_MASK);
