@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 15
+#define RGCN_ABI_VERSION 16
 
 enum {
   RGCN_OK = 0,
@@ -317,7 +317,12 @@ int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const floa
                                    const float* gagg_amax, float gagg_amax_mul, const float* g_amax, int half,
                                    float* grad_x, float* grad_x_amax, void* workspace, size_t workspace_bytes,
                                    void* stream, const rgcn_graph* hub_graph, int hub_transposed,
-                                   float* hub_partial);
+                                   float* hub_partial, float out_scale);
+/* out_scale (> 0; 1 for none): grad_x is additionally multiplied by it in the epilogue (one rounding, before the
+ * ReLU mask and before grad_x_amax is taken).  The two-layer encoder passes 1 / (1 - p) of the dropout between its
+ * layers (src/models/rgcn.py:125) here: the dropped activations relu_mask = relu(z) * m / (1 - p) are positive
+ * exactly where a unit is active AND kept, so mask and factor together are autograd of dropout(relu(z)) - without
+ * rescaling (and re-splitting) the layer's weights every step. */
 /* Transform-first half of the input gradient (layers with d_out >= 2 d_in): T[N, (R + 1) * d_in] =
  * g * [W_0^T | ... | W_{R-1}^T | root^T] from the split weights' natural-order image (no concatenation, no second
  * split); grad_x is then rgcn_aggregate over the merged transposed structure of T viewed [N * (R + 1), d_in].
@@ -381,7 +386,8 @@ int rgcn_layer_bwd_input_fused(const int32_t* rowptr_t, const int32_t* col_t, co
                                const uint32_t* tile_mask_t, int64_t num_nodes, int64_t num_relations,
                                const float* hub_agg, const float* g, const void* packed, int has_root,
                                const float* relu_mask, int64_t d_in, int64_t d_out, const float* g_amax,
-                               float gagg_amax_mul, float* grad_x, float* grad_x_amax, void* stream);
+                               float gagg_amax_mul, float* grad_x, float* grad_x_amax, void* stream,
+                               float out_scale /* as rgcn_transform_bwd_input_split */);
 
 /* ------------------------------------------------------------------------------------
  * DistMult head (rows C1 + C2; rgcn.py:325-326 row gathers + rgcn.py:207-211):

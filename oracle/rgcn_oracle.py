@@ -391,3 +391,99 @@ def encoder_explicit_f64(emb, conv1: dict, conv2: dict, edge_index, edge_type, c
     for name, gd in (("conv1", g1), ("conv2", g2)):
         grads.update({f"{name}.{k}": v for k, v in gd.items() if v is not None})
     return {"out": out, "h": h, "grads": grads}
+
+
+# --------------------------------------------------------------------------
+# restatement #3 on a SAMPLE of rows (graphs too large to evaluate whole on the CPU: BASELINE configs[3])
+# --------------------------------------------------------------------------
+def encoder_rows_f64(emb, conv1: dict, conv2: dict, edge_index, edge_type, cot, out_rows, grad_rows,
+                     relu_mask_fn):
+    """``encoder_explicit_f64`` restricted to the neighbourhoods of a few rows: the same formulas
+    (rgcn.py:117-130 forward; rows A3-A7 of SURVEY section 8a), float64, evaluated only where the
+    requested rows depend on them.
+
+    ``out_rows`` (LongTensor): rows of ``out = conv2(relu(conv1(emb)))`` wanted - needs ``h`` on their
+    in-neighbours, i.e. every in-edge of ``out_rows`` and of those neighbours.
+    ``grad_rows``: rows of ``d <out, cot> / d emb`` wanted - needs ``gz`` on their out-neighbours,
+    i.e. every out-edge of ``grad_rows`` and of those neighbours; the mean divisors are the GLOBAL
+    in-degree counts (integer work over the whole edge list).
+    ``relu_mask_fn(nodes) -> bool [len(nodes), hidden]``: the ReLU decisions of those rows for the
+    backward (the device's ``h > 0``, as in the full-size tests: a pre-activation within rounding of
+    zero must not switch a unit's gradient on one side only).
+
+    -> dict(out=[len(out_rows), d_out], grad_emb=[len(grad_rows), d_in], h_rows=(nodes, h values))"""
+    f64 = torch.float64
+    n = emb.size(0)
+    r = conv1["weight"].size(0)
+    src, dst = edge_index[0], edge_index[1]
+    cnt = torch.bincount(dst * r + edge_type, minlength=n * r).clamp(min=1).to(f64)      # cnt[dst * R + rel]
+
+    def member(nodes):
+        lut = torch.zeros(n, dtype=torch.bool)
+        lut[nodes] = True
+        return lut
+
+    def local(nodes):
+        lut = torch.full((n,), -1, dtype=torch.int64)
+        lut[nodes] = torch.arange(nodes.numel())
+        return lut
+
+    def wcat(c):
+        w = c["weight"].to(f64)
+        parts = [w.reshape(-1, w.size(-1))]
+        if c.get("root") is not None:
+            parts.append(c["root"].to(f64))
+        return w, torch.cat(parts)
+
+    def layer_rows(x_of, rows, c):
+        """rows of one layer's pre-activation: x_of(nodes) -> float64 rows of the layer input"""
+        m = member(rows)[dst]
+        e_src, e_dst, e_rel = src[m], dst[m], edge_type[m]
+        need = torch.unique(torch.cat([rows, e_src]))
+        xin = x_of(need)
+        lx = local(need)
+        lr = local(rows)
+        d = xin.size(1)
+        key = lr[e_dst] * r + e_rel
+        s = torch.zeros(rows.numel() * r, d, dtype=f64).index_add_(0, key, xin[lx[e_src]])
+        agg = (s / cnt[(rows.view(-1, 1) * r + torch.arange(r)).view(-1)].view(-1, 1)).view(rows.numel(), r * d)
+        a = torch.cat([agg, xin[lx[rows]]], 1) if c.get("root") is not None else agg
+        z = a @ wcat(c)[1]
+        if c.get("bias") is not None:
+            z = z + c["bias"].to(f64)
+        return z
+
+    out = {}
+    if out_rows is not None and out_rows.numel():
+        rows0 = torch.unique(out_rows)
+        s1 = torch.unique(torch.cat([rows0, src[member(rows0)[dst]]]))
+        h1 = layer_rows(lambda nodes: emb[nodes].to(f64), s1, conv1).clamp(min=0)
+        l1 = local(s1)
+        z2 = layer_rows(lambda nodes: h1[l1[nodes]], rows0, conv2)
+        out["out"] = z2[local(rows0)[out_rows]]
+        out["h_rows"] = (s1, h1)
+
+    def input_grad_rows(g_of, rows, c):
+        """rows of one layer's input gradient from g_of(nodes) -> float64 rows of its output gradient"""
+        w, _ = wcat(c)
+        m = member(rows)[src]
+        e_src, e_dst, e_rel = src[m], dst[m], edge_type[m]
+        need = torch.unique(torch.cat([rows, e_dst]))
+        gin = g_of(need)
+        lg, lr = local(need), local(rows)
+        d = gin.size(1)
+        contrib = gin[lg[e_dst]] / cnt[e_dst * r + e_rel].view(-1, 1)
+        gagg = torch.zeros(rows.numel() * r, d, dtype=f64).index_add_(0, lr[e_src] * r + e_rel, contrib)
+        gx = gagg.view(rows.numel(), r * d) @ w.transpose(1, 2).reshape(r * d, -1)
+        if c.get("root") is not None:
+            gx = gx + gin[lg[rows]] @ c["root"].to(f64).t()
+        return gx
+
+    if grad_rows is not None and grad_rows.numel():
+        k0 = torch.unique(grad_rows)
+        t1 = torch.unique(torch.cat([k0, dst[member(k0)[src]]]))
+        gz = input_grad_rows(lambda nodes: cot[nodes].to(f64), t1, conv2) * relu_mask_fn(t1).to(f64)
+        lt = local(t1)
+        gx = input_grad_rows(lambda nodes: gz[lt[nodes]], k0, conv1)
+        out["grad_emb"] = gx[local(k0)[grad_rows]]
+    return out

@@ -242,8 +242,9 @@ class _Encoder2Function(torch.autograd.Function):
     With ``p > 0`` the mask is drawn by torch's own dropout kernel from torch's RNG stream,
     exactly where ``rgcn.py:125`` draws it.  Its backward costs nothing extra: the dropped
     activations ``hd = relu(z) * m / (1-p)`` are positive exactly where the unit is both active
-    and kept, so ``hd`` is the epilogue mask, and the factor ``1/(1-p)`` is folded into the
-    (small) weight operand of that GEMM."""
+    and kept, so ``hd`` is the epilogue mask, and the factor ``1/(1-p)`` is one more scalar of that
+    GEMM's epilogue (``out_scale``): the step's split weight images and the hub deferral serve
+    the dropout case unchanged."""
 
     @staticmethod
     def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph, gather_dtype=None, p: float = 0.0,
@@ -288,20 +289,20 @@ class _Encoder2Function(torch.autograd.Function):
         prec = ctx.bwd_precision
         red2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2, graph=graph,
                                         defer=True, amax=(h_amax, h_amax, g_amax), precision=prec)
-        if ctx.p > 0:
-            scale = 1.0 / (1.0 - ctx.p)
-            w2, root2 = w2 * scale, (root2 * scale if root2 is not None else None)
-            pk2 = None                                                      # split for the unscaled weights
+        # dropout backward: the factor 1 / (1 - p) goes into the input-gradient epilogue as a scalar (the mask is h itself,
+        # positive exactly where a unit is active and kept) - the weights keep their split images and the hub deferral
+        scale = 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0
         if _fused_backward(graph, g, r, w2.size(1), w2.size(2), g_amax, pk2, prec):
             gz = ops.layer_bwd_input_fused(graph, g, pk2, h, g_amax, amax_out=gz_amax, inline_limit=_EVAL_INLINE_LIMIT,
-                                           tail=red2)
+                                           tail=red2, out_scale=scale)
         else:
             if _defer_hubs(False, pk2, g_amax, w2.size(2), w2.size(1)) and not graph.bipartite:
                 gagg2, hubs2 = ops.aggregate_deferred(graph, g, transposed=True, tail=red2)
             else:
                 gagg2, hubs2 = ops.aggregate(graph, g, transposed=True, tail=red2), None
             gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph, amax=(g_amax, g_amax),
-                                         amax_mul=wb, amax_out=gz_amax, packed=pk2, precision=prec, hubs=hubs2)   # d loss / d (pre-ReLU of conv1)
+                                         amax_mul=wb, amax_out=gz_amax, packed=pk2, precision=prec, hubs=hubs2,
+                                         out_scale=scale)   # d loss / d (pre-ReLU of conv1)
         red1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1, graph=graph,
                                         defer=True, amax=(x_amax, x_amax, gz_amax), precision=prec)
         gx = None

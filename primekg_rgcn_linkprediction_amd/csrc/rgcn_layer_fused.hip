@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kThreads) void k_layer_fused(
     const __half* __restrict__ Fl, const float* __restrict__ b_inv_scale, const float* __restrict__ x_amax,
     float a1_mul, const float* __restrict__ bias, const float* __restrict__ mask, float* __restrict__ out,
     float* __restrict__ agg, int N, int R, int chunks, const uint32_t* __restrict__ tile_mask,
-    unsigned* __restrict__ amax_out) {
+    unsigned* __restrict__ amax_out, float out_scale) {
   constexpr int D_IN = 4 * G, KS = D_IN / 16, NG = kThreads / G, RPG = kRows / NG;
   constexpr int ROWB = D_IN * 2 + 16;            // bytes of one A row per image: + 16 keeps the fragment reads conflict-free
   constexpr int D_OUT = 32 * NT;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void k_layer_fused(
   }
 
   // C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const float ia = pow2f(chunks > R ? -ea2 : -ea1), ib = b_inv_scale[0];
+  const float ia = pow2f(chunks > R ? -ea2 : -ea1) * out_scale, ib = b_inv_scale[0];   // as k_gemm_nt_split's epilogue
   float cmax = 0.f;
   if (has_cols) {
     float mk[TNW][16];
@@ -333,13 +333,14 @@ struct fused_args {
   int N, R, chunks;
   const uint32_t* tile_mask;
   unsigned* amax_out;
+  float out_scale;
 };
 
 template <int G, int TNW, int NT, int EPI, bool WIDE, bool STORE, bool WEIGHTED>
 void launch_one(const fused_args& a, hipStream_t stream) {
   k_layer_fused<G, TNW, NT, EPI, WIDE, STORE, WEIGHTED><<<(unsigned)ceil_div64(a.N, kRows), kThreads, 0, stream>>>(
       a.x, a.rowptr, a.col, a.wts, a.hub_agg, a.Fh, a.Fl, a.b_inv, a.x_amax, a.a1_mul, a.bias, a.mask, a.out, a.agg, a.N,
-      a.R, a.chunks, a.tile_mask, a.amax_out);
+      a.R, a.chunks, a.tile_mask, a.amax_out, a.out_scale);
 }
 
 // forward (mean): EPI in {none, ReLU}, optional STORE; input gradient (weighted): EPI in {none, mask}
@@ -396,7 +397,7 @@ int rgcn_layer_fwd_fused(const int32_t* rowptr, const int32_t* col, const uint32
   a.Fh = v.Fh_f; a.Fl = v.Fl_f; a.b_inv = v.inv_scale; a.x_amax = x_amax; a.a1_mul = 1.f;
   a.bias = bias; a.out = out; a.agg = agg;
   a.N = (int)N; a.R = (int)R; a.chunks = (int)R + (has_root ? 1 : 0);
-  a.tile_mask = tile_mask; a.amax_out = reinterpret_cast<unsigned*>(out_amax);
+  a.tile_mask = tile_mask; a.amax_out = reinterpret_cast<unsigned*>(out_amax); a.out_scale = 1.f;
   return launch_fused<false>(a, d_in, d_out, relu ? 1 : 0, (hipStream_t)stream_);
 }
 
@@ -404,8 +405,9 @@ int rgcn_layer_bwd_input_fused(const int32_t* rowptr_t, const int32_t* col_t, co
                                const uint32_t* tile_mask_t, int64_t N, int64_t R, const float* hub_agg, const float* g,
                                const void* packed, int has_root, const float* relu_mask, int64_t d_in, int64_t d_out,
                                const float* g_amax, float gagg_amax_mul, float* grad_x, float* grad_x_amax,
-                               void* stream_) {
-  if (N < 0 || !rowptr_t || !g || !packed || !g_amax || !grad_x || !(gagg_amax_mul > 0.f)) return RGCN_ERR_ARG;
+                               void* stream_, float out_scale) {
+  if (N < 0 || !rowptr_t || !g || !packed || !g_amax || !grad_x || !(gagg_amax_mul > 0.f) || !(out_scale > 0.f))
+    return RGCN_ERR_ARG;
   if (!supported(R, d_out, d_in, true)) return RGCN_ERR_UNSUPPORTED;
   if (N == 0) return RGCN_OK;
   if (N > INT32_MAX / 2) return RGCN_ERR_UNSUPPORTED;
@@ -415,7 +417,7 @@ int rgcn_layer_bwd_input_fused(const int32_t* rowptr_t, const int32_t* col_t, co
   a.Fh = v.Fh_b; a.Fl = v.Fl_b; a.b_inv = v.inv_scale; a.x_amax = g_amax; a.a1_mul = gagg_amax_mul;
   a.mask = relu_mask; a.out = grad_x;
   a.N = (int)N; a.R = (int)R; a.chunks = (int)R + (has_root ? 1 : 0);
-  a.tile_mask = tile_mask_t; a.amax_out = reinterpret_cast<unsigned*>(grad_x_amax);
+  a.tile_mask = tile_mask_t; a.amax_out = reinterpret_cast<unsigned*>(grad_x_amax); a.out_scale = out_scale;
   return launch_fused<true>(a, d_out, d_in, relu_mask ? 2 : 0, (hipStream_t)stream_);
 }
 

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
                                                             const float* __restrict__ mask, float* __restrict__ C,
                                                             int M, int N, const uint32_t* __restrict__ tile_mask,
                                                             int kseg, unsigned* __restrict__ amax_out,
-                                                            const hub_fin fin) {
+                                                            const hub_fin fin, float out_scale) {
   constexpr int BM = 32 * WM, BN = 64 * TN, NBUF = WM == 2 ? 3 : 4, D = NBUF - 1;   // D k-tiles in flight
   constexpr int PARTS = LO ? 2 : 1;              // B images staged: hi (and lo)
   constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + PARTS * B_BYTES;
@@ -448,7 +448,9 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
   }
 
   // C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  const float ia = pow2f(K2 > 0 ? -ea2 : -ea1), ib = b_inv_scale[0];   // two exact power-of-two factors
+  // two exact power-of-two factors and the caller's output factor (1, or 1 / (1 - p) of a dropout whose backward
+  // rides in this epilogue): ONE rounding of acc * (ia * out_scale), ib exact
+  const float ia = pow2f(K2 > 0 ? -ea2 : -ea1) * out_scale, ib = b_inv_scale[0];
   float cmax = 0.f;
   if (m0 + BM <= M && n0 + BN <= N) {            // interior tile: straight-line stores (see k_gemm_nt_dma)
     float bv[TN];
@@ -856,7 +858,8 @@ size_t nt_workspace_bytes(int64_t R, int64_t d_in, int64_t d_out) {
 int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __half* Bh, const __half* Bl,
                     const float* b_inv, const float* bias, const float* mask, int epi, float* C, int M, int N,
                     const uint32_t* tile_mask, int kseg, const float* a1_amax, float a1_mul, const float* a2_amax,
-                    float* c_amax, float* scan_slots, bool half, hipStream_t stream, const hub_fin* hubs = nullptr) {
+                    float* c_amax, float* scan_slots, bool half, hipStream_t stream, const hub_fin* hubs = nullptr,
+                    float out_scale = 1.f) {
   const hub_fin fin = hubs ? *hubs : hub_fin{};
   if (fin.ptr && fin.d != 64 && fin.d != 128 && fin.d != 256) return RGCN_ERR_UNSUPPORTED;
   if (fin.ptr && (!a1_amax || fin.d != kseg)) return RGCN_ERR_ARG;   // an unfinished A1 cannot be scanned for its maximum
@@ -879,7 +882,7 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
 #define RGCN_NT_LAUNCH(WM_, TN_, EPI_, LO_)                                                                          \
   k_gemm_nt_split<WM_, TN_, EPI_, LO_><<<grid, 128 * WM_, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, \
                                                                         bias, mask, C, M, N, tile_mask, kseg, amax_out, \
-                                                                        fin)
+                                                                        fin, out_scale)
 #define RGCN_NT_SPLIT(WM_, TN_, EPI_)        \
   do {                                       \
     if (half) RGCN_NT_LAUNCH(WM_, TN_, EPI_, false); \
@@ -1084,8 +1087,9 @@ int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const floa
                                    int64_t R, int64_t d_in, int64_t d_out, const float* gagg_amax,
                                    float gagg_amax_mul, const float* g_amax, int half, float* grad_x,
                                    float* grad_x_amax, void* workspace, size_t workspace_bytes, void* stream_,
-                                   const rgcn_graph* hub_graph, int hub_transposed, float* hub_partial) {
-  if (bad_dims(N, R, d_in, d_out) || !grad_x) return RGCN_ERR_ARG;
+                                   const rgcn_graph* hub_graph, int hub_transposed, float* hub_partial,
+                                   float out_scale) {
+  if (bad_dims(N, R, d_in, d_out) || !grad_x || !(out_scale > 0.f)) return RGCN_ERR_ARG;
   if (N == 0) return RGCN_OK;
   if (!gagg || !g || !weight) return RGCN_ERR_ARG;
   if (d_out % BK) return RGCN_ERR_UNSUPPORTED;
@@ -1105,7 +1109,7 @@ int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const floa
   if (hrc < 0) return hrc;
   return launch_nt_split(gagg, K1, g, K2, v.Bh_b, v.Bl_b, v.inv_scale, nullptr, relu_mask,
                          relu_mask ? EPI_MASK : EPI_NONE, grad_x, (int)N, (int)d_in, tile_mask, (int)d_out, gagg_amax,
-                         gagg_amax_mul, g_amax, grad_x_amax, scan, half != 0, stream, hrc ? &fin : nullptr);
+                         gagg_amax_mul, g_amax, grad_x_amax, scan, half != 0, stream, hrc ? &fin : nullptr, out_scale);
 }
 
 int rgcn_transform_first_split(const float* g, const void* packed, int has_root, int64_t N, int64_t R, int64_t d_in,

@@ -903,8 +903,8 @@ def layer_fwd_fused(graph: BucketedGraph, x: torch.Tensor, packed: SplitWeights,
 def layer_bwd_input_fused(graph: BucketedGraph, g: torch.Tensor, packed: SplitWeights,
                           relu_mask: Optional[torch.Tensor], amax: torch.Tensor,
                           amax_out: Optional[torch.Tensor] = None, inline_limit: int = 16,
-                          tail: Optional["PendingParamGrads"] = None) -> torch.Tensor:
-    """``grad_x = [transposed-aggregate(g) | g] @ [W_r^T ; root^T]`` (``* (relu_mask > 0)``) in ONE kernel
+                          tail: Optional["PendingParamGrads"] = None, out_scale: float = 1.0) -> torch.Tensor:
+    """``grad_x = out_scale * [transposed-aggregate(g) | g] @ [W_r^T ; root^T]`` (``* (relu_mask > 0)``) in ONE kernel
     (``rgcn_layer_bwd_input_fused``): the weighted sums over out-edges are formed in LDS, no ``[N, R * d_out]``
     tensor in HBM.  Bit-identical to ``aggregate(transposed=True)`` -> ``transform_bwd_input(precision="split")``.
     ``amax``: amax buffer of ``g``; ``tail``: a pending parameter-gradient reduction that rides in the gather of
@@ -937,7 +937,8 @@ def layer_bwd_input_fused(graph: BucketedGraph, g: torch.Tensor, packed: SplitWe
         rc = lib.rgcn_layer_bwd_input_fused(_ptr(plan.rowptr), _ptr(plan.col), _ptr(plan.weight), tile_mask,
                                             graph.num_nodes, r, _ptr(hub_agg), _ptr(g), _ptr(packed.buf),
                                             int(packed.has_root), _ptr(relu_mask), d_in, d_out, _ptr(amax),
-                                            float(graph.weight_bound(True)), _ptr(gx), _ptr(amax_out), _stream())
+                                            float(graph.weight_bound(True)), _ptr(gx), _ptr(amax_out), _stream(),
+                                            float(out_scale))
         if FUSED_EVENTS is not None:
             end.record()
             FUSED_EVENTS.append(("bwd_input+mask" if relu_mask is not None else "bwd_input", graph.num_nodes,
@@ -1106,10 +1107,13 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
 def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
                         graph: Optional[BucketedGraph] = None, amax=None, amax_out: Optional[torch.Tensor] = None,
                         precision: Optional[str] = None, packed: Optional[SplitWeights] = None,
-                        amax_mul: float = 1.0, hubs: Optional[DeferredHubs] = None) -> torch.Tensor:
-    """``grad_x = sum_r gagg[:, r] @ weight[r]^T + g @ root^T``; with ``relu_mask`` (the
+                        amax_mul: float = 1.0, hubs: Optional[DeferredHubs] = None,
+                        out_scale: float = 1.0) -> torch.Tensor:
+    """``grad_x = out_scale * (sum_r gagg[:, r] @ weight[r]^T + g @ root^T)``; with ``relu_mask`` (the
     layer's input, when that input is the output of a fused-ReLU layer) the result is
-    additionally multiplied by ``relu_mask > 0``."""
+    additionally multiplied by ``relu_mask > 0``.  ``out_scale`` (the ``1 / (1 - p)`` of a dropout whose
+    backward rides in this call) is applied in the split kernels' epilogue; the fp32 kernels get scaled
+    weights instead."""
     _need_gpu("g", g, torch.float32)
     _need_gpu("gagg", gagg, torch.float32)
     _need_gpu("weight", weight, torch.float32)
@@ -1144,11 +1148,14 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
                                                         _ptr(relu_mask), _mask_for(graph, True, n, r), n, r, d_in,
                                                         d_out, _ptr(a1), float(amax_mul), _ptr(a2), int(split == 2),
                                                         _ptr(gx), _ptr(amax_out), _ptr(ws), nbytes, _stream(),
-                                                        *_hub_args(hubs, n, r))
+                                                        *_hub_args(hubs, n, r), float(out_scale))
         _lib.check(rc, "rgcn_transform_bwd_input_split")
         return gx
     if hubs is not None:
         raise ValueError("deferred hub tails need the split-precision transform (finish them with aggregate instead)")
+    if out_scale != 1.0:                                   # the fp32 kernels have no output factor: scale the (small) weights
+        weight = weight * out_scale
+        root = root * out_scale if root is not None else None
     with _on(g.device):
         gx = torch.empty(n, d_in, dtype=torch.float32, device=g.device)
         with _GemmBracket("bwd_input", n, (r + (root is not None)) * d_out, d_in, "fp32"):

@@ -257,3 +257,93 @@ def test_load_model_uses_the_restricted_unpickler(tmp_path):
         E.load_model(str(tmp_path / "bad.pt"), torch.device("cpu"))
     loaded2, _ = E.load_model(str(tmp_path / "bad.pt"), torch.device("cpu"), trust_pickle=True)
     assert torch.equal(loaded2.state_dict()["encoder.conv1.weight"], model.state_dict()["encoder.conv1.weight"])
+
+
+# ---------------------------------------------------------------------------------- build-time checks (no GPU)
+def _csrc():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return os.path.join(root, "primekg_rgcn_linkprediction_amd", "csrc")
+
+
+def test_no_kernel_reads_an_lds_fragment_before_its_wait():
+    """The transform / fused-layer kernels cover inline-asm ``ds_read``s with hand-counted ``s_waitcnt lgkmcnt``;
+    the compiler sees neither and once hoisted a copy of a fragment register above its wait (commit 7606cc0: wrong
+    bits one run in five).  ``tools/check_waitcnt.py`` walks the gfx950 disassembly of EVERY kernel in the built
+    objects (control flow followed, LDS returns in order, scalar loads out of order) and must find no instruction
+    touching a register whose read is still uncovered - this is that bug class caught at build time."""
+    import glob
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(_csrc()), "..", "tools"))
+    import check_waitcnt as W
+    objs = sorted(glob.glob(os.path.join(_csrc(), "build", "*.o")))
+    assert len(objs) >= 9, "build the library first (conftest does)"
+    kernels = reads = 0
+    for path in objs:
+        found = W.check_object(path)
+        assert not found, {k: v[:3] for k, v in found.items()}
+        k, r = W.stats(path)
+        kernels, reads = kernels + k, reads + r
+    assert kernels > 200 and reads > 3000                      # the walk really saw the kernels (incl. rocPRIM's)
+
+
+def test_waitcnt_checker_catches_the_bug_class():
+    """the checker on hand-made listings: the 7606cc0 shape (a copy of a fragment register above the covering
+    wait), an uncovered use after a counted wait that is one too large, a hazard carried round a loop, and
+    scalar loads, which make a non-zero count prove nothing; and the correct forms of each, which pass."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(_csrc()), "..", "tools"))
+    import check_waitcnt as W
+
+    def listing(body):
+        lines = ["0000000000001000 <k>:"]
+        for i, inst in enumerate(body):
+            lines.append(f"\t{inst:<58} // {0x1000 + 4 * i:012X}: 00000000")
+        return "\n".join(lines) + "\n"
+
+    def violations(body):
+        return W.check_function(W.parse_disassembly(listing(body))["k"])
+
+    reads = ["ds_read_b128 v[2:5], v1", "ds_read_b128 v[6:9], v1 offset:256", "ds_read_b128 v[10:13], v1 offset:512"]
+    ok = reads + ["s_waitcnt lgkmcnt(2)", "v_mov_b32_e32 v20, v2", "s_waitcnt lgkmcnt(0)",
+                  "v_mfma_f32_32x32x16_f16 a[0:15], v[6:9], v[10:13], a[0:15]", "s_endpgm"]
+    assert violations(ok) == []
+    hoisted = reads + ["v_mov_b32_e32 v20, v6", "s_waitcnt lgkmcnt(0)", "s_endpgm"]          # the copy sits above the wait
+    assert len(violations(hoisted)) == 1 and "v6" in violations(hoisted)[0]
+    short = reads + ["s_waitcnt lgkmcnt(2)", "v_add_f32_e32 v21, v6, v6", "s_waitcnt lgkmcnt(0)", "s_endpgm"]
+    assert len(violations(short)) == 1                                                        # lgkmcnt(2) covers the first read only
+    # loop: the read issued at the bottom is used at the top of the next trip; `s_cbranch_scc1 <k+0x4>` jumps back
+    loop = ["s_waitcnt lgkmcnt(0)", "v_add_f32_e32 v30, v2, v2", "ds_read_b128 v[2:5], v1",
+            "s_cbranch_scc1 65533                                   // 00000000100C: 00000000 <k+0x4>", "s_endpgm"]
+    text = listing(loop[:3]) + f"\t{loop[3]}\n\ts_endpgm                                    // 000000001010: 00000000\n"
+    assert len(W.check_function(W.parse_disassembly(text)["k"])) == 1
+    fixed = listing(["v_add_f32_e32 v30, v30, v30", "s_waitcnt lgkmcnt(0)", "v_add_f32_e32 v30, v2, v2"]) \
+        + "\tds_read_b128 v[2:5], v1                                    // 00000000100C: 00000000\n" \
+        + "\ts_cbranch_scc1 65532                                       // 000000001010: 00000000 <k+0x4>\n" \
+        + "\ts_endpgm                                                   // 000000001014: 00000000\n"
+    assert W.check_function(W.parse_disassembly(fixed)["k"]) == []
+    smem = ["ds_read_b32 v2, v1", "s_load_dword s4, s[0:1], 0x0", "ds_read_b32 v3, v1", "s_waitcnt lgkmcnt(1)",
+            "v_add_f32_e32 v9, v2, v2", "s_endpgm"]
+    assert len(violations(smem)) == 1                                                         # out-of-order scalar return
+    assert violations(smem[:3] + ["s_waitcnt lgkmcnt(0)"] + smem[4:]) == []
+
+
+def test_editing_any_header_rebuilds_the_objects_that_include_it(tmp_path):
+    """csrc/Makefile takes its header prerequisites from the compiler (-MMD): touching rgcn_hub_finish.h - the one
+    definition that makes k_reduce_partials and the transform prologue "the same bits" - must put exactly the two
+    objects that include it back on the build list (round 2's hand-written list had left it out)."""
+    import os
+    import subprocess
+    csrc = _csrc()
+    header = os.path.join(csrc, "rgcn_hub_finish.h")
+    st = os.stat(header)
+    try:
+        subprocess.run(["make", "-C", csrc, "-q"], check=False)
+        os.utime(header)                                          # "edited now"
+        plan = subprocess.run(["make", "-C", csrc, "-n"], check=True, capture_output=True, text=True).stdout
+    finally:
+        os.utime(header, (st.st_atime, st.st_mtime))
+    rebuilt = {w[len("build/"):-2] for line in plan.splitlines() if " -c " in line for w in line.split() if w.startswith("build/") and w.endswith(".o")}
+    assert rebuilt == {"rgcn_aggregate", "rgcn_transform_split"}, rebuilt

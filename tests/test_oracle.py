@@ -281,3 +281,30 @@ def test_explicit_f64_encoder_half_forward_is_the_rounded_operand_meaning():
     assert not torch.equal(a1["out"], b1["out"])                        # conv2 rounds h and its weights
     c = O.encoder_explicit_f64(emb, c1, c2, ei, et, cot, half_forward=True, half_backward=True)
     assert torch.equal(b["out"], c["out"]) and not torch.equal(b["grads"]["emb"], c["grads"]["emb"])
+
+
+@pytest.mark.parametrize("root", [True, False])
+def test_sampled_row_evaluation_equals_the_whole_graph_evaluation(root):
+    """``encoder_rows_f64`` (what the full-size configs[3] GPU test compares sampled rows with) against
+    ``encoder_explicit_f64`` on a graph small enough to evaluate whole: duplicate edges, isolated rows,
+    repeated sample rows, with and without root / bias."""
+    ei, et, n, r = synth.uniform_graph(400, 5000, 5, seed=21)
+    ei[:, 10:20] = ei[:, :10]                                      # duplicate columns count once each
+    et[10:20] = et[:10]
+    keep = (ei[1] != 7) & (ei[0] != 7)                             # node 7 isolated
+    ei, et = ei[:, keep], et[keep]
+    torch.manual_seed(21)
+    emb = torch.randn(n, 16)
+    c1 = {"weight": torch.randn(r, 16, 32) * 0.2, "root": torch.randn(16, 32) * 0.2 if root else None,
+          "bias": torch.randn(32) * 0.1 if root else None}
+    c2 = {"weight": torch.randn(r, 32, 24) * 0.2, "root": torch.randn(32, 24) * 0.2 if root else None,
+          "bias": torch.randn(24) * 0.1 if root else None}
+    cot = torch.randn(n, 24)
+    full = O.encoder_explicit_f64(emb, c1, c2, ei, et, cot)
+    rows = torch.tensor([3, 7, 77, 399, 3, 250, 0])
+    mask = full["h"] > 0
+    got = O.encoder_rows_f64(emb, c1, c2, ei, et, cot, rows, rows.flip(0), lambda nodes: mask[nodes])
+    assert (got["out"] - full["out"][rows]).abs().max().item() <= 1e-13
+    assert (got["grad_emb"] - full["grads"]["emb"][rows.flip(0)]).abs().max().item() <= 1e-13
+    nodes, h = got["h_rows"]
+    assert (h - full["h"][nodes]).abs().max().item() <= 1e-13

@@ -198,6 +198,22 @@ def test_fp16_gather_training_reaches_the_same_auc(tmp_path):
         ev = ModelEvaluator(trainer.model, te, full, dev)
         scores, labels = ev.compute_scores_and_labels()
         aucs.append(ev.compute_classification_metrics(scores, labels)["auc_roc"])
+        steps = -(-trainer.train_edge_index.size(1) // 1024)                         # one epoch, batch 1,024
+    # what this test computed, beside the parity error table (profiles/r03_parity_errors.json).  The reference's own
+    # AUC-ROC 0.978 is NOT reproducible here: data/processed/train_data.pt is absent from the reference mount, so the
+    # run is one epoch on the synthetic PrimeKG-shaped graph - a +-0.005 agreement test between the two arithmetics.
+    try:
+        import json, os
+        log_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r03.json")
+        os.makedirs(os.path.dirname(log_path), exist_ok=True)
+        log = json.load(open(log_path)) if os.path.exists(log_path) else {}
+        log["C5_auc_one_epoch_synthetic"] = {"auc_roc_fp32_run": float(aucs[0]), "auc_roc_fp16_run": float(aucs[1]),
+                                             "abs_difference": abs(float(aucs[0]) - float(aucs[1])),
+                                             "optimizer_steps": int(steps), "train_edge_columns": int(trainer.train_edge_index.size(1)),
+                                             "held_out_pairs_scored": int(labels.numel())}
+        json.dump(log, open(log_path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
     assert aucs[0] > 0.6 and abs(aucs[0] - aucs[1]) <= 0.005, aucs
 
 
