@@ -3,30 +3,33 @@
 synthetic graph (BASELINE.json metric; configs[1] = C2: 30,926 nodes / 849,456 edges /
 3 relations, 64 -> 128 -> 128, fp32 in / fp32 out).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4-1gpu]
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4]
 
 A step = one pass of the two-layer encoder over the whole graph, forward + backward
 (conv1 -> relu -> conv2, seeded cotangent; dropout p = 0; bucketing excluded - the graph is
 static and bucketed once, the one-time cost is reported in `bucket_ms`).
 value = L * E * K / t with L = 2 layers.  N > 1: node-partitioned across the ranks with an
 exchange per layer and direction (primekg_rgcn_linkprediction_amd/dist.py), one process
-per GPU, launched by torch.distributed.run.
+per GPU, launched by torch.distributed.run; `--workload c4` is BASELINE configs[3]
+(500k nodes / 20M edge columns / 16 relations) and runs at any N.
 
 Rank 0 prints ONE JSON line.  Beside the contract's fields it carries
-  roofline       the dominant gather kernel: algorithmic bytes / live HIP-event time against the HBM peak
-                 (the contract's figure; exceeds 1 at C2 because the 8-16 MB row table is L2/Infinity-Cache
-                 resident) AND the two figures that mean something there: compulsory HBM bytes / time
-                 against the HBM peak, and the achieved rate against the chip's measured L2-resident
-                 indexed-row ceiling (MI355X_MICROARCH.md, "Indexed rows: gather into LDS")
-  roofline_mfma  the time-dominant dense transform: flops / live HIP-event time against the fp32 matrix
-                 peak (the arithmetic the caller asked for) and, in split precision, the executed fp16
-                 MFMA flops (3 passes) against the fp16 matrix peak
-  cpu_baseline   (N = 1) the oracle's PyG-equivalent CPU path on this host, thread count swept
-The secondary workloads (`--workload c3`, `--workload c4-1gpu`: C4's 500k-node / 20M-edge / 16-relation
-graph on ONE GPU, where the 256 MB table is no longer cache resident) print the same line for their
-shape; the headline stays C2.
+  roofline         the gather instantiation with the most time per step: algorithmic bytes / live HIP-event time.
+                   While the gathered row table is cache resident (C2: 8-16 MB) the bound is the chip's L2-resident
+                   indexed-row rate (`bound: "l2"`, peak 16.8 TB/s, MI355X_MICROARCH.md "Indexed rows"): `frac` is
+                   against THAT and is <= 1; the ratio to the HBM peak (> 1 there) is kept as
+                   `algorithmic_over_hbm_peak`.  At C4's size the table exceeds the caches: `bound: "hbm"`, peak 8 TB/s.
+  dominant_kernel  the launch with the most time per step (a transform GEMM at C2), with BOTH its fractions: of the
+                   time its operand bytes need at the achievable streaming rate, and of the dense fp16 MFMA peak
+  roofline_mfma    the time-dominant dense transform against the fp32 matrix peak (the arithmetic asked for)
+  fp32_mfma_ms_per_step   (N = 1, headline) the same step with RGCN_GEMM_PRECISION=fp32 (exact fp32 MFMA products)
+  secondary        (headline) `c4_1gpu`: a short run of configs[3]'s graph on this GPU, where the gather IS HBM-bound
+                   (the >= 40 %-of-HBM-roofline clause of the north star, driver-timed); at N > 1: `c4`, the same
+                   graph node-partitioned over the N ranks
+  cpu_baseline     (N = 1) the oracle's PyG-equivalent CPU path on this host, thread count swept
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -38,21 +41,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_STREAM_GBS = 6300.0        # same guide: achievable streaming rate (float4 copy 6.29 TB/s)
 L2_GATHER_CEILING_GBS = (16800.0, 18800.0)   # same guide: rows gathered from the XCD's L2, chip-wide
 MALL_GATHER_GBS = 8600.0       # same guide: 38 MB table, uniformly random rows (Infinity Cache)
 F32_MATRIX_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32 (= fp32 vector rate)
 F16_MATRIX_PEAK_TF = 2500.0    # dense fp16 MFMA
 LAYERS = 2
-PMC_FILES = ("r02_pmc_counters.json", "r01_pmc_counters.json")
+PMC_FILES = ("r03_pmc_counters.json", "r02_pmc_counters.json", "r01_pmc_counters.json")
+METRIC = "edges/sec per RGCN layer (fwd+bwd), PrimeKG 30.9k nodes/849k edges/3 rels"
 
 WORKLOADS = {
     "c2": {"dims": (64, 128, 128), "bases": None, "graph": "primekg",
            "name": "C2: PrimeKG-shaped synthetic graph"},
     "c3": {"dims": (64, 256, 256), "bases": 4, "graph": "primekg",
            "name": "C3 (secondary): PrimeKG-shaped synthetic graph, num_bases=4"},
-    "c4-1gpu": {"dims": (64, 128, 128), "bases": None, "graph": "uniform", "nodes": 500_000, "edges": 20_000_000,
-                "relations": 16, "name": "C4 on ONE GPU (secondary): uniform synthetic graph"},
+    "c4": {"dims": (64, 128, 128), "bases": None, "graph": "uniform", "nodes": 500_000, "edges": 20_000_000,
+           "relations": 16, "name": "C4 (BASELINE configs[3]): uniform synthetic graph"},
 }
+WORKLOADS["c4-1gpu"] = WORKLOADS["c4"]          # round 2's name for the N = 1 run of the same graph
 
 
 def parse_args():
@@ -67,6 +73,8 @@ def parse_args():
     ap.add_argument("--graph", action="store_true", help="time the HIP graph replay even if eager calibrates faster")
     ap.add_argument("--no-replica", action="store_true",
                     help="N > 1: skip the batch-replica leg reported beside the node-partitioned number")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline run: skip the fp32-MFMA pass and the short C4 leg (profiling passes use this)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--fp16-gather", action="store_true",
                     help="BASELINE configs[4]: forward gathers read an fp16 copy of the feature table "
@@ -157,6 +165,313 @@ def cpu_baseline(ei, et, n, r, dims, bases, seconds):
                       f"at {best} threads, the fastest of {settings} on this {os.cpu_count()}-cpu host"}
 
 
+# ------------------------------------------------------------------------------------------------
+# building a workload and timing it
+# ------------------------------------------------------------------------------------------------
+class Run:
+    """one workload on this process's GPU (N = 1) or this rank's shard (N > 1): `step()` = one fwd + bwd"""
+
+    def __init__(self, name, args, dev, dist, world, edges=None, fp16=False):
+        from primekg_rgcn_linkprediction_amd import RGCNConv, ops, rgcn_encoder2, synth
+        wl = WORKLOADS[name]
+        self.name, self.wl, self.dev, self.dist, self.world = name, wl, dev, dist, world
+        self.dims, self.bases = wl["dims"], wl["bases"]
+        if wl["graph"] == "primekg":
+            ei, et, n, r = synth.primekg_like(num_edges=edges or synth.PRIMEKG_EDGES, seed=42)
+        else:
+            ei, et, n, r = synth.uniform_graph(wl["nodes"], wl["edges"], wl["relations"], seed=42)
+        self.ei, self.et, self.n, self.r, self.num_edges = ei, et, n, r, ei.size(1)
+        dims = self.dims
+        torch.manual_seed(0)
+        self.emb_cpu = torch.nn.init.xavier_uniform_(torch.empty(n, dims[0]))
+        gdt = torch.float16 if fp16 else None
+        self.convs = [RGCNConv(dims[0], dims[1], r, num_bases=self.bases, gather_dtype=gdt),
+                      RGCNConv(dims[1], dims[2], r, num_bases=self.bases, gather_dtype=gdt)]
+        self.cot_cpu = torch.randn(n, dims[2])
+        self.summary = None
+        if world == 1:
+            eid, etd = ei.to(dev), et.to(dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ops.bucket(eid, etd, n, r)
+            torch.cuda.synchronize()
+            self.bucket_ms = (time.perf_counter() - t0) * 1e3
+            emb = self.emb_cpu.to(dev).requires_grad_(True)
+            convs = self.convs = [c.to(dev) for c in self.convs]
+            cot = self.cot_cpu.to(dev)
+            params = [emb] + [p for c in convs for p in c.parameters()]
+            self._keep = (eid, etd)
+
+            def step():
+                # DrugDiseaseRGCN.forward with dropout inactive: conv1 -> relu -> conv2
+                out = rgcn_encoder2(emb, eid, etd, convs[0], convs[1])
+                for p in params:
+                    p.grad = None
+                out.backward(cot)
+            self.step = step
+            self.parallelism = "1 GPU"
+        else:
+            from primekg_rgcn_linkprediction_amd import dist as rdist
+            backend = os.environ.get("RGCN_BENCH_BACKEND", "nccl")
+            t0 = time.perf_counter()
+            enc = self.enc = rdist.PartitionedEncoder(ei, et, n, r, self.emb_cpu, self.convs, dev)
+            torch.cuda.synchronize()
+            self.bucket_ms = (time.perf_counter() - t0) * 1e3
+            cot = enc.shard_rows(self.cot_cpu).to(dev)
+            self.step = lambda: enc.step(cot)                                     # noqa: E731
+            exchange = "RCCL over xGMI" if backend == "nccl" else f"{backend} (host-staged rehearsal, NOT RCCL)"
+            self.summary = summ = enc.exchange_summary()
+            how = ("halo all-to-all-v of the rows a rank's edges read, interior rows computed while it is in flight"
+                   if summ["scheme"] == "pull" else
+                   "partial sums of the boundary rows from the source owner: reduce-scatter forward, halo all-to-all-v backward")
+            self.parallelism = (f"node-partitioned x{world} (degree-balanced deal), scheme '{summ['scheme']}': {how}, per "
+                                f"layer and direction, over {exchange}")
+
+    def describe(self, headline):
+        d = self.dims
+        return (f"{self.wl['name']}, {self.n} nodes / {self.num_edges} edge columns / {self.r} relations, encoder "
+                f"{d[0]}->{d[1]}->{d[2]}, 2 layers fwd+bwd, full graph per step, dropout 0"
+                + ("" if headline else "  [NOT the headline configuration]"))
+
+    def sync(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, fn, k):
+        self.sync()
+        t = time.perf_counter()
+        for _ in range(k):
+            fn()
+        self.sync()
+        return (time.perf_counter() - t) / k
+
+    def agree(self, value, op):
+        """the same number on every rank (launch-mode decisions must not diverge between ranks)"""
+        if self.dist is None:
+            return value
+        t = torch.tensor([float(value)], device=self.dev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=op)
+        return t.item()
+
+    def capture(self):
+        """ONE HIP graph of the step (RCCL collectives included at N > 1: they capture like kernels)"""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.step()
+        torch.cuda.current_stream().wait_stream(side)
+        hip_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(hip_graph, capture_error_mode="thread_local"):
+            self.step()
+        for _ in range(3):
+            hip_graph.replay()
+        torch.cuda.synchronize()
+        return hip_graph
+
+    def measure(self, steps, warmup, use_graph, force_graph=False):
+        """-> (seconds for `steps` steps: max over ranks, launch mode).  The step is a fixed sequence of launches on
+        a static graph: issued eagerly or replayed from ONE captured HIP graph (same kernels and work either way); a
+        short untimed calibration picks the faster launch mode on this machine."""
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        run, mode = self.step, "eager"
+        if use_graph:
+            hip_graph = self.capture()                         # a failure here is a failure of the run: no silent fallback
+            t_graph, t_eager = self.timed(hip_graph.replay, 10), self.timed(self.step, 10)
+            if force_graph or t_graph < 1.1 * t_eager:         # replay unless eager is clearly faster (10 iterations each: noisy)
+                run, mode = hip_graph.replay, "hipGraph replay"
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            elapsed = self.agree(elapsed, self.dist.ReduceOp.MAX)
+        return elapsed, mode
+
+    def events(self, event_steps):
+        """Per-kernel durations, live, from HIP events on the launch stream: an eager pass of the same step (events
+        cannot be read back from inside a captured graph).  At N > 1 every rank runs the pass - the exchanges are
+        collective - and rank 0 reports its own shard."""
+        from primekg_rgcn_linkprediction_amd import ops
+        ops.GATHER_EVENTS, ops.GEMM_EVENTS, ops.FUSED_EVENTS = [], [], []
+        try:
+            for _ in range(event_steps):
+                # a short device-side spin first, so that the host has queued the step's launches
+                # before they execute: the events then bracket back-to-back kernels, not launch gaps
+                if self.world == 1:
+                    torch.cuda._sleep(4_000_000)
+                self.step()
+            self.sync()
+        finally:
+            ev = (ops.GATHER_EVENTS, ops.GEMM_EVENTS, ops.FUSED_EVENTS)
+            ops.GATHER_EVENTS = ops.GEMM_EVENTS = ops.FUSED_EVENTS = None
+        return ev
+
+
+def event_overhead_us(world):
+    """what an empty bracket costs on this stream (two event records, nothing between): reported, not subtracted -
+    the profiler's kernel-only durations in profiles/ are shorter by about this much"""
+    if world == 1:
+        torch.cuda._sleep(2_000_000)
+    pairs = []
+    for _ in range(20):
+        b, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b.record()
+        e.record()
+        pairs.append((b, e))
+    torch.cuda.synchronize()
+    return sum(b.elapsed_time(e) for b, e in pairs) / len(pairs) * 1e3
+
+
+def kernel_tables(run, events, event_steps):
+    """-> (gather + fused kernels, transform calls) as lists of dicts from the three event lists"""
+    gather_events, gemm_events, fused_events = events
+    r = run.r
+    kernels = []
+    per, shape = {}, {}
+    for transposed, d, edges, segments, beg, end in gather_events:
+        per.setdefault((transposed, d), []).append(beg.elapsed_time(end) * 1e-3)   # seconds
+        shape[(transposed, d)] = (edges, segments)
+    for (transposed, d), ts in sorted(per.items()):
+        avg = sum(ts) / len(ts)
+        edges, segments = shape[(transposed, d)]
+        nbytes = gather_bytes(edges, segments // r, r, d, transposed)
+        comp = gather_compulsory_bytes(edges, segments // r, r, d, transposed)
+        kernels.append({"kernel": f"k_aggregate<{d // 4},{'true' if transposed else 'false'}>", "kind": "gather",
+                        "d": d, "transposed": transposed, "launches_per_step": len(ts) // event_steps,
+                        "avg_us": avg * 1e6, "bytes": nbytes, "gbs": nbytes / avg / 1e9,
+                        "compulsory_hbm_bytes": comp, "table_bytes": 4 * (segments // r) * d,
+                        "total_us_per_step": sum(ts) / event_steps * 1e6})
+    # the one-kernel layers (gather into LDS + transform): algorithmic bytes = what the gather and the rows in /
+    # out cost - there is no aggregate write + read; "+store": the kept aggregate's one write
+    per, shape = {}, {}
+    for kind, rows, rels, edges, hub_rows, dk, dn, beg, end in fused_events:
+        per.setdefault((kind, dk, dn), []).append(beg.elapsed_time(end) * 1e-3)
+        shape[(kind, dk, dn)] = (rows, rels, edges, hub_rows)
+    for (kind, dk, dn), ts in sorted(per.items()):
+        rows, rels, edges, hub_rows = shape[(kind, dk, dn)]
+        avg = sum(ts) / len(ts)
+        weighted = kind.startswith("bwd")
+        ids = edges * (8 if weighted else 4) + 4 * (rows * rels + 1)
+        dense = 4 * rows * (dk + dn) + (4 * rows * dn if kind.endswith("mask") else 0) \
+            + (4 * rows * rels * dk if kind.endswith("store") else 0)
+        nbytes = edges * 4 * dk + hub_rows * 4 * dk + ids + dense
+        comp = 4 * rows * dk + ids + dense                  # the table once instead of once per edge
+        kernels.append({"kernel": f"k_layer_fused<{kind}, {dk}->{dn}>", "kind": "fused layer", "d": dk,
+                        "transposed": weighted, "launches_per_step": len(ts) // event_steps, "avg_us": avg * 1e6,
+                        "bytes": nbytes, "gbs": nbytes / avg / 1e9, "compulsory_hbm_bytes": comp,
+                        "table_bytes": 4 * rows * dk, "total_us_per_step": sum(ts) / event_steps * 1e6,
+                        "flops": 2.0 * rows * (rels + 1) * dk * dn})
+    calls = []
+    per = {}
+    for kind, m, k, nn, prec, beg, end in gemm_events:
+        per.setdefault((kind, m, k, nn, prec), []).append(beg.elapsed_time(end) * 1e-3)
+    for (kind, m, k, nn, prec), ts in sorted(per.items()):
+        avg = sum(ts) / len(ts)
+        flops = 2.0 * m * k * nn
+        # operand bytes of the call: NT calls read A [M, K] once and write C [M, N]; the parameter-gradient call
+        # (M = (R + 1) d_in columns, K = node rows, N = d_out) reads [agg | x] and g once (weights / slabs: small)
+        nbytes = 4.0 * (k * (m + nn) if kind == "bwd_params" else m * (k + nn))
+        calls.append({"call": kind, "M": m, "K": k, "N": nn, "arithmetic": prec,
+                      "launches_per_step": len(ts) // event_steps, "avg_us": avg * 1e6, "flops": flops,
+                      "tflops": flops / avg / 1e12, "operand_bytes": nbytes,
+                      "total_us_per_step": sum(ts) / event_steps * 1e6})
+    return kernels, calls
+
+
+def roofline_of(dom, headline_single):
+    """the contract's `roofline` object for the dominant gather / fused-layer kernel"""
+    traffic, traffic_source = pmc_traffic(dom["kernel"]) if headline_single else (None, "not applicable")
+    cache_resident = dom["table_bytes"] <= 200e6          # fits the 256 MiB Infinity Cache beside the streams
+    l2_resident = dom["table_bytes"] <= 32e6              # and the 8 x 4 MiB L2s (C2: 7.9 / 15.8 MB)
+    if l2_resident:
+        bound, peak = "l2", L2_GATHER_CEILING_GBS[0]
+        note = ("the gathered row table is L2 / Infinity-Cache resident, so the launch is bounded by the chip's L2-resident "
+                "indexed-row rate (guide: 16.8-18.8 TB/s), not by HBM: `frac` = achieved / 16.8 TB/s; "
+                "`algorithmic_over_hbm_peak` (> 1 here) is the same rate against the 8 TB/s HBM peak and "
+                "`frac_compulsory` what HBM itself has to deliver")
+    else:
+        bound, peak = "hbm", HBM_PEAK_GBS
+        note = ("the gathered row table exceeds the L2s" + (" (Infinity-Cache resident)" if cache_resident else " and the Infinity Cache")
+                + ": `frac` is a fraction of the HBM peak")
+    return {"bound": bound, "achieved": dom["gbs"], "peak": peak, "unit": "GB/s", "frac": dom["gbs"] / peak,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": dom["kernel"], "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"],
+            "algorithmic_over_hbm_peak": dom["gbs"] / HBM_PEAK_GBS,
+            "compulsory_hbm_bytes": dom["compulsory_hbm_bytes"],
+            "frac_compulsory": dom["compulsory_hbm_bytes"] / (dom["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+            "table_bytes": dom["table_bytes"], "table_cache_resident": cache_resident,
+            "l2_indexed_row_ceiling_gbs": list(L2_GATHER_CEILING_GBS), "note": note}
+
+
+def dominant_kernel_of(kernels, calls):
+    """the launch with the most time per step, with its byte-floor and MFMA fractions"""
+    best = None
+    for k in kernels:
+        floor_us = k["bytes"] / (L2_GATHER_CEILING_GBS[0] * 1e9 if k["table_bytes"] <= 32e6 else HBM_STREAM_GBS * 1e9) * 1e6
+        cand = {"kernel": k["kernel"], "kind": k["kind"], "avg_us": k["avg_us"], "launches_per_step": k["launches_per_step"],
+                "total_us_per_step": k["total_us_per_step"], "bytes": k["bytes"],
+                "byte_floor_us": floor_us, "frac_of_byte_floor": floor_us / k["avg_us"],
+                "byte_floor_rate": "L2-resident indexed rows 16.8 TB/s" if k["table_bytes"] <= 32e6 else "HBM streaming 6.3 TB/s",
+                "mfma_frac": (3.0 * k["flops"] / (k["avg_us"] * 1e-6) / 1e12 / F16_MATRIX_PEAK_TF) if "flops" in k else None}
+        if best is None or cand["total_us_per_step"] > best["total_us_per_step"]:
+            best = cand
+    for c in calls:
+        passes = 3 if c["arithmetic"] == "split" else 1
+        peak = F16_MATRIX_PEAK_TF if c["arithmetic"] in ("split", "half", "f16") else F32_MATRIX_PEAK_TF
+        floor_us = c["operand_bytes"] / (HBM_STREAM_GBS * 1e9) * 1e6
+        cand = {"kernel": f"transform {c['call']} [{c['M']} x {c['K']}] x [{c['K']} x {c['N']}] ({c['arithmetic']})",
+                "kind": "transform GEMM", "avg_us": c["avg_us"], "launches_per_step": c["launches_per_step"],
+                "total_us_per_step": c["total_us_per_step"], "bytes": c["operand_bytes"],
+                "byte_floor_us": floor_us, "frac_of_byte_floor": floor_us / c["avg_us"],
+                "byte_floor_rate": "operands once at the achievable streaming rate, 6.3 TB/s",
+                "executed_tflops": passes * c["tflops"], "mfma_frac": passes * c["tflops"] / peak,
+                "mfma_peak_tflops": peak}
+        if best is None or cand["total_us_per_step"] > best["total_us_per_step"]:
+            best = cand
+    return best
+
+
+def free_run(run):
+    """drop everything a workload holds on the device (its closures pin the tensors), then the cached structures"""
+    from primekg_rgcn_linkprediction_amd import ops
+    run.__dict__.clear()
+    ops.clear_graph_cache()
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def secondary_c4(args, dev, dist, world):
+    """a short run of BASELINE configs[3]'s graph: on ONE GPU the table (128 / 256 MB) is not cache resident and the
+    gather is HBM-bound; at N > 1 the graph is node-partitioned over the ranks"""
+    run = Run("c4", args, dev, dist, world)
+    steps, warmup = 10, 3
+    elapsed, mode = run.measure(steps, warmup, use_graph=False)
+    out = {"workload": run.describe(False), "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": elapsed / steps * 1e3, "value": LAYERS * run.num_edges * steps / elapsed, "unit": "edges/s",
+           "launch": mode, "parallelism": run.parallelism, "bucket_ms": run.bucket_ms}
+    if world > 1:
+        out["exchange_rank0"] = run.summary
+    ev_steps = 3
+    kernels, calls = kernel_tables(run, run.events(ev_steps), ev_steps)
+    if kernels:
+        dom = max(kernels, key=lambda k: k["total_us_per_step"])
+        out["roofline"] = roofline_of(dom, False)
+        gathers = [k for k in kernels if k["kind"] == "gather"]
+        if gathers:
+            g = max(gathers, key=lambda k: k["total_us_per_step"])
+            out["gather_vs_hbm_peak"] = {"kernel": g["kernel"], "avg_us": g["avg_us"], "achieved_gbs": g["gbs"],
+                                         "frac_of_hbm_peak": g["gbs"] / HBM_PEAK_GBS, "table_bytes": g["table_bytes"]}
+        out["kernels"] = [{k: v for k, v in kk.items() if k in ("kernel", "avg_us", "gbs", "launches_per_step", "total_us_per_step")}
+                          for kk in kernels]
+    free_run(run)
+    return out
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,12 +482,12 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 "
                              f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus}")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    if world > 1 and args.workload != "c2":
-        raise SystemExit("N > 1 runs the headline workload (c2) only")
+    if world > 1 and WORKLOADS[args.workload]["bases"] is not None:
+        raise SystemExit("N > 1 runs c2 (headline) or c4 (BASELINE configs[3]); basis-decomposed layers are N = 1 only")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the measured path")
 
-    from primekg_rgcn_linkprediction_amd import RGCNConv, _lib, ops, rgcn_encoder2, synth
+    from primekg_rgcn_linkprediction_amd import _lib, ops, synth
     if not os.path.exists(_lib.LIB_PATH):                 # a fresh checkout: the library is a build product
         if local_rank == 0:
             import __graft_entry__
@@ -196,238 +511,42 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    wl = WORKLOADS[args.workload]
-    dims, bases = wl["dims"], wl["bases"]
-    if wl["graph"] == "primekg":
-        ei, et, n, r = synth.primekg_like(num_edges=args.edges or synth.PRIMEKG_EDGES, seed=42)
-    else:
-        ei, et, n, r = synth.uniform_graph(wl["nodes"], wl["edges"], wl["relations"], seed=42)
-    num_edges = ei.size(1)
-    torch.manual_seed(0)
-    emb_cpu = torch.nn.init.xavier_uniform_(torch.empty(n, dims[0]))
-    gdt = torch.float16 if args.fp16_gather else None
-    convs = [RGCNConv(dims[0], dims[1], r, num_bases=bases, gather_dtype=gdt),
-             RGCNConv(dims[1], dims[2], r, num_bases=bases, gather_dtype=gdt)]
-    cot_cpu = torch.randn(n, dims[2])
+    is_c4 = args.workload in ("c4", "c4-1gpu")
+    run = Run(args.workload, args, dev, dist, world, edges=args.edges, fp16=args.fp16_gather)
+    use_graph = world == 1 and not args.no_graph
+    elapsed, launch_mode = run.measure(args.steps, args.warmup, use_graph, force_graph=args.graph)
 
-    if world == 1:
-        eid, etd = ei.to(dev), et.to(dev)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ops.bucket(eid, etd, n, r)
-        torch.cuda.synchronize()
-        bucket_ms = (time.perf_counter() - t0) * 1e3
-        emb = emb_cpu.to(dev).requires_grad_(True)
-        convs = [c.to(dev) for c in convs]
-        cot = cot_cpu.to(dev)
-        params = [emb] + [p for c in convs for p in c.parameters()]
-
-        def step():
-            # DrugDiseaseRGCN.forward with dropout inactive: conv1 -> relu -> conv2
-            out = rgcn_encoder2(emb, eid, etd, convs[0], convs[1])
-            for p in params:
-                p.grad = None
-            out.backward(cot)
-        parallelism = "1 GPU"
-    else:
-        from primekg_rgcn_linkprediction_amd import dist as rdist
-        t0 = time.perf_counter()
-        enc = rdist.PartitionedEncoder(ei, et, n, r, emb_cpu, convs, dev)
-        torch.cuda.synchronize()
-        bucket_ms = (time.perf_counter() - t0) * 1e3
-        cot = enc.shard_rows(cot_cpu).to(dev)
-        step = lambda: enc.step(cot)                                     # noqa: E731
-        exchange = "RCCL over xGMI" if backend == "nccl" else f"{backend} (host-staged rehearsal, NOT RCCL)"
-        summ = enc.exchange_summary()
-        how = ("halo all-to-all-v of the rows a rank's edges read" if summ["scheme"] == "pull" else
-               "partial sums from the source owner: reduce-scatter forward, halo all-to-all-v backward")
-        parallelism = (f"node-partitioned x{world} (degree-balanced deal), scheme '{summ['scheme']}': {how}, per layer "
-                       f"and direction, over {exchange}")
-
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync()
-
-    # The step is a fixed sequence of launches on a static graph.  It can be issued eagerly (the
-    # host runs ahead of the GPU) or replayed from ONE captured HIP graph (no per-launch host
-    # cost, robust against a busy host): same kernels and work either way.  A short untimed
-    # calibration picks the faster launch mode on this machine; --no-graph / --graph force one.
-    def timed(fn, k):
-        sync()
-        t = time.perf_counter()
-        for _ in range(k):
-            fn()
-        sync()
-        return (time.perf_counter() - t) / k
-
-    def agree(value, op):
-        """the same number on every rank (launch-mode decisions must not diverge between ranks)"""
-        if dist is None:
-            return value
-        t = torch.tensor([float(value)], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=op)
-        return t.item()
-
-    def capture(step_fn):
-        """ONE HIP graph of the step (RCCL collectives included at N > 1: they capture like kernels)"""
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step_fn()
-        torch.cuda.current_stream().wait_stream(side)
-        hip_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(hip_graph, capture_error_mode="thread_local"):
-            step_fn()
-        for _ in range(3):
-            hip_graph.replay()
-        torch.cuda.synchronize()
-        return hip_graph
-
-    run, launch_mode = step, "eager"
-    if world == 1 and not args.no_graph:
-        hip_graph = capture(step)                          # a failure here is a failure of the run: no silent fallback
-        t_graph, t_eager = timed(hip_graph.replay, 10), timed(step, 10)
-        if args.graph or t_graph < 1.1 * t_eager:         # replay unless eager is clearly faster (10 iterations each: noisy)
-            run, launch_mode = hip_graph.replay, "hipGraph replay"
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    sync()
-    elapsed = time.perf_counter() - t0
-
-    # Per-kernel durations, live, from HIP events on the launch stream: an eager pass of the same
-    # step (events cannot be read back from inside a captured graph).  (At N > 1 every rank runs
-    # the pass - the exchanges are collective - and rank 0 reports its own shard.)
     event_steps = min(args.steps, 20)
-    ops.GATHER_EVENTS, ops.GEMM_EVENTS, ops.FUSED_EVENTS = [], [], []
-    for _ in range(event_steps):
-        # a short device-side spin first, so that the host has queued the step's launches
-        # before they execute: the events then bracket back-to-back kernels, not launch gaps
-        if world == 1:
-            torch.cuda._sleep(4_000_000)
-        step()
-    sync()
-    events, ops.GATHER_EVENTS = ops.GATHER_EVENTS, None
-    gemm_events, ops.GEMM_EVENTS = ops.GEMM_EVENTS, None
-    fused_events, ops.FUSED_EVENTS = ops.FUSED_EVENTS, None
-    # what an empty bracket costs on this stream (two event records, nothing between): reported, not
-    # subtracted - the profiler's kernel-only durations in profiles/ are shorter by about this much
-    if world == 1:
-        torch.cuda._sleep(2_000_000)
-    pairs = []
-    for _ in range(20):
-        b, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        b.record()
-        e.record()
-        pairs.append((b, e))
-    torch.cuda.synchronize()
-    event_overhead_us = sum(b.elapsed_time(e) for b, e in pairs) / len(pairs) * 1e3
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    events = run.events(event_steps)
+    overhead_us = event_overhead_us(world)
 
     headline = args.workload == "c2" and not args.fp16_gather and args.edges in (None, synth.PRIMEKG_EDGES)
     result = {
-        "metric": "edges/sec per RGCN layer (fwd+bwd), PrimeKG 30.9k nodes/849k edges/3 rels",
-        "value": LAYERS * num_edges * args.steps / elapsed,
+        "metric": METRIC,
+        "value": LAYERS * run.num_edges * args.steps / elapsed,
         "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": ("f32" if not args.fp16_gather else "f16 feature table, f32 accumulate/transform"),
         "data": "synthetic",
-        "config": {"workload": f"{wl['name']}, {n} nodes / {num_edges} edge columns / {r} relations, encoder "
-                               f"{dims[0]}->{dims[1]}->{dims[2]}, 2 layers fwd+bwd, full graph per step, dropout 0"
-                               + ("" if headline else "  [NOT the headline configuration]"),
-                   "parallelism": parallelism, "launch": launch_mode,
+        "config": {"workload": run.describe(headline),
+                   "parallelism": run.parallelism, "launch": launch_mode,
                    "transform_arithmetic": ("fp32 values as fp16 hi/lo pairs on the fp16 matrix cores, fp32 accumulate "
                                             "(3 MFMA passes; 1e-5 gates of tests/test_gpu_parity.py)"
                                             if ops.GEMM_PRECISION == "split" else "fp32 MFMA")},
-        "bucket_ms": bucket_ms,
+        "bucket_ms": run.bucket_ms,
     }
     if world > 1:
-        result["exchange_rank0"] = summ          # rows received per exchange as a fraction of the rows rank 0 does not own
+        result["exchange_rank0"] = run.summary   # rows received per exchange as a fraction of the rows rank 0 does not own
 
-    fused_kernels = []
-    if fused_events:
-        # the one-kernel layers (gather into LDS + transform): algorithmic bytes = what the gather and the rows in /
-        # out cost - there is no aggregate write + read; "+store": the kept aggregate's one write
-        per, shape = {}, {}
-        for kind, rows, rels, edges, hub_rows, dk, dn, beg, end in fused_events:
-            per.setdefault((kind, dk, dn), []).append(beg.elapsed_time(end) * 1e-3)
-            shape[(kind, dk, dn)] = (rows, rels, edges, hub_rows)
-        for (kind, dk, dn), ts in sorted(per.items()):
-            rows, rels, edges, hub_rows = shape[(kind, dk, dn)]
-            avg = sum(ts) / len(ts)
-            weighted = kind.startswith("bwd")
-            ids = edges * (8 if weighted else 4) + 4 * (rows * rels + 1)
-            dense = 4 * rows * (dk + dn) + (4 * rows * dn if kind.endswith("mask") else 0) \
-                + (4 * rows * rels * dk if kind.endswith("store") else 0)
-            nbytes = edges * 4 * dk + hub_rows * 4 * dk + ids + dense
-            comp = 4 * rows * dk + ids + dense                  # the table once instead of once per edge
-            fused_kernels.append({"kernel": f"k_layer_fused<{kind}, {dk}->{dn}>", "d": dk, "transposed": weighted,
-                                  "launches_per_step": len(ts) // event_steps, "avg_us": avg * 1e6, "bytes": nbytes,
-                                  "gbs": nbytes / avg / 1e9, "compulsory_hbm_bytes": comp, "table_bytes": 4 * rows * dk,
-                                  "total_us_per_step": sum(ts) / event_steps * 1e6,
-                                  "flops": 2.0 * rows * (rels + 1) * dk * dn})
-
-    if events or fused_kernels:
-        # per instantiation of the gather kernel: average duration from the live HIP events
-        per, shape = {}, {}
-        for transposed, d, edges, segments, beg, end in events:
-            per.setdefault((transposed, d), []).append(beg.elapsed_time(end) * 1e-3)   # seconds
-            shape[(transposed, d)] = (edges, segments)
-        kernels = []
-        for (transposed, d), ts in sorted(per.items()):
-            avg = sum(ts) / len(ts)
-            edges, segments = shape[(transposed, d)]
-            nbytes = gather_bytes(edges, segments // r, r, d, transposed)
-            comp = gather_compulsory_bytes(edges, segments // r, r, d, transposed)
-            kernels.append({"kernel": f"k_aggregate<{d // 4},{'true' if transposed else 'false'}>",
-                            "d": d, "transposed": transposed, "launches_per_step": len(ts) // event_steps,
-                            "avg_us": avg * 1e6, "bytes": nbytes, "gbs": nbytes / avg / 1e9,
-                            "compulsory_hbm_bytes": comp, "table_bytes": 4 * (segments // r) * d,
-                            "total_us_per_step": sum(ts) / event_steps * 1e6})
-        kernels += fused_kernels
+    kernels, calls = kernel_tables(run, events, event_steps)
+    if kernels:
         dom = max(kernels, key=lambda k: k["total_us_per_step"])
-        traffic, traffic_source = pmc_traffic(dom["kernel"]) if (world == 1 and headline) else (None, "not applicable")
-        cache_resident = dom["table_bytes"] <= 200e6          # fits the 256 MiB Infinity Cache beside the streams
-        result["roofline"] = {
-            "bound": "hbm", "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom["gbs"] / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": dom["kernel"], "avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["bytes"],
-            "compulsory_hbm_bytes": dom["compulsory_hbm_bytes"],
-            "frac_compulsory": dom["compulsory_hbm_bytes"] / (dom["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-            "table_bytes": dom["table_bytes"], "table_cache_resident": cache_resident,
-            "l2_indexed_row_ceiling_gbs": list(L2_GATHER_CEILING_GBS),
-            "frac_of_l2_ceiling": [dom["gbs"] / L2_GATHER_CEILING_GBS[1], dom["gbs"] / L2_GATHER_CEILING_GBS[0]],
-            "note": ("the gathered row table is L2 / Infinity-Cache resident: `frac` (algorithmic bytes against the HBM "
-                     "peak, the contract's figure) can exceed 1; `frac_of_l2_ceiling` is the meaningful fraction here and "
-                     "`frac_compulsory` is what HBM itself has to deliver"
-                     if cache_resident else
-                     "the gathered row table exceeds the caches: `frac` is a true fraction of the HBM peak"),
-            "event_bracket_overhead_us": event_overhead_us}
+        result["roofline"] = roofline_of(dom, world == 1 and headline)
+        result["roofline"]["event_bracket_overhead_us"] = overhead_us
         result["gather_kernels"] = kernels
-
-    if gemm_events:
-        per = {}
-        for kind, m, k, nn, prec, beg, end in gemm_events:
-            per.setdefault((kind, m, k, nn, prec), []).append(beg.elapsed_time(end) * 1e-3)
-        calls = []
-        for (kind, m, k, nn, prec), ts in sorted(per.items()):
-            avg = sum(ts) / len(ts)
-            flops = 2.0 * m * k * nn
-            calls.append({"call": kind, "M": m, "K": k, "N": nn, "arithmetic": prec,
-                          "launches_per_step": len(ts) // event_steps, "avg_us": avg * 1e6, "flops": flops,
-                          "tflops": flops / avg / 1e12, "total_us_per_step": sum(ts) / event_steps * 1e6})
+    if calls:
         domg = max(calls, key=lambda c: c["total_us_per_step"])
         executed = domg["flops"] * (3 if domg["arithmetic"] == "split" else 1)
         result["roofline_mfma"] = {
@@ -442,22 +561,26 @@ def main():
                      "peak) and its bracket includes the operand scan and the weight split launches"),
             "sum_transform_us_per_step": sum(c["total_us_per_step"] for c in calls)}
         result["transform_calls"] = calls
+    if kernels or calls:
+        result["dominant_kernel"] = dominant_kernel_of(kernels, calls)
 
-    if world > 1 and not args.no_replica:
+    if world > 1 and not args.no_replica and not is_c4:
         # Reported beside the node-partitioned number (never instead of it): batch-replica mode,
         # every GPU the whole graph and its own mini-batch, one flat all-reduce of all parameter
         # gradients per step.  Per-GPU work is fixed, so this one is weak scaling.
         import copy
-        rep = rdist.ReplicatedEncoder(ei, et, n, r, emb_cpu, [copy.deepcopy(c) for c in convs], dev)
-        cot_full = cot_cpu.to(dev)
+        from primekg_rgcn_linkprediction_amd import dist as rdist
+        rep = rdist.ReplicatedEncoder(run.ei, run.et, run.n, run.r, run.emb_cpu, [copy.deepcopy(c) for c in run.convs], dev)
+        cot_full = run.cot_cpu.to(dev)
         for _ in range(args.warmup):
             rep.step(cot_full)
         rep_step = lambda: rep.step(cot_full)                              # noqa: E731
-        rep_s = agree(timed(rep_step, args.steps), dist.ReduceOp.MAX)
-        result["replica"] = {"value": world * LAYERS * num_edges / rep_s, "unit": "edges/s",
+        rep_s = run.agree(run.timed(rep_step, args.steps), dist.ReduceOp.MAX)
+        result["replica"] = {"value": world * LAYERS * run.num_edges / rep_s, "unit": "edges/s",
                              "ms_per_step": rep_s * 1e3, "scaling": "weak", "launch": "eager",
                              "parallelism": f"batch replicas x{world}: full graph and encoder per GPU, one "
                                             f"{rep._flat.numel() * 4 / 1e6:.1f} MB gradient all-reduce per step"}
+        del rep, cot_full
 
     exit_code = 0
     if world > 1:
@@ -467,38 +590,73 @@ def main():
         # hang, so the attempt comes last, its outcome is written into the line, and the process exits
         # non-zero if it failed or hung (the eager line is still printed first).
         result["graph_attempt"] = "not attempted (opt in with RGCN_BENCH_GRAPH_N=1)"
-        if os.environ.get("RGCN_BENCH_GRAPH_N", "0") == "1" and not args.no_graph:
-            import threading
 
-            def bail_out():                                                    # pragma: no cover
-                result["graph_attempt"] = "hung: a replayed collective never completed; eager numbers reported"
-                if rank == 0:
-                    print(json.dumps(result), flush=True)
-                os._exit(4)
-
-            watchdog = threading.Timer(float(os.environ.get("RGCN_BENCH_GRAPH_TIMEOUT", "120")), bail_out)
-            watchdog.daemon = True
-            watchdog.start()
+    # ---- secondary legs of the headline line (short; the whole command stays well inside the driver's limit) ----
+    want_graph_n = world > 1 and os.environ.get("RGCN_BENCH_GRAPH_N", "0") == "1" and not args.no_graph
+    if headline and not args.no_secondary and want_graph_n:
+        result["secondary"] = {"skipped": "RGCN_BENCH_GRAPH_N=1: the graph attempt may end the process, so it runs alone"}
+    if headline and not args.no_secondary and not want_graph_n:
+        secondary = {}
+        if world == 1:
+            # the same step with exact fp32 MFMA products (RGCN_GEMM_PRECISION=fp32): every module reads
+            # ops.GEMM_PRECISION at call time, so the switch is in-process; same graph, same tensors
+            saved = ops.GEMM_PRECISION
             try:
-                g = capture(step)
-                g_s = agree(timed(g.replay, args.steps), dist.ReduceOp.MAX)
-                result["graph_attempt"] = "ok"
-                result["graph_ms_per_step"] = g_s * 1e3
-                if g_s < result["ms_per_step"] * 1e-3:
-                    result["eager_ms_per_step"] = result["ms_per_step"]
-                    result.update(value=LAYERS * num_edges / g_s, ms_per_step=g_s * 1e3)
-                    result["config"]["launch"] = "hipGraph replay"
-            except Exception as exc:                                           # pragma: no cover
-                result["graph_attempt"] = f"failed: {exc!r}; eager numbers reported"
-                watchdog.cancel()
-                if rank == 0:
-                    print(json.dumps(result), flush=True)
-                sys.stderr.flush()
-                os._exit(3)                       # HIP is unusable in this process now: no teardown, non-zero exit
+                ops.GEMM_PRECISION = "fp32"
+                fp32_s, fp32_mode = run.measure(20, 5, use_graph, force_graph=args.graph)
+                result["fp32_mfma_ms_per_step"] = fp32_s / 20 * 1e3
+                result["fp32_mfma"] = {"ms_per_step": fp32_s / 20 * 1e3, "value": LAYERS * run.num_edges * 20 / fp32_s,
+                                       "unit": "edges/s", "steps": 20, "launch": fp32_mode,
+                                       "arithmetic": "v_mfma_f32_32x32x2_f32: every product exact fp32 (bit for bit an fmaf chain)"}
             finally:
-                watchdog.cancel()
+                ops.GEMM_PRECISION = saved
+        keep_cpu = (run.ei, run.et, run.n, run.r, run.dims, run.bases)
+        free_run(run)
+        run = None
+        try:
+            secondary["c4_1gpu" if world == 1 else "c4"] = secondary_c4(args, dev, dist, world)
+        except Exception as exc:                                           # the headline line must survive this leg
+            secondary["c4_1gpu" if world == 1 else "c4"] = {"error": repr(exc)}
+            exit_code = exit_code or 5
+        result["secondary"] = secondary
+    else:
+        keep_cpu = (run.ei, run.et, run.n, run.r, run.dims, run.bases)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if want_graph_n and run is not None:
+        import threading
+
+        def bail_out():                                                    # pragma: no cover
+            result["graph_attempt"] = "hung: a replayed collective never completed; eager numbers reported"
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            os._exit(4)
+
+        watchdog = threading.Timer(float(os.environ.get("RGCN_BENCH_GRAPH_TIMEOUT", "120")), bail_out)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            g = run.capture()
+            g_s = run.agree(run.timed(g.replay, args.steps), dist.ReduceOp.MAX)
+            result["graph_attempt"] = "ok"
+            result["graph_ms_per_step"] = g_s * 1e3
+            if g_s < result["ms_per_step"] * 1e-3:
+                result["eager_ms_per_step"] = result["ms_per_step"]
+                result.update(value=LAYERS * run.num_edges / g_s, ms_per_step=g_s * 1e3)
+                result["config"]["launch"] = "hipGraph replay"
+        except Exception as exc:                                           # pragma: no cover
+            result["graph_attempt"] = f"failed: {exc!r}; eager numbers reported"
+            watchdog.cancel()
+            if rank == 0:
+                print(json.dumps(result), flush=True)
+            sys.stderr.flush()
+            os._exit(3)                       # HIP is unusable in this process now: no teardown, non-zero exit
+        finally:
+            watchdog.cancel()
+
+    if rank == 0 and world == 1 and is_c4 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = None            # one oracle step over 20M edge columns takes minutes: timed for C2 only
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ei, et, n, r, dims, bases = keep_cpu
         result["cpu_baseline"] = cpu_baseline(ei, et, n, r, dims, bases, args.cpu_seconds)
         result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
 

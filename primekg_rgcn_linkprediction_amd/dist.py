@@ -31,6 +31,16 @@ Two exchange schemes, switchable (``scheme=`` / ``RGCN_DIST_SCHEME``), same resu
 Parameter gradients are partial sums over a rank's rows -> ONE flat all-reduce per layer
 (<= 0.4 MB), overlapped with the gather that follows.
 
+Overlap ("pull"): a rank's slots hold its INTERIOR rows first - rows none of whose edges (either
+direction) crosses ranks - then its boundary rows.  Per layer and direction the halo exchange is issued
+first; gather + transform of the interior rows (they read own rows only) and, in backward, the
+parameter-gradient GEMM run while it is in flight; the boundary rows follow the wait.  Both halves
+write row ranges of ONE aggregate / output tensor, in the same per-segment order as the unsplit form
+(fp32 arithmetic: the same bits).  How many rows are interior is the partition's doing: the
+degree-balanced deal below scatters neighbours over all ranks (C2, P = 8: a handful of low-degree
+rows), a locality-aware assignment (``NodePartition.from_assignment``) keeps whole neighbourhoods.
+"push" reduce-scatters only the rows that receive a message from another rank's sources.
+
 xGMI is point to point (7 links per GPU): an all-to-all / all-gather / reduce-scatter of slabs
 drives all seven links at once.
 
@@ -62,8 +72,8 @@ class HipBackend:
         return self.ops.BucketedGraph.from_shard(key, other, etype, n_key, n_other, num_relations,
                                                  edge_weight)
 
-    def aggregate(self, shard, x):
-        return self.ops.aggregate(shard, x)
+    def aggregate(self, shard, x, out=None):
+        return self.ops.aggregate(shard, x, out=out)
 
     def _amax(self, table, shard):
         """operand scales of the split-precision transforms: the aggregate is bounded by
@@ -77,13 +87,17 @@ class HipBackend:
     # `shard` = the structure the aggregate operand was built over (its relation-occupancy mask
     # lets the kernels skip all-zero tiles), `table` = the rows it was gathered from; backends
     # without these notions ignore them
-    def transform_fwd(self, agg, x, weight, root, bias, relu=False, shard=None, table=None):
+    def transform_fwd(self, agg, x, weight, root, bias, relu=False, shard=None, table=None, out=None):
         amax, mul = self._amax(table, shard)
-        return self.ops.transform_fwd(agg, x, weight, root, bias, relu, shard, amax=amax, amax_mul=mul)
+        return self.ops.transform_fwd(agg, x, weight, root, bias, relu, shard, amax=amax, amax_mul=mul, out=out)
 
-    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None, shard=None, table=None):
+    def transform_bwd_input(self, gagg, g, weight, root, relu_mask=None, shard=None, table=None, out=None):
         amax, mul = self._amax(table, shard)
-        return self.ops.transform_bwd_input(gagg, g, weight, root, relu_mask, shard, amax=amax, amax_mul=mul)
+        gx = self.ops.transform_bwd_input(gagg, g, weight, root, relu_mask, shard, amax=amax, amax_mul=mul)
+        if out is None:
+            return gx
+        out.copy_(gx)                     # (the input-gradient entry points allocate their result: one row-range copy)
+        return out
 
     def transform_bwd_params(self, agg, x, g, num_relations, want_root, want_bias, shard=None):
         return self.ops.transform_bwd_params(agg, x, g, num_relations, want_root, want_bias, shard)
@@ -105,31 +119,76 @@ class NodePartition:
         self.world, self.num_nodes = world, num_nodes
         self.cap = (num_nodes + world - 1) // world
         rank_of, slot_of = self._deal(deg, world, self.cap, self.EXACT_HEAD if exact_head is None else exact_head)
-        self._finish(rank_of, slot_of)
+        self._finish(*self._interior_first(rank_of, slot_of, ei, self.cap))
+
+    @classmethod
+    def from_assignment(cls, rank_of: Tensor, edge_index: Tensor, world: int) -> "NodePartition":
+        """a partition from a given node -> rank assignment (a locality-aware partitioner's output): slots in node
+        order, interior rows first; every rank at most ceil(N / world) rows"""
+        part = cls.__new__(cls)
+        rank_of = rank_of.to(torch.int64).cpu()
+        n = rank_of.numel()
+        part.world, part.num_nodes, part.cap = world, n, (n + world - 1) // world
+        counts = torch.bincount(rank_of, minlength=world)
+        if int(counts.max()) > part.cap:
+            raise ValueError(f"a rank holds {int(counts.max())} rows, more than ceil(N / world) = {part.cap}")
+        order = torch.argsort(rank_of, stable=True)
+        start = torch.cumsum(counts, 0) - counts
+        slot_of = torch.empty(n, dtype=torch.int64)
+        slot_of[order] = torch.arange(n) - start[rank_of[order]]
+        part._finish(*cls._interior_first(rank_of, slot_of, edge_index.cpu(), part.cap))
+        return part
+
+    @staticmethod
+    def _interior_first(rank_of: Tensor, slot_of: Tensor, ei: Tensor, cap: int):
+        """re-number each rank's slots so that its interior rows (no edge of theirs, in either direction, crosses
+        ranks) come first, each class in the old slot order -> (rank_of, slot_of, interior flag)"""
+        n = rank_of.numel()
+        cross = rank_of[ei[0]] != rank_of[ei[1]]
+        boundary = torch.zeros(n, dtype=torch.bool)
+        boundary[ei[0][cross]] = True
+        boundary[ei[1][cross]] = True
+        order = torch.argsort(rank_of * (2 * cap) + boundary.long() * cap + slot_of, stable=True)
+        counts = torch.bincount(rank_of, minlength=int(rank_of.max()) + 1 if n else 1)
+        start = torch.cumsum(counts, 0) - counts
+        new_slot = torch.empty(n, dtype=torch.int64)
+        new_slot[order] = torch.arange(n) - start[rank_of[order]]
+        return rank_of, new_slot, ~boundary
 
     @classmethod
     def shared(cls, edge_index: Tensor, num_nodes: int, group=None, device=None) -> "NodePartition":
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         if rank == 0:
             part = cls(edge_index, num_nodes, world)
-            payload = torch.stack([part.rank_of, part.slot_of])
+            payload = torch.stack([part.rank_of, part.slot_of, part.interior.long()])
         else:
             part = cls.__new__(cls)
             part.world, part.num_nodes, part.cap = world, num_nodes, (num_nodes + world - 1) // world
-            payload = torch.empty(2, num_nodes, dtype=torch.int64)
+            payload = torch.empty(3, num_nodes, dtype=torch.int64)
         if world > 1:
             on_dev = dist.get_backend(group) == "nccl"
             buf = payload.to(device) if on_dev else payload
             dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             payload = buf.cpu()
         if rank != 0:
-            part._finish(payload[0].clone(), payload[1].clone())
+            part._finish(payload[0].clone(), payload[1].clone(), payload[2].bool())
         return part
 
-    def _finish(self, rank_of: Tensor, slot_of: Tensor) -> None:
-        self.rank_of, self.slot_of = rank_of, slot_of
+    def _finish(self, rank_of: Tensor, slot_of: Tensor, interior: Tensor) -> None:
+        self.rank_of, self.slot_of, self.interior = rank_of, slot_of, interior
         self.pid = rank_of * self.cap + slot_of                         # row in the gathered layout
         self.counts = torch.bincount(rank_of, minlength=self.world)
+        # rows [0, num_interior[k]) of rank k are interior, [num_interior[k], counts[k]) boundary
+        self.num_interior = torch.bincount(rank_of[interior], minlength=self.world)
+        self._dev = {}
+
+    def on(self, device) -> "_PartitionTensors":
+        """rank_of / slot_of / pid on ``device`` (cached): the shard plans are index arithmetic over the whole edge
+        list - 20M columns at C4 - and run where the edges are"""
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = _PartitionTensors(self.rank_of.to(device), self.slot_of.to(device), self.pid.to(device))
+        return self._dev[key]
 
     @staticmethod
     def _deal(deg: Tensor, world: int, cap: int, exact_head: int):
@@ -205,6 +264,11 @@ class NodePartition:
         return gathered[self.pid.to(gathered.device)]
 
 
+class _PartitionTensors:
+    def __init__(self, rank_of, slot_of, pid):
+        self.rank_of, self.slot_of, self.pid = rank_of, slot_of, pid
+
+
 # ------------------------------------------------------------------------------------------
 # what one rank holds of the static graph
 # ------------------------------------------------------------------------------------------
@@ -216,31 +280,38 @@ class HaloPlan:
     no handshake; sender and receiver order a pair's rows by the owner's slot."""
 
     def __init__(self, reader: Tensor, read: Tensor, part: NodePartition, rank: int, device):
+        """``reader`` / ``read`` live on the plan device (the GPU when there is one); so does everything below"""
         world, n = part.world, part.num_nodes
-        r_reader, r_read = part.rank_of[reader], part.rank_of[read]
+        pt = part.on(reader.device)
+        self._pt, self._cap = pt, part.cap
+        r_reader, r_read = pt.rank_of[reader], pt.rank_of[read]
         cross = r_reader != r_read
         # rows this rank receives: the distinct nodes its own readers read from other ranks
         mine = cross & (r_reader == rank)
         remote = torch.unique(read[mine])
-        remote = remote[torch.argsort(part.pid[remote])]                 # by owner, then by the owner's slot
+        remote = remote[torch.argsort(pt.pid[remote])]                   # by owner, then by the owner's slot
         self.halo_nodes, self.num_halo = remote, int(remote.numel())
-        self.recv_splits = torch.bincount(part.rank_of[remote], minlength=world).tolist()
+        self.recv_splits = torch.bincount(pt.rank_of[remote], minlength=world).tolist()
         # rows this rank sends: its own nodes that readers of other ranks read, per reading rank
         theirs = cross & (r_read == rank)
         pair = torch.unique(r_reader[theirs] * n + read[theirs])         # (reading rank, own node), distinct
         to_rank, node = pair // n, pair % n
-        order = torch.argsort(to_rank * (part.cap + 1) + part.slot_of[node])
+        order = torch.argsort(to_rank * (part.cap + 1) + pt.slot_of[node])
         self.send_splits = torch.bincount(to_rank, minlength=world).tolist()
-        self.send_slots = part.slot_of[node][order].to(device)
+        self.send_slots = pt.slot_of[node][order].to(device)
         self.num_send = int(pair.numel())
+        self._lut = None
 
     def local_index(self, part: NodePartition, rank: int, nodes: Tensor) -> Tensor:
         """node id -> row of the local table (own slot, or cap + position among the halo rows)"""
-        lut = torch.full((part.num_nodes,), -1, dtype=torch.int64)
-        own = torch.nonzero(part.rank_of == rank).flatten()
-        lut[own] = part.slot_of[own]
-        lut[self.halo_nodes] = part.cap + torch.arange(self.num_halo)
-        out = lut[nodes]
+        if self._lut is None:
+            pt = self._pt
+            lut = torch.full((part.num_nodes,), -1, dtype=torch.int64, device=pt.rank_of.device)
+            own = torch.nonzero(pt.rank_of == rank).flatten()
+            lut[own] = pt.slot_of[own]
+            lut[self.halo_nodes] = part.cap + torch.arange(self.num_halo, device=lut.device)
+            self._lut = lut
+        out = self._lut[nodes]
         if out.numel() and int(out.min()) < 0:
             raise RuntimeError("halo plan does not cover an edge endpoint")
         return out
@@ -255,38 +326,81 @@ class RankShard:
     """What one rank holds of the static graph: the bucketed structures of its rows, in the rank's LOCAL
     row space ``[own rows (cap) | halo rows]``, and the two halo plans."""
 
+    MIN_SPLIT_ROWS = 32      # fewer interior (or boundary) rows than this: one gather / transform over all rows
+
     def __init__(self, part: NodePartition, edge_index: Tensor, edge_type: Tensor, num_relations: int,
-                 rank: int, device, backend, scheme: str = "pull"):
+                 rank: int, device, backend, scheme: str = "pull", split: Optional[bool] = None):
         if scheme not in SCHEMES:
             raise ValueError(f"scheme must be one of {SCHEMES}, got {scheme!r}")
-        ei, et = edge_index.cpu(), edge_type.cpu()
+        device = torch.device(device)
+        pd = device if device.type == "cuda" else torch.device("cpu")    # where the plans are computed
+        ei, et = edge_index.to(pd), edge_type.to(pd)
+        pt = part.on(pd)
         n, r = part.num_nodes, num_relations
         src, dst = ei[0], ei[1]
         cnt = torch.bincount(dst * r + et, minlength=n * r).clamp(min=1).to(torch.float32)
         self.part, self.rank, self.num_relations, self.scheme = part, rank, r, scheme
         self.cap, self.rows_all = part.cap, part.cap * part.world
         self.num_own = int(part.counts[rank])
-        m_in = part.rank_of[dst] == rank             # in-edges of own rows, column order kept
-        m_out = part.rank_of[src] == rank            # out-edges of own rows
+        self.num_interior = int(part.num_interior[rank])
+        m_in = pt.rank_of[dst] == rank               # in-edges of own rows, column order kept
+        m_out = pt.rank_of[src] == rank              # out-edges of own rows
         self.num_in_edges, self.num_out_edges = int(m_in.sum()), int(m_out.sum())
         w_out = (1.0 / cnt[dst[m_out] * r + et[m_out]]).to(torch.float32)
+        n_int = self.num_interior
+        if split is None:
+            split = os.environ.get("RGCN_DIST_SPLIT", "1") == "1"
+        # interior / boundary halves (pull): worth two launches each only when both halves are real
+        self.split = bool(split and scheme == "pull" and part.world > 1 and n_int >= self.MIN_SPLIT_ROWS
+                          and self.cap - n_int >= self.MIN_SPLIT_ROWS)
+        to_dev = lambda t: t.to(device)                                  # noqa: E731
         # backward of both schemes: out-edges of own rows over the local table [own | halo of g]
         self.halo_out = HaloPlan(src, dst, part, rank, device)          # a node's owner reads g of its out-neighbours
-        self.g_out = backend.make_shard(part.slot_of[src[m_out]].to(device),
-                                        self.halo_out.local_index(part, rank, dst[m_out]).to(device),
-                                        et[m_out].to(device), self.cap, self.cap + self.halo_out.num_halo, r,
-                                        w_out.to(device))
+        key_out = pt.slot_of[src[m_out]]
+        oth_out = self.halo_out.local_index(part, rank, dst[m_out])
+        self.g_out = backend.make_shard(to_dev(key_out), to_dev(oth_out), to_dev(et[m_out]), self.cap,
+                                        self.cap + self.halo_out.num_halo, r, to_dev(w_out))
+        self.g_out_int = self.g_out_bnd = self.g_in_int = self.g_in_bnd = None
+        if self.split:
+            i_ = key_out < n_int                     # an interior row's out-neighbours are all own rows
+            self.g_out_int = backend.make_shard(to_dev(key_out[i_]), to_dev(oth_out[i_]), to_dev(et[m_out][i_]), n_int,
+                                                self.cap, r, to_dev(w_out[i_]))
+            self.g_out_bnd = backend.make_shard(to_dev(key_out[~i_] - n_int), to_dev(oth_out[~i_]), to_dev(et[m_out][~i_]),
+                                                self.cap - n_int, self.cap + self.halo_out.num_halo, r, to_dev(w_out[~i_]))
         if scheme == "pull":                         # forward: in-edges of own rows over [own | halo of x]
             self.halo_in = HaloPlan(dst, src, part, rank, device)       # a node's owner reads x of its in-neighbours
-            self.g_in = backend.make_shard(part.slot_of[dst[m_in]].to(device),
-                                           self.halo_in.local_index(part, rank, src[m_in]).to(device),
-                                           et[m_in].to(device), self.cap, self.cap + self.halo_in.num_halo, r)
+            key_in = pt.slot_of[dst[m_in]]
+            oth_in = self.halo_in.local_index(part, rank, src[m_in])
+            self.g_in = backend.make_shard(to_dev(key_in), to_dev(oth_in), to_dev(et[m_in]), self.cap,
+                                           self.cap + self.halo_in.num_halo, r)
+            if self.split:
+                i_ = key_in < n_int
+                self.g_in_int = backend.make_shard(to_dev(key_in[i_]), to_dev(oth_in[i_]), to_dev(et[m_in][i_]), n_int,
+                                                   self.cap, r)
+                self.g_in_bnd = backend.make_shard(to_dev(key_in[~i_] - n_int), to_dev(oth_in[~i_]), to_dev(et[m_in][~i_]),
+                                                   self.cap - n_int, self.cap + self.halo_in.num_halo, r)
             self.g_push = None
+            self.push_rows = None
         else:                                        # forward: partial sums of ALL rows from own sources
             self.halo_in = None
             self.g_in = None
-            self.g_push = backend.make_shard(part.pid[dst[m_out]].to(device), part.slot_of[src[m_out]].to(device),
-                                             et[m_out].to(device), self.rows_all, self.cap, r, w_out.to(device))
+            self.g_push = backend.make_shard(to_dev(pt.pid[dst[m_out]]), to_dev(pt.slot_of[src[m_out]]),
+                                             to_dev(et[m_out]), self.rows_all, self.cap, r, to_dev(w_out))
+            # the rows that receive a message from ANOTHER rank's source: only their partial outputs travel.  Per
+            # owner, in slot order, padded to the longest list (reduce-scatter wants equal chunks); every rank
+            # derives the same lists from the replicated edge list.
+            remote_dst = torch.unique(dst[pt.rank_of[src] != pt.rank_of[dst]])
+            remote_dst = remote_dst[torch.argsort(pt.pid[remote_dst])]
+            per_owner = torch.bincount(pt.rank_of[remote_dst], minlength=part.world)
+            width = int(per_owner.max()) if remote_dst.numel() else 0
+            start = torch.cumsum(per_owner, 0) - per_owner
+            pos = torch.arange(remote_dst.numel(), device=pd) - start[pt.rank_of[remote_dst]]
+            send = torch.full((part.world * max(width, 1),), -1, dtype=torch.int64, device=pd)
+            send[pt.rank_of[remote_dst] * max(width, 1) + pos] = pt.pid[remote_dst]
+            own_rows = remote_dst[pt.rank_of[remote_dst] == rank]
+            self.push_rows = {"width": max(width, 1), "send_pid": to_dev(send.clamp(min=0)), "send_valid": to_dev(send >= 0),
+                              "own_slots": to_dev(pt.slot_of[own_rows]), "count": int(own_rows.numel()),
+                              "total": int(remote_dst.numel())}
         remote_rows = n - self.num_own
         self.halo_fraction_in = (self.halo_in.num_halo / max(remote_rows, 1)) if self.halo_in else None
         self.halo_fraction_out = self.halo_out.num_halo / max(remote_rows, 1)
@@ -398,14 +512,34 @@ def _zero_pad_rows(g: Tensor, num_own: int) -> Tensor:
 def _layer_fwd(x, weight, root, bias, relu, shard: RankShard, backend, group):
     """one layer on this rank's rows -> (out, agg as the parameter-gradient GEMM needs it)"""
     if shard.scheme == "pull":
-        tbl = _Halo(x, shard.halo_in, group).table()
-        agg = backend.aggregate(shard.g_in, tbl)
-        return backend.transform_fwd(agg, x, weight, root, bias, relu, shard.g_in, table=tbl), agg
+        halo = _Halo(x, shard.halo_in, group)                              # in flight ...
+        if not shard.split:
+            tbl = halo.table()
+            agg = backend.aggregate(shard.g_in, tbl)
+            return backend.transform_fwd(agg, x, weight, root, bias, relu, shard.g_in, table=tbl), agg
+        # ... behind the interior rows, which read own rows only; the boundary rows follow the wait.  Both halves
+        # write row ranges of the same two tensors.
+        k = shard.num_interior
+        agg = x.new_empty(shard.cap, shard.num_relations * x.size(1))
+        out = x.new_empty(shard.cap, weight.size(2))
+        backend.aggregate(shard.g_in_int, x, out=agg[:k])
+        backend.transform_fwd(agg[:k], x[:k], weight, root, bias, relu, shard.g_in_int, table=x, out=out[:k])
+        tbl = halo.table()
+        backend.aggregate(shard.g_in_bnd, tbl, out=agg[k:])
+        backend.transform_fwd(agg[k:], x[k:], weight, root, bias, relu, shard.g_in_bnd, table=tbl, out=out[k:])
+        return out, agg
     # push: partial aggregates of ALL rows from own sources; the transform is linear, so partial outputs add
     part = backend.aggregate(shard.g_push, x)                                         # [P*cap, R*d_in]
     dummy = x.new_zeros(part.size(0), x.size(1))
     partial_out = backend.transform_fwd(part, dummy, weight, None, None, False, shard.g_push, table=x)
-    out = _reduce_scatter_rows(partial_out, shard.part.world, group)
+    world, cap, rank = shard.part.world, shard.cap, shard.rank
+    out = partial_out[rank * cap:(rank + 1) * cap].clone()          # rows no other rank's source reaches are final here
+    pr = shard.push_rows
+    if world > 1 and pr["total"] > 0:
+        # only the rows with a message from another rank's source travel: [P * width, d_out] -> this rank's [width, d_out]
+        send = partial_out.index_select(0, pr["send_pid"]) * pr["send_valid"].view(-1, 1).to(partial_out.dtype)
+        summed = _reduce_scatter_rows(send, world, group)
+        out[pr["own_slots"]] = summed[: pr["count"]]
     if root is not None:
         out = out + x @ root
     if bias is not None:
@@ -425,10 +559,34 @@ def _param_grads(agg, x, g, shard: RankShard, backend, group, has_root, has_bias
     return _flat_all_reduce([gw, x.t() @ g if has_root else None, g.sum(0) if has_bias else None], group)
 
 
-def _input_grad(g, weight, root, relu_mask, shard: RankShard, backend, group):
-    tbl = _Halo(g, shard.halo_out, group).table()
-    gagg = backend.aggregate(shard.g_out, tbl)
-    return backend.transform_bwd_input(gagg, g, weight, root, relu_mask, shard.g_out, table=tbl)
+def _input_grad(g, weight, root, relu_mask, shard: RankShard, backend, group, halo=None):
+    """``halo``: the exchange of g's rows if the caller issued it already (so that work that needs own rows only -
+    the parameter-gradient GEMM - runs while it is in flight)"""
+    halo = halo if halo is not None else _Halo(g, shard.halo_out, group)
+    if not shard.split:
+        tbl = halo.table()
+        gagg = backend.aggregate(shard.g_out, tbl)
+        return backend.transform_bwd_input(gagg, g, weight, root, relu_mask, shard.g_out, table=tbl)
+    k = shard.num_interior
+    gagg = g.new_empty(shard.cap, shard.num_relations * g.size(1))
+    gx = g.new_empty(shard.cap, weight.size(1))
+    mask_i = relu_mask[:k] if relu_mask is not None else None
+    mask_b = relu_mask[k:] if relu_mask is not None else None
+    backend.aggregate(shard.g_out_int, g, out=gagg[:k])
+    backend.transform_bwd_input(gagg[:k], g[:k], weight, root, mask_i, shard.g_out_int, table=g, out=gx[:k])
+    tbl = halo.table()
+    backend.aggregate(shard.g_out_bnd, tbl, out=gagg[k:])
+    backend.transform_bwd_input(gagg[k:], g[k:], weight, root, mask_b, shard.g_out_bnd, table=tbl, out=gx[k:])
+    return gx
+
+
+def _backward_layer(agg, x, g, weight, root, relu_mask, shard, backend, group, has_root, has_bias, need_x=True):
+    """one layer's backward: the halo exchange of g first, the parameter-gradient GEMM (own rows only) and its
+    all-reduce behind it, then the input gradient -> (pending reduction, grad_x | None)"""
+    halo = _Halo(g, shard.halo_out, group) if need_x else None
+    red = _param_grads(agg, x, g, shard, backend, group, has_root, has_bias)
+    gx = _input_grad(g, weight, root, relu_mask, shard, backend, group, halo) if need_x else None
+    return red, gx
 
 
 class _PartitionedEncoder2Function(torch.autograd.Function):
@@ -452,10 +610,11 @@ class _PartitionedEncoder2Function(torch.autograd.Function):
         shard, backend, group = ctx.shard, ctx.backend, ctx.group
         has_root1, has_b1, has_root2, has_b2 = ctx.flags
         g = _zero_pad_rows(g, shard.num_own)
-        red2 = _param_grads(agg2, h, g, shard, backend, group, has_root2, has_b2)     # all-reduce in flight ...
-        gz = _input_grad(g, w2, root2, h, shard, backend, group)                      # ... ReLU backward in the epilogue
-        red1 = _param_grads(agg1, x, gz, shard, backend, group, has_root1, has_b1)
-        gx = _input_grad(gz, w1, root1, None, shard, backend, group) if ctx.needs_input_grad[0] else None
+        # per layer: halo exchange of the gradient rows, then the parameter-gradient GEMM + its all-reduce behind it,
+        # then the input gradient (ReLU backward in its epilogue)
+        red2, gz = _backward_layer(agg2, h, g, w2, root2, h, shard, backend, group, has_root2, has_b2)
+        red1, gx = _backward_layer(agg1, x, gz, w1, root1, None, shard, backend, group, has_root1, has_b1,
+                                   need_x=ctx.needs_input_grad[0])
         _wait(red2)
         _wait(red1)
         gw2, groot2, gb2 = _unflatten(red2[1], red2[2], has_root2, has_b2)
@@ -480,8 +639,8 @@ class _PartitionedConvFunction(torch.autograd.Function):
         if ctx.relu:
             g_own = g_own * (out > 0)                                       # ReLU backward
         g_own = _zero_pad_rows(g_own, shard.num_own)
-        red = _param_grads(agg, x_own, g_own, shard, backend, group, ctx.has_root, ctx.has_bias)
-        gx = _input_grad(g_own, weight, root, None, shard, backend, group) if ctx.needs_input_grad[0] else None
+        red, gx = _backward_layer(agg, x_own, g_own, weight, root, None, shard, backend, group, ctx.has_root,
+                                  ctx.has_bias, need_x=ctx.needs_input_grad[0])
         _wait(red)
         gw, groot, gbias = _unflatten(red[1], red[2], ctx.has_root, ctx.has_bias)
         return gx, gw, groot, gbias, None, None, None, None
@@ -502,15 +661,21 @@ class PartitionedEncoder:
 
     def __init__(self, edge_index: Tensor, edge_type: Tensor, num_nodes: int, num_relations: int,
                  emb_full: Tensor, convs: Sequence[torch.nn.Module], device, backend=None, group=None,
-                 scheme: Optional[str] = None):
+                 scheme: Optional[str] = None, assignment: Optional[Tensor] = None, split: Optional[bool] = None):
+        """``assignment`` (int64 [N], optional): node -> rank from a locality-aware partitioner, identical on every
+        rank (default: the degree-balanced deal, computed on rank 0 and broadcast); ``split``: interior / boundary
+        overlap of the "pull" scheme (default on where a rank has >= 32 rows of each kind; RGCN_DIST_SPLIT=0)."""
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.group = group
         self.scheme = scheme or os.environ.get("RGCN_DIST_SCHEME", "pull")
         self.backend = backend if backend is not None else HipBackend()
-        self.part = NodePartition.shared(edge_index, num_nodes, group, device)
+        if assignment is not None:
+            self.part = NodePartition.from_assignment(assignment, edge_index, self.world)
+        else:
+            self.part = NodePartition.shared(edge_index, num_nodes, group, device)
         self.shard = RankShard(self.part, edge_index, edge_type, num_relations, self.rank, device,
-                               self.backend, self.scheme)
+                               self.backend, self.scheme, split=split)
         self.emb = self.part.shard_rows(emb_full, self.rank).to(device).requires_grad_(True)
         self.convs: List[torch.nn.Module] = [c.to(device) for c in convs]
         self.params = [self.emb] + [p for c in self.convs for p in c.parameters()]
@@ -519,6 +684,8 @@ class PartitionedEncoder:
         """rows this rank receives per exchange, as a fraction of the rows it does not own"""
         s = self.shard
         return {"scheme": self.scheme, "rows_own": s.num_own, "rows_remote": self.part.num_nodes - s.num_own,
+                "rows_interior": s.num_interior, "interior_boundary_split": s.split,
+                "push_rows_exchanged": (s.push_rows["total"] if s.push_rows else None),
                 "halo_rows_forward": s.halo_in.num_halo if s.halo_in else None,
                 "halo_fraction_forward": s.halo_fraction_in,
                 "halo_rows_backward": s.halo_out.num_halo, "halo_fraction_backward": s.halo_fraction_out}
