@@ -82,23 +82,21 @@ def parse_args():
     return ap.parse_args()
 
 
-def gather_bytes(num_edges, num_nodes, num_relations, d, weighted):
+def gather_bytes(num_edges, segments, d, weighted):
     """Algorithmic bytes of ONE level-0 gather launch that materialises its output
     (SURVEY.md section 8d / DESIGN.md): every edge reads one d-float row + a 4-byte column id
     (+ a 4-byte 1/cnt weight in the transposed form), plus rowptr and cnt once, plus the
-    [N*R, d] output written once."""
-    nr = num_nodes * num_relations
-    b = num_edges * (4 * d + 4) + 4 * (nr + 1) + 4 * nr * d
-    b += 4 * num_edges if weighted else 4 * nr
+    [segments = N*R, d] output written once."""
+    b = num_edges * (4 * d + 4) + 4 * (segments + 1) + 4 * segments * d
+    b += 4 * num_edges if weighted else 4 * segments
     return b
 
 
-def gather_compulsory_bytes(num_edges, num_nodes, num_relations, d, weighted):
+def gather_compulsory_bytes(num_edges, segments, table_rows, d, weighted):
     """What HBM must move for that launch if every cache were perfect: the row table ONCE, the ids
     (and weights) once, rowptr / cnt once, the output once."""
-    nr = num_nodes * num_relations
-    b = 4 * num_nodes * d + 4 * num_edges + 4 * (nr + 1) + 4 * nr * d
-    b += 4 * num_edges if weighted else 4 * nr
+    b = 4 * table_rows * d + 4 * num_edges + 4 * (segments + 1) + 4 * segments * d
+    b += 4 * num_edges if weighted else 4 * segments
     return b
 
 
@@ -330,21 +328,20 @@ def event_overhead_us(world):
 def kernel_tables(run, events, event_steps):
     """-> (gather + fused kernels, transform calls) as lists of dicts from the three event lists"""
     gather_events, gemm_events, fused_events = events
-    r = run.r
     kernels = []
     per, shape = {}, {}
-    for transposed, d, edges, segments, beg, end in gather_events:
+    for transposed, d, edges, segments, table_rows, beg, end in gather_events:
         per.setdefault((transposed, d), []).append(beg.elapsed_time(end) * 1e-3)   # seconds
-        shape[(transposed, d)] = (edges, segments)
+        shape[(transposed, d)] = (edges, segments, table_rows)
     for (transposed, d), ts in sorted(per.items()):
         avg = sum(ts) / len(ts)
-        edges, segments = shape[(transposed, d)]
-        nbytes = gather_bytes(edges, segments // r, r, d, transposed)
-        comp = gather_compulsory_bytes(edges, segments // r, r, d, transposed)
+        edges, segments, table_rows = shape[(transposed, d)]
+        nbytes = gather_bytes(edges, segments, d, transposed)
+        comp = gather_compulsory_bytes(edges, segments, table_rows, d, transposed)
         kernels.append({"kernel": f"k_aggregate<{d // 4},{'true' if transposed else 'false'}>", "kind": "gather",
                         "d": d, "transposed": transposed, "launches_per_step": len(ts) // event_steps,
                         "avg_us": avg * 1e6, "bytes": nbytes, "gbs": nbytes / avg / 1e9,
-                        "compulsory_hbm_bytes": comp, "table_bytes": 4 * (segments // r) * d,
+                        "compulsory_hbm_bytes": comp, "table_bytes": 4 * table_rows * d,
                         "total_us_per_step": sum(ts) / event_steps * 1e6})
     # the one-kernel layers (gather into LDS + transform): algorithmic bytes = what the gather and the rows in /
     # out cost - there is no aggregate write + read; "+store": the kept aggregate's one write

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 16
+#define RGCN_ABI_VERSION 17
 
 enum {
   RGCN_OK = 0,
@@ -482,6 +482,37 @@ int rgcn_adam_clip_step(int num_tensors, float* const* params, const float* cons
 int distmult_rank_tails(const float* hr, const float* emb, const float* true_score,
                         const int64_t* tail, int64_t batch, int64_t num_entities, int64_t d,
                         int32_t* beaten_by, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * A recorded pass issued by ONE call.  The reference re-runs its encoder from Python for every 1,024-edge batch
+ * (src/train.py:291-297, src/models/rgcn.py:123,128); on a static graph the launches of a pass are the same list
+ * every time and only the addresses of the step's tensors change.  `calls` names entry points of THIS header and
+ * where their arguments sit in `args`; an argument is a constant, the bits of a double (float parameters), an
+ * address relative to one of the caller's `bases` (the pass's buffers: its arena, its inputs), one of the call's
+ * own rgcn_slab_job slots (filled by a *_begin call, consumed by a later one), the run's stream, or a HOST array
+ * whose entries (constants / base-relative addresses) follow at args[index .. index + value).  The calls are
+ * issued in order on `stream`; the first non-zero return code ends the run and is returned.  Nothing is
+ * allocated, nothing synchronises: capturable like the calls it forwards to.
+ * ---------------------------------------------------------------------------------- */
+enum { RGCN_SEQ_IMM = 0, RGCN_SEQ_FLOAT = 1, RGCN_SEQ_BASE = 2, RGCN_SEQ_JOB = 3, RGCN_SEQ_STREAM = 4, RGCN_SEQ_ARRAY = 5 };
+enum {
+  RGCN_FN_ABSMAX = 0, RGCN_FN_ABSMAX_MULTI, RGCN_FN_ABSMAX_PACK, RGCN_FN_WEIGHTS_SPLIT_PACK_MULTI, RGCN_FN_AGGREGATE,
+  RGCN_FN_AGGREGATE_AND_REDUCE, RGCN_FN_AGGREGATE_AMAX, RGCN_FN_AGGREGATE_DEFERRED, RGCN_FN_TRANSFORM_FWD_SPLIT,
+  RGCN_FN_TRANSFORM_BWD_INPUT_SPLIT, RGCN_FN_TRANSFORM_FIRST_SPLIT, RGCN_FN_TRANSFORM_BWD_PARAMS_SPLIT_BEGIN,
+  RGCN_FN_SLAB_REDUCE, RGCN_FN_LAYER_FWD_FUSED, RGCN_FN_LAYER_BWD_INPUT_FUSED, RGCN_FN_COUNT
+};
+typedef struct rgcn_seq_arg {
+  int32_t kind;  /* RGCN_SEQ_* */
+  int32_t index; /* BASE: which base; JOB: which slot; ARRAY: first entry in args */
+  int64_t value; /* IMM: the value; FLOAT: bits of a double; BASE: byte offset; ARRAY: number of entries */
+} rgcn_seq_arg;
+typedef struct rgcn_seq_call {
+  int32_t fn;        /* RGCN_FN_* */
+  int32_t num_args;  /* exactly the parameter count of that entry point */
+  int64_t first_arg; /* index of its first argument in args */
+} rgcn_seq_call;
+int rgcn_sequence_run(const rgcn_seq_call* calls, int num_calls, const rgcn_seq_arg* args, int64_t num_args,
+                      void* const* bases, int num_bases, void* stream);
 
 #ifdef __cplusplus
 }

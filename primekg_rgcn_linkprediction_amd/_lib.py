@@ -13,7 +13,7 @@ from ctypes import c_float, POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -32,6 +32,31 @@ class SlabJob(ctypes.Structure):
     _fields_ = [("slab", c_void_p), ("bias_part", c_void_p), ("splits", ctypes.c_int32), ("K1", ctypes.c_int32),
                 ("Kc", ctypes.c_int32), ("N", ctypes.c_int32), ("grad_weight", c_void_p), ("grad_root", c_void_p),
                 ("grad_bias", c_void_p)]
+
+
+class SeqArg(ctypes.Structure):
+    """``rgcn_seq_arg``"""
+    _fields_ = [("kind", ctypes.c_int32), ("index", ctypes.c_int32), ("value", ctypes.c_int64)]
+
+
+class SeqCall(ctypes.Structure):
+    """``rgcn_seq_call``"""
+    _fields_ = [("fn", ctypes.c_int32), ("num_args", ctypes.c_int32), ("first_arg", ctypes.c_int64)]
+
+
+SEQ_IMM, SEQ_FLOAT, SEQ_BASE, SEQ_JOB, SEQ_STREAM, SEQ_ARRAY = range(6)
+# entry points rgcn_sequence_run can forward to (RGCN_FN_* of the header, in its order)
+SEQ_FUNCTIONS = ("rgcn_absmax", "rgcn_absmax_multi", "rgcn_absmax_pack", "rgcn_weights_split_pack_multi", "rgcn_aggregate",
+                 "rgcn_aggregate_and_reduce", "rgcn_aggregate_amax", "rgcn_aggregate_deferred", "rgcn_transform_fwd_split",
+                 "rgcn_transform_bwd_input_split", "rgcn_transform_first_split", "rgcn_transform_bwd_params_split_begin",
+                 "rgcn_slab_reduce", "rgcn_layer_fwd_fused", "rgcn_layer_bwd_input_fused")
+# their HOST array parameters: position -> (entries are device pointers?, position of the parameter holding the count)
+SEQ_HOST_ARRAYS = {
+    "rgcn_absmax_multi": {1: (True, 0), 2: (False, 0), 3: (True, 0)},
+    "rgcn_absmax_pack": {6: (True, 5), 7: (True, 5), 8: (False, 5), 9: (False, 5), 10: (False, 5), 11: (True, 5), 12: (False, 5)},
+    "rgcn_weights_split_pack_multi": {1: (True, 0), 2: (True, 0), 3: (False, 0), 4: (False, 0), 5: (False, 0), 6: (True, 0),
+                                      7: (True, 0), 8: (True, 0), 9: (False, 0)},
+}
 
 
 # name -> (restype, argtypes); mirrors include/rgcn_hip.h one to one
@@ -89,6 +114,7 @@ PROTOTYPES = {
     "rgcn_layer_bwd_input_fused_supported": (c_int, [_I64, _I64, _I64]),
     "rgcn_layer_bwd_input_fused": (c_int, [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, c_int, _P, _I64, _I64, _P, c_float, _P, _P,
                                            _P, c_float]),
+    "rgcn_sequence_run": (c_int, [_P, c_int, _P, _I64, _P, c_int, _P]),
     "distmult_fwd": (c_int, [_P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P]),
     "rgcn_index_error_fetch": (c_int, [POINTER(c_int), _P]),
     "distmult_bwd_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),

@@ -36,7 +36,10 @@ def _table(x: Tensor, gather_dtype) -> Tensor:
     """the FEATURE table the forward gather reads: x itself, or its fp16 copy (configs[4]:
     "fp16 features + fp32 accumulate").  Gradient tables stay fp32: they span many orders of
     magnitude and would need loss scaling to survive fp16."""
-    return x if gather_dtype in (None, torch.float32) else x.to(gather_dtype)
+    if gather_dtype in (None, torch.float32):
+        return x
+    ops.guard_torch_op("fp16 copy of the feature table")
+    return x.to(gather_dtype)
 
 
 class _BasisCompose(torch.autograd.Function):
@@ -74,7 +77,7 @@ class _Scales:
         self._buf, self._next, self.first = None, 1, None
         self.packed = [None] * len(layers)
         if ops.GEMM_PRECISION == "split":
-            self._buf = torch.empty(slots, ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
+            self._buf = ops._empty(slots, ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
             self.first = self._buf[0]
             if layers:
                 self.packed = ops.absmax_and_split(t, self.first, self._buf[1:slots], list(layers))
@@ -137,6 +140,7 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
     if from_packed:
         t = ops.transform_first(g.contiguous(), packed, g_amax)                   # from the step's split weights: no cat, no second split
     else:
+        ops.guard_torch_op("weight concatenation of the transform-first input gradient")
         wcat = torch.cat([weight.reshape(r * d_in, d_out), root]).view(1, (r + 1) * d_in, d_out)
         t = ops.transform_bwd_input(g, g, wcat, None, amax=(g_amax, None), precision=precision)   # [N, (R+1) d_in] = g @ wcat^T
     return ops.aggregate(merged, t.view(-1, d_in), tail=tail)
@@ -171,7 +175,7 @@ def _layer_train_forward(graph: "ops.BucketedGraph", x: Tensor, gather_dtype, we
     fused = _TRAIN_FUSED == "1" or (_TRAIN_FUSED == "auto" and n * r * d_in * 4 >= _TRAIN_FUSED_MIN_BYTES)
     if (fused and not half and packed is not None and x_amax is not None and not graph.weighted_shard
             and n == graph.num_other_nodes and ops.fused_supported(r, d_in, d_out)):
-        agg = torch.empty(n, r * d_in, dtype=torch.float32, device=x.device)
+        agg = ops._empty(n, r * d_in, dtype=torch.float32, device=x.device)
         out = ops.layer_fwd_fused(graph, x, packed, bias, relu, x_amax, amax_out, inline_limit=_EVAL_INLINE_LIMIT,
                                   agg_out=agg)
         return agg, out
@@ -233,6 +237,81 @@ class _RGCNConvFunction(torch.autograd.Function):
         return gx, gw, groot, gbias, None, None, None, None
 
 
+def _packs(bufs, layers):
+    return [ops.SplitWeights(b, w, root) if b is not None else None for b, (w, root) in zip(bufs, layers)]
+
+
+def _enc2_layer1(x, w1, root1, b1, w2, root2, *, graph, gather_dtype, half):
+    """first launch of the pass (max |x|, cleared amax slots, both layers' split weights) + conv1 with its ReLU
+    -> (h, agg1, amax buffers [x | h], split images of conv1, of conv2)"""
+    scales = _Scales(x, layers=[(w1, root1), (w2, root2)])       # ONE launch
+    x_amax, h_amax = scales.first, scales.slot()
+    pk1, pk2 = scales.packed                                      # once, for forward and backward
+    agg1, h = _layer_train_forward(graph, x, gather_dtype, w1, root1, b1, True, half, x_amax, h_amax, pk1)
+    return h, agg1, scales._buf, (pk1.buf if pk1 is not None else None), (pk2.buf if pk2 is not None else None)
+
+
+def _enc2_layer2(h, w2, root2, b2, h_amax, pk2buf, *, graph, gather_dtype, half):
+    pk2 = _packs([pk2buf], [(w2, root2)])[0]
+    agg2, out = _layer_train_forward(graph, h, gather_dtype, w2, root2, b2, False, half, h_amax, None, pk2)
+    return out, agg2
+
+
+def _enc2_forward(x, w1, root1, b1, w2, root2, b2, *, graph, gather_dtype, half):
+    """both layers (no dropout between them) as one pass -> (out, h, agg1, agg2, amax buffers, images 1, images 2)"""
+    h, agg1, amax, pk1buf, pk2buf = _enc2_layer1(x, w1, root1, b1, w2, root2, graph=graph, gather_dtype=gather_dtype, half=half)
+    out, agg2 = _enc2_layer2(h, w2, root2, b2, amax[1] if amax is not None else None, pk2buf, graph=graph,
+                             gather_dtype=gather_dtype, half=half)
+    return out, h, agg1, agg2, amax, pk1buf, pk2buf
+
+
+def _enc2_backward(x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax, pk1buf, pk2buf, g, *, graph, flags, p,
+                   prec, need_x):
+    """the whole backward of conv1 -> ReLU -> [dropout p] -> conv2 -> (gx | None, gw1, groot1, gb1, gw2, groot2, gb2)"""
+    r = graph.num_relations
+    has_root1, has_b1, has_root2, has_b2 = flags
+    pk1, pk2 = _packs([pk1buf, pk2buf], [(w1, root1), (w2, root2)])
+    scales = _Scales(g)
+    g_amax, gz_amax = scales.first, scales.slot()
+    wb = graph.weight_bound(True)        # |transposed aggregate| <= wb * max |gradient table|
+    # the slab reductions of the parameter gradients ride in the transposed gathers that follow them
+    red2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2, graph=graph,
+                                    defer=True, amax=(h_amax, h_amax, g_amax), precision=prec)
+    # dropout backward: the factor 1 / (1 - p) goes into the input-gradient epilogue as a scalar (the mask is h itself,
+    # positive exactly where a unit is active and kept) - the weights keep their split images and the hub deferral
+    scale = 1.0 / (1.0 - p) if p > 0 else 1.0
+    if _fused_backward(graph, g, r, w2.size(1), w2.size(2), g_amax, pk2, prec):
+        gz = ops.layer_bwd_input_fused(graph, g, pk2, h, g_amax, amax_out=gz_amax, inline_limit=_EVAL_INLINE_LIMIT,
+                                       tail=red2, out_scale=scale)
+    else:
+        if _defer_hubs(False, pk2, g_amax, w2.size(2), w2.size(1)) and not graph.bipartite:
+            gagg2, hubs2 = ops.aggregate_deferred(graph, g, transposed=True, tail=red2)
+        else:
+            gagg2, hubs2 = ops.aggregate(graph, g, transposed=True, tail=red2), None
+        gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph, amax=(g_amax, g_amax),
+                                     amax_mul=wb, amax_out=gz_amax, packed=pk2, precision=prec, hubs=hubs2,
+                                     out_scale=scale)   # d loss / d (pre-ReLU of conv1)
+    red1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1, graph=graph,
+                                    defer=True, amax=(x_amax, x_amax, gz_amax), precision=prec)
+    gx = None
+    if need_x:
+        gx = _input_grad(graph, gz, w1, root1, tail=red1, g_amax=gz_amax, scales=scales, packed=pk1, precision=prec)
+    red2.finish()
+    red1.finish()
+    (gw2, groot2, gb2), (gw1, groot1, gb1) = red2.grads, red1.grads
+    return gx, gw1, groot1, gb1, gw2, groot2, gb2
+
+
+_R_LAYER1 = ops.Region("encoder2.layer1", _enc2_layer1)
+_R_LAYER2 = ops.Region("encoder2.layer2", _enc2_layer2)
+_R_FORWARD = ops.Region("encoder2.forward", _enc2_forward)
+_R_BACKWARD = ops.Region("encoder2.backward", _enc2_backward)
+
+
+def _policy_key():
+    return (_TRAIN_FUSED, _DEFER_HUBS, _TRANSFORM_FIRST_RATIO, _EVAL_INLINE_LIMIT, _TRAIN_FUSED_MIN_BYTES)
+
+
 class _Encoder2Function(torch.autograd.Function):
     """conv1 -> ReLU -> [dropout] -> conv2 (``src/models/rgcn.py:123-128``) as one autograd
     node: the ReLU rides in conv1's GEMM epilogue, and its backward rides in the epilogue of
@@ -244,7 +323,10 @@ class _Encoder2Function(torch.autograd.Function):
     activations ``hd = relu(z) * m / (1-p)`` are positive exactly where the unit is both active
     and kept, so ``hd`` is the epilogue mask, and the factor ``1/(1-p)`` is one more scalar of that
     GEMM's epilogue (``out_scale``): the step's split weight images and the hub deferral serve
-    the dropout case unchanged."""
+    the dropout case unchanged.
+
+    Forward and backward are ``ops.Region`` passes: after three steps on a graph their launches are
+    issued by one native call each (``rgcn_sequence_run``) instead of ~14 wrapper calls."""
 
     @staticmethod
     def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph, gather_dtype=None, p: float = 0.0,
@@ -252,65 +334,52 @@ class _Encoder2Function(torch.autograd.Function):
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
         root1 = root1.contiguous() if root1 is not None else None
         root2 = root2.contiguous() if root2 is not None else None
-        ctx.gather_dtype = gather_dtype
+        b1 = b1.contiguous() if b1 is not None else None
+        b2 = b2.contiguous() if b2 is not None else None
         half = gather_dtype == torch.float16          # configs[4]: fp16 operands on the fp16 matrix cores too
         # configs[4] backward: the three gradient GEMMs per layer in ONE fp16 pass (operands rounded under their
         # per-tensor power-of-two scales = loss scaling per tensor, fp32 accumulate); the gradient gathers stay fp32
         ctx.bwd_precision = "half" if (half and half_backward and ops.GEMM_PRECISION == "split") else None
-        # operand scales of the split-precision transforms: max |.| of every dense tensor, left behind by
-        # the kernel that produced it (one zeroed buffer per pass); None throughout in fp32 / fp16 mode
+        static = dict(graph=graph, gather_dtype=gather_dtype, half=half)
+        key = (tuple(x.shape), tuple(w1.shape), tuple(w2.shape), root1 is not None, b1 is not None, root2 is not None,
+               b2 is not None, gather_dtype, _policy_key())
         # A dense tensor's maximum is left behind by the launch that produces it (the first launch of the pass
         # for x, the epilogue of conv1's transform for h); an aggregate is scaled by the bound its table's
         # maximum gives (a mean of rows cannot exceed it), so the gathers publish nothing.
-        scales = _Scales(x, layers=[(w1, root1), (w2, root2)])       # ONE launch: max |x|, cleared slots, both layers' split weights
-        x_amax, h_amax = scales.first, scales.slot()
-        pk1, pk2 = scales.packed                                      # once, for forward and backward
-        agg1, h = _layer_train_forward(graph, x, gather_dtype, w1, root1, b1, True, half, x_amax, h_amax, pk1)
         if p > 0:
+            h, agg1, amax, pk1buf, pk2buf = _R_LAYER1.run(graph, key, (x, w1, root1, b1, w2, root2), static, want={0, 2})
             h = torch.native_dropout(h, p, True)[0]
-            h_amax = h_amax * (1.0 / (1.0 - p)) if h_amax is not None else None     # kept units are scaled up
-        agg2, out = _layer_train_forward(graph, h, gather_dtype, w2, root2, b2, False, half, h_amax, None, pk2)
-        ctx.graph, ctx.p, ctx.packed = graph, p, (pk1, pk2)
+            h_amax = amax[1] * (1.0 / (1.0 - p)) if amax is not None else None      # kept units are scaled up
+            x_amax = amax[0] if amax is not None else None
+            out, agg2 = _R_LAYER2.run(graph, key, (h, w2, root2, b2, h_amax, pk2buf), static, want={0})
+        else:
+            out, h, agg1, agg2, amax, pk1buf, pk2buf = _R_FORWARD.run(graph, key, (x, w1, root1, b1, w2, root2, b2),
+                                                                     static, want={0})
+            x_amax = h_amax = None
+            if amax is not None:                      # rows 0 / 1 of the amax allocation, as tensors or as arena offsets
+                if isinstance(amax, ops.Lazy):
+                    row = ops.AMAX_FLOATS * 4
+                    x_amax = ops.Lazy(amax.arena, amax.offset, (ops.AMAX_FLOATS,), torch.float32)
+                    h_amax = ops.Lazy(amax.arena, amax.offset + row, (ops.AMAX_FLOATS,), torch.float32)
+                else:
+                    x_amax, h_amax = amax[0], amax[1]
+        ctx.graph, ctx.p, ctx.key = graph, p, key
         ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
-        ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax)
+        ctx.save_for_backward(x, w1, root1, w2, root2)           # the node's inputs (autograd checks their versions)
+        ctx.kept = (agg1, h, agg2, x_amax, h_amax, pk1buf, pk2buf)   # tensors, or arena offsets of a replayed pass
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax = ctx.saved_tensors
-        graph, r = ctx.graph, ctx.graph.num_relations
-        has_root1, has_b1, has_root2, has_b2 = ctx.flags
+        x, w1, root1, w2, root2 = ctx.saved_tensors
+        agg1, h, agg2, x_amax, h_amax, pk1buf, pk2buf = ctx.kept
         g = g.contiguous()
-        scales = _Scales(g)
-        g_amax, gz_amax = scales.first, scales.slot()
-        pk1, pk2 = ctx.packed
-        wb = graph.weight_bound(True)        # |transposed aggregate| <= wb * max |gradient table|
-        # the slab reductions of the parameter gradients ride in the transposed gathers that follow them
-        prec = ctx.bwd_precision
-        red2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2, graph=graph,
-                                        defer=True, amax=(h_amax, h_amax, g_amax), precision=prec)
-        # dropout backward: the factor 1 / (1 - p) goes into the input-gradient epilogue as a scalar (the mask is h itself,
-        # positive exactly where a unit is active and kept) - the weights keep their split images and the hub deferral
-        scale = 1.0 / (1.0 - ctx.p) if ctx.p > 0 else 1.0
-        if _fused_backward(graph, g, r, w2.size(1), w2.size(2), g_amax, pk2, prec):
-            gz = ops.layer_bwd_input_fused(graph, g, pk2, h, g_amax, amax_out=gz_amax, inline_limit=_EVAL_INLINE_LIMIT,
-                                           tail=red2, out_scale=scale)
-        else:
-            if _defer_hubs(False, pk2, g_amax, w2.size(2), w2.size(1)) and not graph.bipartite:
-                gagg2, hubs2 = ops.aggregate_deferred(graph, g, transposed=True, tail=red2)
-            else:
-                gagg2, hubs2 = ops.aggregate(graph, g, transposed=True, tail=red2), None
-            gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph, amax=(g_amax, g_amax),
-                                         amax_mul=wb, amax_out=gz_amax, packed=pk2, precision=prec, hubs=hubs2,
-                                         out_scale=scale)   # d loss / d (pre-ReLU of conv1)
-        red1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1, graph=graph,
-                                        defer=True, amax=(x_amax, x_amax, gz_amax), precision=prec)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = _input_grad(graph, gz, w1, root1, tail=red1, g_amax=gz_amax, scales=scales, packed=pk1, precision=prec)
-        red2.finish()
-        red1.finish()
-        (gw2, groot2, gb2), (gw1, groot1, gb1) = red2.grads, red1.grads
+        need_x = bool(ctx.needs_input_grad[0])
+        static = dict(graph=ctx.graph, flags=ctx.flags, p=ctx.p, prec=ctx.bwd_precision, need_x=need_x)
+        grads = _R_BACKWARD.run(ctx.graph, (ctx.key, ctx.p, need_x, ctx.bwd_precision),
+                                (x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax, pk1buf, pk2buf, g), static,
+                                want={0, 1, 2, 3, 4, 5, 6})
+        gx, gw1, groot1, gb1, gw2, groot2, gb2 = grads
         return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None, None, None
 
 
@@ -354,13 +423,13 @@ def _layer_eval_blocked(graph: "ops.BucketedGraph", x: Tensor, table: Tensor, we
             and x.size(0) == graph.num_other_nodes and ops.fused_supported(r, d_in, d_out)):
         return ops.layer_fwd_fused(graph, x, packed, bias, relu, amax[1], amax_out, inline_limit=_EVAL_INLINE_LIMIT)
     rows = max(32, _EVAL_BLOCK_BYTES // max(1, r * d_in * 4))
-    out = torch.empty(n, d_out, dtype=torch.float32, device=x.device)
+    out = ops._empty(n, d_out, dtype=torch.float32, device=x.device)
     if rows >= n:                                   # one block: the plain two launches, a temporary aggregate
         agg = ops.aggregate(graph, table)
         return ops.transform_fwd(agg, x, weight, root, bias, relu=relu, graph=graph, half=half, amax=amax,
                                  amax_out=amax_out, packed=packed, out=out)
     blocks = graph.row_blocks(rows)
-    buf = torch.empty(blocks[0][1] - blocks[0][0], r * d_in, dtype=torch.float32, device=x.device)
+    buf = ops._empty(blocks[0][1] - blocks[0][0], r * d_in, dtype=torch.float32, device=x.device)
     for lo, hi, shard in blocks:
         agg = ops.aggregate(shard, table, out=buf[: hi - lo])
         ops.transform_fwd(agg, x[lo:hi], weight, root, bias, relu=relu, graph=shard, half=half, amax=amax,

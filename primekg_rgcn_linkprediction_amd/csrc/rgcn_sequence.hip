@@ -1,0 +1,148 @@
+// rgcn_sequence_run: a recorded, FIXED list of this library's launches issued by one C call.
+//
+// The reference runs its layer from Python (src/models/rgcn.py:123,128, once per 1,024-edge batch:
+// src/train.py:291-297); so does this package - but on a static graph the launches of one pass are the same list
+// every step, only the addresses of the step's tensors change.  The host side (ops.Region) records that list once
+// (which entry point, which arguments), classifies every pointer argument as constant (graph structures, handles)
+// or as base + offset into one of the step's buffers (the pass's arena, its inputs), and from then on issues the
+// whole pass with ONE call into this function: ~14 ctypes calls, their argument checks and a dozen allocations
+// become one call and one allocation (host time per eager encoder step: DESIGN.md section 7).
+// Nothing here computes: every case below forwards to the entry point of include/rgcn_hip.h it names.
+#include <string.h>
+
+#include "rgcn_common.h"
+
+namespace {
+
+constexpr int kMaxArgs = 32, kMaxJobs = 8, kMaxArrayEntries = 8, kMaxArrays = 8;
+
+struct Resolved {
+  uint64_t v[kMaxArgs];
+};
+
+inline float as_float(uint64_t bits) {
+  double d;
+  memcpy(&d, &bits, 8);
+  return (float)d;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rgcn_sequence_run(const rgcn_seq_call* calls, int num_calls, const rgcn_seq_arg* args, int64_t num_args,
+                      void* const* bases, int num_bases, void* stream) {
+  if (num_calls < 0 || num_args < 0 || (num_calls > 0 && (!calls || !args)) || num_bases < 0 || (num_bases > 0 && !bases))
+    return RGCN_ERR_ARG;
+  rgcn_slab_job jobs[kMaxJobs];
+  for (auto& j : jobs) j = rgcn_slab_job{};
+  for (int c = 0; c < num_calls; ++c) {
+    const rgcn_seq_call& call = calls[c];
+    if (call.num_args < 0 || call.num_args > kMaxArgs || call.first_arg < 0 || call.first_arg + call.num_args > num_args)
+      return RGCN_ERR_ARG;
+    Resolved r;
+    uint64_t arrays[kMaxArrays][kMaxArrayEntries];
+    int used_arrays = 0;
+    for (int i = 0; i < call.num_args; ++i) {
+      const rgcn_seq_arg& a = args[call.first_arg + i];
+      switch (a.kind) {
+        case RGCN_SEQ_IMM: r.v[i] = (uint64_t)a.value; break;
+        case RGCN_SEQ_FLOAT: r.v[i] = (uint64_t)a.value; break;                 // the bits of a double
+        case RGCN_SEQ_BASE:
+          if (a.index < 0 || a.index >= num_bases) return RGCN_ERR_ARG;
+          r.v[i] = (uint64_t)((char*)bases[a.index] + a.value);
+          break;
+        case RGCN_SEQ_JOB:
+          if (a.index < 0 || a.index >= kMaxJobs) return RGCN_ERR_ARG;
+          r.v[i] = (uint64_t)&jobs[a.index];
+          break;
+        case RGCN_SEQ_STREAM: r.v[i] = (uint64_t)stream; break;
+        case RGCN_SEQ_ARRAY: {                       // a HOST array argument: its `value` entries start at args[index]
+          if (used_arrays >= kMaxArrays || a.value < 0 || a.value > kMaxArrayEntries || a.index < 0 ||
+              a.index + a.value > num_args)
+            return RGCN_ERR_ARG;
+          uint64_t* dst = arrays[used_arrays++];
+          for (int64_t k = 0; k < a.value; ++k) {
+            const rgcn_seq_arg& e = args[a.index + k];
+            if (e.kind == RGCN_SEQ_IMM) dst[k] = (uint64_t)e.value;
+            else if (e.kind == RGCN_SEQ_BASE && e.index >= 0 && e.index < num_bases) dst[k] = (uint64_t)((char*)bases[e.index] + e.value);
+            else return RGCN_ERR_ARG;
+          }
+          r.v[i] = (uint64_t)dst;
+          break;
+        }
+        default: return RGCN_ERR_ARG;
+      }
+    }
+#define P(i) ((void*)r.v[i])
+#define CF(i) ((const float*)r.v[i])
+#define MF(i) ((float*)r.v[i])
+#define I(i) ((int64_t)r.v[i])
+#define F(i) (as_float(r.v[i]))
+#define G(i) ((const rgcn_graph*)r.v[i])
+#define J(i) ((rgcn_slab_job*)r.v[i])
+#define NEED(n) if (call.num_args != (n)) return RGCN_ERR_ARG
+    int rc = RGCN_OK;
+    switch (call.fn) {
+      case RGCN_FN_ABSMAX: NEED(6);
+        rc = rgcn_absmax(CF(0), I(1), MF(2), MF(3), (int)I(4), P(5)); break;
+      case RGCN_FN_ABSMAX_MULTI: NEED(7);
+        rc = rgcn_absmax_multi((int)I(0), (const float* const*)P(1), (const int64_t*)P(2), (float* const*)P(3), MF(4),
+                               (int)I(5), P(6)); break;
+      case RGCN_FN_ABSMAX_PACK: NEED(14);
+        rc = rgcn_absmax_pack(CF(0), I(1), MF(2), MF(3), (int)I(4), (int)I(5), (const float* const*)P(6),
+                              (const float* const*)P(7), (const int64_t*)P(8), (const int64_t*)P(9), (const int64_t*)P(10),
+                              (void* const*)P(11), (const size_t*)P(12), P(13)); break;
+      case RGCN_FN_WEIGHTS_SPLIT_PACK_MULTI: NEED(11);
+        rc = rgcn_weights_split_pack_multi((int)I(0), (const float* const*)P(1), (const float* const*)P(2),
+                                           (const int64_t*)P(3), (const int64_t*)P(4), (const int64_t*)P(5),
+                                           (const float* const*)P(6), (const float* const*)P(7), (void* const*)P(8),
+                                           (const size_t*)P(9), P(10)); break;
+      case RGCN_FN_AGGREGATE: NEED(8);
+        rc = rgcn_aggregate(G(0), (int)I(1), CF(2), I(3), MF(4), P(5), (size_t)I(6), P(7)); break;
+      case RGCN_FN_AGGREGATE_AND_REDUCE: NEED(9);
+        rc = rgcn_aggregate_and_reduce(G(0), (int)I(1), CF(2), I(3), MF(4), P(5), (size_t)I(6), J(7), P(8)); break;
+      case RGCN_FN_AGGREGATE_AMAX: NEED(10);
+        rc = rgcn_aggregate_amax(G(0), (int)I(1), CF(2), I(3), MF(4), P(5), (size_t)I(6), J(7), MF(8), P(9)); break;
+      case RGCN_FN_AGGREGATE_DEFERRED: NEED(9);
+        rc = rgcn_aggregate_deferred(G(0), (int)I(1), CF(2), I(3), MF(4), P(5), (size_t)I(6), J(7), P(8)); break;
+      case RGCN_FN_TRANSFORM_FWD_SPLIT: NEED(24);
+        rc = rgcn_transform_fwd_split(CF(0), CF(1), CF(2), CF(3), P(4), CF(5), (int)I(6), (const uint32_t*)P(7), I(8), I(9),
+                                      I(10), I(11), CF(12), F(13), CF(14), (int)I(15), MF(16), MF(17), P(18), (size_t)I(19),
+                                      P(20), G(21), (int)I(22), MF(23)); break;
+      case RGCN_FN_TRANSFORM_BWD_INPUT_SPLIT: NEED(24);
+        rc = rgcn_transform_bwd_input_split(CF(0), CF(1), CF(2), CF(3), P(4), CF(5), (const uint32_t*)P(6), I(7), I(8), I(9),
+                                            I(10), CF(11), F(12), CF(13), (int)I(14), MF(15), MF(16), P(17), (size_t)I(18),
+                                            P(19), G(20), (int)I(21), MF(22), F(23)); break;
+      case RGCN_FN_TRANSFORM_FIRST_SPLIT: NEED(13);
+        rc = rgcn_transform_first_split(CF(0), P(1), (int)I(2), I(3), I(4), I(5), I(6), CF(7), (int)I(8), MF(9), P(10),
+                                        (size_t)I(11), P(12)); break;
+      case RGCN_FN_TRANSFORM_BWD_PARAMS_SPLIT_BEGIN: NEED(20);
+        rc = rgcn_transform_bwd_params_split_begin(CF(0), CF(1), CF(2), (const uint32_t*)P(3), I(4), I(5), I(6), I(7), CF(8),
+                                                   F(9), CF(10), CF(11), (int)I(12), MF(13), MF(14), MF(15), P(16),
+                                                   (size_t)I(17), P(18), J(19)); break;
+      case RGCN_FN_SLAB_REDUCE: NEED(2);
+        rc = rgcn_slab_reduce(J(0), P(1)); break;
+      case RGCN_FN_LAYER_FWD_FUSED: NEED(18);
+        rc = rgcn_layer_fwd_fused((const int32_t*)P(0), (const int32_t*)P(1), (const uint32_t*)P(2), I(3), I(4), CF(5), CF(6),
+                                  P(7), (int)I(8), CF(9), (int)I(10), I(11), I(12), CF(13), MF(14), MF(15), MF(16), P(17)); break;
+      case RGCN_FN_LAYER_BWD_INPUT_FUSED: NEED(19);
+        rc = rgcn_layer_bwd_input_fused((const int32_t*)P(0), (const int32_t*)P(1), CF(2), (const uint32_t*)P(3), I(4), I(5),
+                                        CF(6), CF(7), P(8), (int)I(9), CF(10), I(11), I(12), CF(13), F(14), MF(15), MF(16),
+                                        P(17), F(18)); break;
+      default: return RGCN_ERR_UNSUPPORTED;
+    }
+#undef P
+#undef CF
+#undef MF
+#undef I
+#undef F
+#undef G
+#undef J
+#undef NEED
+    if (rc != RGCN_OK) return rc;
+  }
+  return RGCN_OK;
+}
+
+}  // extern "C"

@@ -778,6 +778,242 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------
+// The same slab GEMM with the operands split ONCE per workgroup (round 3; the default).
+// k_gemm_tn_split above has every wave collect its fragments with 48 ds_read_b32 per m-tile and split them in
+// registers - the A columns twice (two column waves share them), the G columns four times (four kc waves) -
+// 275 vector instructions per m-tile and wave against 12 MFMAs: the launch was bound by vector issue and LDS
+// reads (PMC, profiles/r02_pmc_counters.json: 5.6 M VALU instructions, MFMA pipes 11 % busy).  Here the fp32
+// m-tile still arrives by LDS-DMA (ring of THREE 32 KB slots: two tiles in flight), but the workgroup converts it
+// ONCE: thread (column pair, row group) reads its 2 x 8 values down the reduction index with eight ds_read_b64,
+// splits them (the same arithmetic, the same scale: the same fp16 bits) and writes them as 16-byte MFMA fragments -
+// eight consecutive m of one column - into fp16 hi / lo planes (double buffered, 2 x 32 KB); the waves then fetch
+// a fragment with ONE ds_read_b128.  Per m-tile and thread: 8 + 12 LDS reads, 4 writes, ~100 vector instructions,
+// 12 MFMAs - and ONE barrier: iteration i multiplies tile i from plane buffer i % 2 while it converts tile i + 1
+// into the other; the barrier at its top says (a) every thread's planes of tile i are written, (b) every wave's
+// DMAs of tile i + 1 have landed, (c) everybody is done with tile i - 1's planes and with tile i's ring slot,
+// which the DMA of tile i + 3 then refills.  Same MFMA operands in the same order as the kernel above: same bits.
+// LDS: 3 x 32 KB + 2 x 32 KB = all 160 KB of the CU, one 512-thread workgroup per CU.
+// ---------------------------------------------------------------------------------------
+template <bool LO>
+__global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const float* __restrict__ A1, int K1,
+                                                               const float* __restrict__ A2, int K2,
+                                                               const float* __restrict__ G, int M, int N,
+                                                               int n_tiles, int rows_per_split,
+                                                               amax_ref amax1, float a1_mul, amax_ref amax2, amax_ref gmax,
+                                                               float* __restrict__ slab,
+                                                               float* __restrict__ bias_part,
+                                                               const uint32_t* __restrict__ tile_mask, int kseg) {
+  constexpr int TKC = TN_TKC, RING = 3, A_FLOATS = 32 * TKC, G_FLOATS = 32 * 128;
+  constexpr int SLOT_BYTES = (A_FLOATS + G_FLOATS) * 4;          // 32 KB: one fp32 m-tile of both operands
+  constexpr int PLANE = 4 * 128 * 16;                            // 8 KB: one fp16 image of one operand's m-tile
+  constexpr int PBUF_BYTES = 4 * PLANE;                          // A hi, A lo, G hi, G lo
+  constexpr int A_PW = 2, G_PW = 2, P = A_PW + G_PW;             // LDS-DMA instructions per wave and m-tile (2 rows each)
+  __shared__ __attribute__((aligned(16))) char lds[RING * SLOT_BYTES + 2 * PBUF_BYTES];   // the ONLY LDS object (160 KB)
+  const int Kc = K1 + K2;
+  int bx = blockIdx.x, split = blockIdx.y;                       // a split's tiles on one XCD (see k_gemm_tn_dma)
+  {
+    const int gx = (int)gridDim.x, full = ((int)gridDim.y >> 3) << 3;
+    const int lin = blockIdx.y * gx + blockIdx.x;
+    if (lin < gx * full) {
+      const int q = lin >> 3;
+      bx = q % gx;
+      split = (q / gx) * 8 + (lin & 7);
+    }
+  }
+  const int kc_tile = bx / n_tiles, kc_tiles = (int)gridDim.x / n_tiles;
+  const int kc0 = kc_tile * TKC, n0 = (bx % n_tiles) * 128;
+  const int mbeg = split * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const bool bias_block = (bias_part != nullptr) && (kc_tile == (K2 > 0 ? kc_tiles - 1 : 0));
+  const bool do_bias = bias_block && (tid < 128);
+  unsigned rel_bits = 0u;                                        // m-tiles without any of this kc tile's relations: skipped
+  if (tile_mask != nullptr && !bias_block && kc0 + TKC <= K1)
+    for (int c = kc0; c < kc0 + TKC; c += kseg) rel_bits |= 1u << (c / kseg);
+  const bool sparse = rel_bits != 0u;
+  auto next_mt = [&](int mt) {
+    mt += 32;
+    while (sparse && mt < mend && !(tile_mask[mt >> 5] & rel_bits)) mt += 32;
+    return min(mt, mend + 31);
+  };
+
+  floatx16 acc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  float bsum = 0.f;
+
+  // LDS-DMA: 32 lanes per row (2 rows per wave instruction); this lane's 4 columns of the kc tile lie in one operand
+  const int d_row = lane >> 5, d_col = (lane & 31) * 4;
+  const int acol = min(kc0 + d_col, Kc - 4);                     // columns past Kc re-read valid ones; never stored
+  const bool a_first = acol < K1;
+  const float* a_src = a_first ? A1 + acol : A2 + (acol - K1);
+  const int lda = a_first ? K1 : K2;
+  const bool g_ok = n0 + d_col < N;
+  auto stage = [&](int mt, int slot) {
+    char* sA = lds + slot * SLOT_BYTES;
+    char* sG = sA + A_FLOATS * 4;
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) {
+      const int r0 = (wave * A_PW + j) * 2;
+      const int m = min(mt + r0 + d_row, M - 1);                 // rows past mend are zeroed by the conversion
+      glds16(a_src + (size_t)m * lda, sA + r0 * TKC * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < G_PW; ++j) {
+      const int r0 = (wave * G_PW + j) * 2;
+      const int m = min(mt + r0 + d_row, M - 1);
+      if (g_ok) glds16(G + (size_t)m * N + n0 + d_col, sG + r0 * 128 * 4);
+    }
+  };
+
+  // tiles T0, T1, T2 in the ring; `cur` is multiplied, `nxt` converted, `aft` in flight
+  int cur = next_mt(mbeg - 32), nxt = cur < mend ? next_mt(cur) : mend, aft = nxt < mend ? next_mt(nxt) : mend;
+  if (cur < mend) stage(cur, 0);
+  if (nxt < mend) stage(nxt, 1);
+  if (aft < mend) stage(aft, 2);
+
+  // operand scales (behind the first DMA issue).  Conversion: waves 0-3 convert A - thread (column pair cp, row
+  // group mg) - waves 4-7 convert G; a column pair lies in one A operand (K1 even).
+  const bool conv_a = wave < 4;
+  const int cp = tid & 63, mg = (tid >> 6) & 3;
+  const float amax_a1 = amax_of(amax1, lane) * a1_mul;
+  const float amax_a2 = amax2.slots ? amax_of(amax2, lane) : amax_a1;
+  const int ea1 = scale_exponent(amax_a1), ea2 = scale_exponent(amax_a2), eg = scale_exponent(amax_of(gmax, lane));
+  const bool cfirst = kc0 + 2 * cp < K1 || !amax2.slots;         // the converting thread's columns
+  const float sconv = conv_a ? pow2f(cfirst ? ea1 : ea2) : pow2f(eg);
+  const bool w_first = kc0 + wk * 32 < K1 || !amax2.slots;       // the multiplying wave's 32 kc columns (epilogue scale)
+  const int ea = w_first ? ea1 : ea2;
+
+  // byte addresses: conversion source (inside a ring slot), conversion destination and fragments (inside a plane buffer)
+  const unsigned cv_src = (unsigned)((conv_a ? 0 : A_FLOATS * 4) + (8 * mg * 128 + 2 * cp) * 4);
+  const unsigned cv_dst = (unsigned)((conv_a ? 0 : 2 * PLANE) + (mg * 128 + 2 * cp) * 16);
+  const unsigned fa = (unsigned)((lh * 128 + wk * 32 + li) * 16);                   // + s * 2 * 128 * 16 per 16-row step
+  const unsigned fg = (unsigned)(2 * PLANE + (lh * 128 + wn * 64 + li) * 16);       // + b * 32 * 16 per column block
+  constexpr unsigned kPlanes = RING * SLOT_BYTES;
+
+  // conversion of the tile in ring slot `slot` (rows mt .. mt + 31) into plane buffer `pb`
+  auto convert = [&](int mt, int slot, int pb) {
+    const unsigned src = (unsigned)(slot * SLOT_BYTES) + cv_src;
+    float2v v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[j]) : "v"(src), "n"(j * 128 * 4));
+    float bv[32];
+    if (do_bias) {                               // column sums of G, fp32, rows in order (as k_gemm_tn_dma)
+      const unsigned baddr = (unsigned)(slot * SLOT_BYTES + A_FLOATS * 4) + (unsigned)tid * 4u;
+#pragma unroll
+      for (int mm = 0; mm < 32; ++mm) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bv[mm]) : "v"(baddr), "n"(mm * 128 * 4));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    if (do_bias) {
+      asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]),
+                        "+v"(bv[8]), "+v"(bv[9]), "+v"(bv[10]), "+v"(bv[11]), "+v"(bv[12]), "+v"(bv[13]), "+v"(bv[14]), "+v"(bv[15]));
+      asm volatile("" : "+v"(bv[16]), "+v"(bv[17]), "+v"(bv[18]), "+v"(bv[19]), "+v"(bv[20]), "+v"(bv[21]), "+v"(bv[22]), "+v"(bv[23]),
+                        "+v"(bv[24]), "+v"(bv[25]), "+v"(bv[26]), "+v"(bv[27]), "+v"(bv[28]), "+v"(bv[29]), "+v"(bv[30]), "+v"(bv[31]));
+#pragma unroll
+      for (int mm = 0; mm < 32; ++mm) bsum += (mt + mm < mend) ? bv[mm] : 0.f;
+    }
+    half8 h0, l0, h1, l1;                        // the two columns' fragments: 8 consecutive rows each
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool live = mt + 8 * mg + j < mend;  // ragged last tile: rows >= mend contribute 0
+      const float x0 = live ? v[j][0] * sconv : 0.f, x1 = live ? v[j][1] * sconv : 0.f;
+      const _Float16 a = (_Float16)x0, b = (_Float16)x1;
+      h0[j] = a;
+      h1[j] = b;
+      if (LO) {
+        l0[j] = (_Float16)(x0 - (float)a);
+        l1[j] = (_Float16)(x1 - (float)b);
+      }
+    }
+    const unsigned dst = kPlanes + (unsigned)(pb * PBUF_BYTES) + cv_dst;
+    asm volatile("ds_write_b128 %0, %1" ::"v"(dst), "v"(__builtin_bit_cast(f32x4, h0)) : "memory");
+    asm volatile("ds_write_b128 %0, %1 offset:16" ::"v"(dst), "v"(__builtin_bit_cast(f32x4, h1)) : "memory");
+    if (LO) {
+      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(dst), "v"(__builtin_bit_cast(f32x4, l0)), "n"(PLANE) : "memory");
+      asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(dst), "v"(__builtin_bit_cast(f32x4, l1)), "n"(PLANE + 16) : "memory");
+    }
+  };
+
+  int t = 0;
+  if (cur < mend) {                              // tile 0: landed for this wave, then for all; converted into planes 0
+    if (aft < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    else if (nxt < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    convert(cur, 0, 0);
+  }
+  for (; cur < mend; ++t) {
+    // own plane writes of tile t done; own DMAs of tile t + 1 landed (tile t + 2's may still fly); then everybody's
+    if (aft < mend) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int fut = aft < mend ? next_mt(aft) : mend;            // tile t + 3 -> the ring slot tile t has just left
+    if (fut < mend) stage(fut, t % RING);
+    // fragments of tile t (plane buffer t % 2): per 16-row step A hi / lo and two column blocks of G hi / lo
+    const unsigned pl = kPlanes + (unsigned)((t & 1) * PBUF_BYTES);
+    f32x4 qa[2][2], qg[2][2][2];                 // [step][hi | lo], [step][block][hi | lo]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qa[s][0]) : "v"(pl + fa), "n"(s * 2 * 128 * 16));
+      if (LO) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qa[s][1]) : "v"(pl + fa), "n"(s * 2 * 128 * 16 + PLANE));
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qg[s][b][0]) : "v"(pl + fg), "n"(s * 2 * 128 * 16 + b * 32 * 16));
+        if (LO) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qg[s][b][1]) : "v"(pl + fg), "n"(s * 2 * 128 * 16 + b * 32 * 16 + PLANE));
+      }
+    }
+    if (LO) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(qa[0][0]), "+v"(qa[0][1]), "+v"(qg[0][0][0]), "+v"(qg[0][0][1]), "+v"(qg[0][1][0]), "+v"(qg[0][1][1]),
+                     "+v"(qa[1][0]), "+v"(qa[1][1]), "+v"(qg[1][0][0]), "+v"(qg[1][0][1]), "+v"(qg[1][1][0]), "+v"(qg[1][1][1]));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(qa[0][0]), "+v"(qg[0][0][0]), "+v"(qg[0][1][0]), "+v"(qa[1][0]), "+v"(qg[1][0][0]), "+v"(qg[1][1][0]));
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const half8 ah = __builtin_bit_cast(half8, qa[s][0]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {              // small terms first, as k_gemm_tn_split
+        const half8 gh = __builtin_bit_cast(half8, qg[s][b][0]);
+        if (LO) {
+          const half8 al = __builtin_bit_cast(half8, qa[s][1]);
+          const half8 gl = __builtin_bit_cast(half8, qg[s][b][1]);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh, acc[b], 0, 0, 0);
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl, acc[b], 0, 0, 0);
+        }
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh, acc[b], 0, 0, 0);
+      }
+    }
+    // tile t + 1 (landed: the barrier above) -> the other plane buffer, behind the MFMAs of tile t
+    if (nxt < mend) convert(nxt, (t + 1) % RING, (t + 1) & 1);
+    cur = nxt;
+    nxt = aft;
+    aft = fut;
+  }
+
+  const float ia = pow2f(-ea), ig = pow2f(-eg);
+  float* out = slab + (size_t)split * Kc * N;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int nn = n0 + (wn * 2 + b) * 32 + li;
+    if (nn >= N) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kc = kc0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (kc < Kc) out[(size_t)kc * N + nn] = acc[b][r] * ia * ig;
+    }
+  }
+  if (do_bias && n0 + tid < N) bias_part[(size_t)split * N + n0 + tid] = bsum;
+}
+
+// ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -1174,14 +1410,22 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
   const uint32_t* tmask = (d_in % 64 == 0) ? tile_mask : nullptr;
   float* bp = grad_bias ? bias_part : nullptr;
-  if (half)
-    k_gemm_tn_split<false><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                              p.rows_per_split, r1, a1_mul, r2, rg, slab, bp, tmask,
-                                                              (int)d_in);
-  else
-    k_gemm_tn_split<true><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                             p.rows_per_split, r1, a1_mul, r2, rg, slab, bp, tmask,
-                                                             (int)d_in);
+  // RGCN_TN_KERNEL=split: round 2's kernel (every wave splits its own fragments) for A/B runs; same bits either way
+  static const bool coop = [] {
+    const char* e = getenv("RGCN_TN_KERNEL");
+    return !(e && e[0] == 's');
+  }();
+#define RGCN_TN_LAUNCH(KERNEL, LO_)                                                                              \
+  KERNEL<LO_><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles, p.rows_per_split, \
+                                                 r1, a1_mul, r2, rg, slab, bp, tmask, (int)d_in)
+  if (coop) {
+    if (half) RGCN_TN_LAUNCH(k_gemm_tn_coop, false);
+    else RGCN_TN_LAUNCH(k_gemm_tn_coop, true);
+  } else {
+    if (half) RGCN_TN_LAUNCH(k_gemm_tn_split, false);
+    else RGCN_TN_LAUNCH(k_gemm_tn_split, true);
+  }
+#undef RGCN_TN_LAUNCH
   RGCN_HIP_TRY(hipGetLastError());
   job->slab = slab;
   job->bias_part = bias_part;

@@ -26,6 +26,20 @@ from . import _lib
 # helpers
 # ----------------------------------------------------------------------------------
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_REC = None           # the Region recorder while a pass is being sized / recorded (see Region below), else None
+
+
+def _empty(*shape, dtype, device) -> torch.Tensor:
+    """``torch.empty`` for every tensor a pass allocates: while a Region records the pass, the allocation is part of
+    the record (sizes first, then views of the pass's arena)"""
+    if _REC is None:
+        return torch.empty(*shape, dtype=dtype, device=device)
+    return _REC.alloc(shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else shape, dtype, device)
+
+
+def _L():
+    """the library - or, while a Region records a pass, the proxy that notes every call"""
+    return _lib.load() if _REC is None or _REC.proxy is None else _REC.proxy
 
 
 def _stream() -> int:
@@ -126,10 +140,10 @@ def absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None, clear: Optional[
     the incoming gradient).  One launch, no atomics; ``clear`` (``[k, AMAX_FLOATS]``, contiguous): amax
     buffers whose heads the same launch zeroes - the ones the kernels of the coming pass publish into."""
     _need_gpu("x", x, torch.float32)
-    lib = _lib.load()
+    lib = _L()
     with _on(x.device):
         if out is None:
-            out = torch.empty(AMAX_FLOATS, dtype=torch.float32, device=x.device)
+            out = _empty(AMAX_FLOATS, dtype=torch.float32, device=x.device)
         _check_amax("out", out, x.device)
         count = 0
         if clear is not None:
@@ -162,7 +176,7 @@ def absmax_many(tensors, outs, clear: Optional[torch.Tensor] = None) -> None:
     numels = (ctypes.c_int64 * n)(*[t.numel() for t in tensors])
     outp = (ctypes.c_void_p * n)(*[_ptr(o) for o in outs])
     with _on(dev):
-        rc = _lib.load().rgcn_absmax_multi(n, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(numels, ctypes.c_void_p),
+        rc = _L().rgcn_absmax_multi(n, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(numels, ctypes.c_void_p),
                                            ctypes.cast(outp, ctypes.c_void_p), _ptr(clear), count, _stream())
     _lib.check(rc, "rgcn_absmax_multi")
 
@@ -209,12 +223,12 @@ def split_weights_many(layers, amax=None):
             todo.append(i)
     if not todo:
         return out
-    lib = _lib.load()
+    lib = _L()
     dev = layers[todo[0]][0].device
     n = len(todo)
     with _on(dev):
         sizes = [_query("rgcn_weights_split_bytes", *layers[i][0].shape) for i in todo]
-        bufs = [torch.empty(sz, dtype=torch.uint8, device=dev) for sz in sizes]
+        bufs = [_empty(sz, dtype=torch.uint8, device=dev) for sz in sizes]
         arr = ctypes.c_void_p * n
         i64 = ctypes.c_int64 * n
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)                                   # noqa: E731
@@ -269,7 +283,7 @@ def absmax_and_split(x: torch.Tensor, out: torch.Tensor, clear: Optional[torch.T
         # scans all of them for the maximum (35 us at C3); here one launch takes the maxima, a second one splits
         tensors, outs, wam = [x], [out], {}
         with _on(x.device):
-            allbufs = torch.empty(2 * len(todo), AMAX_FLOATS, dtype=torch.float32, device=x.device)   # every head is written
+            allbufs = _empty(2 * len(todo), AMAX_FLOATS, dtype=torch.float32, device=x.device)   # every head is written
         for k, i in enumerate(todo):
             bufs = allbufs[2 * k: 2 * k + 2]
             wam[i] = (bufs[0], bufs[1] if layers[i][1] is not None else None)
@@ -289,11 +303,11 @@ def absmax_and_split(x: torch.Tensor, out: torch.Tensor, clear: Optional[torch.T
         if clear.numel() % AMAX_FLOATS or clear.device != x.device:
             raise ValueError("clear must hold whole amax buffers on x's device")
         count = clear.numel() // AMAX_FLOATS
-    lib = _lib.load()
+    lib = _L()
     n = len(todo)
     with _on(x.device):
         sizes = [_query("rgcn_weights_split_bytes", *layers[i][0].shape) for i in todo]
-        bufs = [torch.empty(sz, dtype=torch.uint8, device=x.device) for sz in sizes]
+        bufs = [_empty(sz, dtype=torch.uint8, device=x.device) for sz in sizes]
         arr, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
         cast = lambda a: ctypes.cast(a, ctypes.c_void_p)                                   # noqa: E731
         rc = lib.rgcn_absmax_pack(
@@ -323,7 +337,7 @@ def _query(name: str, *args) -> int:
 def _workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     if nbytes <= 0:
         return None
-    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return _empty(nbytes, dtype=torch.uint8, device=device)
 
 
 # ----------------------------------------------------------------------------------
@@ -355,7 +369,7 @@ class BucketedGraph:
         _need_gpu("edge_type", edge_type, torch.int64)
         if edge_type.device != edge_index.device:
             raise RuntimeError("edge_index and edge_type are on different devices")
-        lib = _lib.load()
+        lib = _L()
         self.device = edge_index.device
         self.num_nodes, self.num_relations = int(num_nodes), int(num_relations)
         self.num_other_nodes = self.num_nodes      # rows of the gathered input
@@ -388,7 +402,7 @@ class BucketedGraph:
             _need_gpu("edge_weight", edge_weight, torch.float32)
             if edge_weight.shape != key_node.shape:
                 raise ValueError("edge_weight must be [E]")
-        lib = _lib.load()
+        lib = _L()
         self.device = key_node.device
         self.num_nodes, self.num_relations = int(num_key_nodes), int(num_relations)
         self.num_other_nodes = int(num_other_nodes)
@@ -448,7 +462,7 @@ class BucketedGraph:
         self.bipartite = self.weighted_shard = False
         handle = ctypes.c_void_p()
         with _on(device):
-            rc = _lib.load().rgcn_graph_import(e, n, r, *(_ptr(dev[k]) for k in want), _stream(),
+            rc = _L().rgcn_graph_import(e, n, r, *(_ptr(dev[k]) for k in want), _stream(),
                                                ctypes.byref(handle))
         _lib.check(rc, "rgcn_graph_import")
         self._handle = handle
@@ -474,7 +488,7 @@ class BucketedGraph:
         handle = self.handle                                         # raises once the graph is destroyed
         cache = self.__dict__.setdefault("_mask_ptrs", {})          # fixed for the life of the handle
         if transposed not in cache:
-            cache[transposed] = _lib.load().rgcn_graph_tile_mask(handle, int(transposed), None) or None
+            cache[transposed] = _L().rgcn_graph_tile_mask(handle, int(transposed), None) or None
         return cache[transposed]
 
     def workspace_bytes(self, transposed: bool, d: int) -> int:
@@ -483,14 +497,14 @@ class BucketedGraph:
         cache = self.__dict__.setdefault("_ws_bytes", {})
         key = (bool(transposed), int(d))
         if key not in cache:
-            cache[key] = _lib.load().rgcn_aggregate_workspace_bytes(handle, int(transposed), int(d))
+            cache[key] = _L().rgcn_aggregate_workspace_bytes(handle, int(transposed), int(d))
         return cache[key]
 
     def num_levels(self, transposed: bool) -> int:
         handle = self.handle                                         # raises once the graph is destroyed
         cache = self.__dict__.setdefault("_levels", {})              # fixed for the life of the handle
         if transposed not in cache:
-            cache[transposed] = _lib.load().rgcn_graph_num_levels(handle, int(transposed))
+            cache[transposed] = _L().rgcn_graph_num_levels(handle, int(transposed))
         return cache[transposed]
 
     def deferrable(self, transposed: bool, d: int) -> bool:
@@ -499,7 +513,7 @@ class BucketedGraph:
         cache = self.__dict__.setdefault("_deferrable", {})
         key = (bool(transposed), int(d))
         if key not in cache:
-            cache[key] = bool(_lib.load().rgcn_aggregate_deferrable(handle, int(transposed), int(d)))
+            cache[key] = bool(_L().rgcn_aggregate_deferrable(handle, int(transposed), int(d)))
         return cache[key]
 
     def weight_bound(self, transposed: bool) -> float:
@@ -509,19 +523,19 @@ class BucketedGraph:
         cache = self.__dict__.setdefault("_wbound", {})
         key = bool(transposed and not self.bipartite)
         if key not in cache:
-            cache[key] = float(_lib.load().rgcn_graph_weight_bound(handle, int(key)))
+            cache[key] = float(_L().rgcn_graph_weight_bound(handle, int(key)))
         return cache[key]
 
     def arrays(self, transposed: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         """Copies of (rowptr int32[N*R+1], col int32[E], perm int64[E], val float32) on the
         device: val = cnt[N*R] (forward) or w_t[E] (transposed).  For parity tests."""
-        lib = _lib.load()
+        lib = _L()
         nr, e = self.num_nodes * self.num_relations, self.num_edges
         with _on(self.device):
-            rowptr = torch.empty(nr + 1, dtype=torch.int32, device=self.device)
-            col = torch.empty(e, dtype=torch.int32, device=self.device)
-            perm = torch.empty(e, dtype=torch.int64, device=self.device)
-            val = torch.empty(e if transposed else nr, dtype=torch.float32, device=self.device)
+            rowptr = _empty(nr + 1, dtype=torch.int32, device=self.device)
+            col = _empty(e, dtype=torch.int32, device=self.device)
+            perm = _empty(e, dtype=torch.int64, device=self.device)
+            val = _empty(e if transposed else nr, dtype=torch.float32, device=self.device)
             rc = lib.rgcn_graph_export(self.handle, int(transposed), _ptr(rowptr), _ptr(col), _ptr(perm),
                                        _ptr(val), _stream())
         _lib.check(rc, "rgcn_graph_export")
@@ -636,7 +650,7 @@ class BucketedGraph:
                 plan.hub.destroy()
         if self._handle is not None:
             try:
-                _lib.load().rgcn_graph_destroy(self._handle)
+                _L().rgcn_graph_destroy(self._handle)
             finally:
                 self._handle = None
 
@@ -715,7 +729,7 @@ def clear_graph_cache() -> None:
 # ----------------------------------------------------------------------------------
 # aggregate (rows A3 + A4 / their autograd)
 # ----------------------------------------------------------------------------------
-# bench.py sets this to a list to collect (weighted, d, edges, segments, start_event, end_event) per
+# bench.py sets this to a list to collect (weighted, d, edges, segments, table rows, start_event, end_event) per
 # level-0 gather launch; None (the default) means one C call per aggregate, no events.
 GATHER_EVENTS = None
 # likewise for the dense transforms: (kind, M, K, N, precision, start_event, end_event) per call - the
@@ -759,7 +773,7 @@ class PendingParamGrads:
         if not self.done:
             dev = self.grads[0].device
             with _on(dev):
-                rc = _lib.load().rgcn_slab_reduce(ctypes.byref(self.job), _stream())
+                rc = _L().rgcn_slab_reduce(ctypes.byref(self.job), _stream())
             _lib.check(rc, "rgcn_slab_reduce")
             self._launched()
 
@@ -791,14 +805,14 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
     _check_amax("amax_out", amax_out, x.device)
     if amax_out is not None and half_in:
         raise ValueError("amax_out goes with the fp32 gather (the fp16 path's transform needs no scale)")
-    lib = _lib.load()
+    lib = _L()
     if out is not None:
         _need_gpu("out", out, torch.float32)
         if tuple(out.shape) != (graph.num_nodes, graph.num_relations * d) or out.device != x.device:
             raise ValueError(f"out must be [{graph.num_nodes}, {graph.num_relations * d}] on x's device")
     with _on(x.device):
         if out is None:
-            out = torch.empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
+            out = _empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
         nbytes = graph.workspace_bytes(transposed, d)
         ws = _workspace(nbytes, x.device)
         if tail is not None and not tail.done and (half_in or GATHER_EVENTS is not None):
@@ -833,7 +847,8 @@ def aggregate(graph: BucketedGraph, x: torch.Tensor, transposed: bool = False,
                 if level == 0:
                     end.record()
                     weighted = bool(transposed) or (graph.bipartite and graph.weighted_shard)
-                    GATHER_EVENTS.append((weighted, d, graph.num_edges, graph.num_nodes * graph.num_relations, beg, end))
+                    GATHER_EVENTS.append((weighted, d, graph.num_edges, graph.num_nodes * graph.num_relations,
+                                          graph.num_other_nodes, beg, end))
     _lib.check(rc, "rgcn_aggregate")
     return out
 
@@ -879,10 +894,10 @@ def layer_fwd_fused(graph: BucketedGraph, x: torch.Tensor, packed: SplitWeights,
     plan = graph.fused_plan(min(int(inline_limit), d_in // 4))    # one id window of d_in / 4 lanes per segment
     hub_agg = aggregate(plan.hub, x) if plan.hub is not None else None
     tile_mask = graph.tile_mask_ptr(False) if graph.num_relations <= 32 else None
-    lib = _lib.load()
+    lib = _L()
     with _on(x.device):
         if out is None:
-            out = torch.empty(graph.num_nodes, d_out, dtype=torch.float32, device=x.device)
+            out = _empty(graph.num_nodes, d_out, dtype=torch.float32, device=x.device)
         elif tuple(out.shape) != (graph.num_nodes, d_out) or out.dtype != torch.float32 or out.device != x.device:
             raise ValueError(f"out must be float32 [{graph.num_nodes}, {d_out}] on x's device")
         if FUSED_EVENTS is not None:
@@ -928,9 +943,9 @@ def layer_bwd_input_fused(graph: BucketedGraph, g: torch.Tensor, packed: SplitWe
     if tail is not None and not tail.done:
         tail.finish()
     tile_mask = graph.tile_mask_ptr(True) if graph.num_relations <= 32 else None
-    lib = _lib.load()
+    lib = _L()
     with _on(g.device):
-        gx = torch.empty(graph.num_nodes, d_in, dtype=torch.float32, device=g.device)
+        gx = _empty(graph.num_nodes, d_in, dtype=torch.float32, device=g.device)
         if FUSED_EVENTS is not None:
             beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             beg.record()
@@ -962,7 +977,7 @@ def aggregate_deferred(graph: BucketedGraph, x: torch.Tensor, transposed: bool =
     rows of the long segments tile by tile itself (same order, same bits) and completes ``agg`` in passing.
     ``hubs`` is None (and ``agg`` complete) where nothing can be deferred: no long segment, a structure with more
     than one reduce level, a width other than 64 / 128 / 256, an fp16 table, measurement mode."""
-    lib = _lib.load()
+    lib = _L()
     d = x.size(1) if x.dim() == 2 else 0
     deferrable = (x.dtype == torch.float32 and GATHER_EVENTS is None and graph.num_levels(transposed) == 2
                   and graph.deferrable(transposed, d))
@@ -974,7 +989,7 @@ def aggregate_deferred(graph: BucketedGraph, x: torch.Tensor, transposed: bool =
     if x.size(0) != graph.num_other_nodes or x.device != graph.device:
         raise ValueError(f"x must be [{graph.num_other_nodes}, d] on the graph's device, got {tuple(x.shape)}")
     with _on(x.device):
-        out = torch.empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
+        out = _empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
         nbytes = graph.workspace_bytes(transposed, d)
         ws = _workspace(nbytes, x.device)
         job = tail.job if (tail is not None and not tail.done) else None
@@ -1052,7 +1067,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
     ``x`` by its own maximum; a missing buffer is scanned here (one more pass over that operand).
     ``amax_out`` (a ZEROED amax buffer): receives ``max |out|``."""
     n, r, d_in, d_out = _check_layer(agg, x, weight, root, bias)
-    lib = _lib.load()
+    lib = _L()
     _check_amax("amax_out", amax_out, x.device)
     if out is not None:
         _need_gpu("out", out, torch.float32)
@@ -1067,7 +1082,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
         if packed is not None and not packed.matches(weight, root):
             raise ValueError("packed does not belong to these weights")
         with _on(x.device):
-            out = given_out if given_out is not None else torch.empty(n, d_out, dtype=torch.float32, device=x.device)
+            out = given_out if given_out is not None else _empty(n, d_out, dtype=torch.float32, device=x.device)
             nbytes = _query("rgcn_transform_split_workspace_bytes", r, d_in, d_out)
             ws = _workspace(nbytes, x.device)
             with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "split" if split == 1 else "half"):
@@ -1082,7 +1097,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
         raise ValueError("deferred hub tails need the split-precision transform (finish them with aggregate instead)")
     if half and d_in % 32 == 0:
         with _on(x.device):
-            out = given_out if given_out is not None else torch.empty(n, d_out, dtype=torch.float32, device=x.device)
+            out = given_out if given_out is not None else _empty(n, d_out, dtype=torch.float32, device=x.device)
             nbytes = lib.rgcn_transform_fwd_f16_workspace_bytes(r, d_in, d_out)
             ws = _workspace(nbytes, x.device)
             with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "f16"):
@@ -1094,7 +1109,7 @@ def transform_fwd(agg, x, weight, root=None, bias=None, relu: bool = False,
             absmax(out, amax_out)
         return out
     with _on(x.device):
-        out = given_out if given_out is not None else torch.empty(n, d_out, dtype=torch.float32, device=x.device)
+        out = given_out if given_out is not None else _empty(n, d_out, dtype=torch.float32, device=x.device)
         with _GemmBracket("fwd", n, (r + (root is not None)) * d_in, d_out, "fp32"):
             rc = lib.rgcn_transform_fwd(_ptr(agg), _ptr(x), _ptr(weight), _ptr(root), _ptr(bias), int(relu),
                                         _mask_for(graph, False, n, r), n, r, d_in, d_out, _ptr(out), _stream())
@@ -1127,7 +1142,7 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
         _need_gpu("relu_mask", relu_mask, torch.float32)
         if tuple(relu_mask.shape) != (n, d_in):
             raise ValueError(f"relu_mask must be [{n}, {d_in}]")
-    lib = _lib.load()
+    lib = _L()
     _check_amax("amax_out", amax_out, g.device)
     if d_in % 4 or d_out % 4:
         raise ValueError("in/out channels must be multiples of 4")
@@ -1139,7 +1154,7 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
         if packed is not None and not packed.matches(weight, root):
             raise ValueError("packed does not belong to these weights")
         with _on(g.device):
-            gx = torch.empty(n, d_in, dtype=torch.float32, device=g.device)
+            gx = _empty(n, d_in, dtype=torch.float32, device=g.device)
             nbytes = _query("rgcn_transform_split_workspace_bytes", r, d_in, d_out)
             ws = _workspace(nbytes, g.device)
             with _GemmBracket("bwd_input", n, (r + (root is not None)) * d_out, d_in, "split" if split == 1 else "half"):
@@ -1157,7 +1172,7 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
         weight = weight * out_scale
         root = root * out_scale if root is not None else None
     with _on(g.device):
-        gx = torch.empty(n, d_in, dtype=torch.float32, device=g.device)
+        gx = _empty(n, d_in, dtype=torch.float32, device=g.device)
         with _GemmBracket("bwd_input", n, (r + (root is not None)) * d_out, d_in, "fp32"):
             rc = lib.rgcn_transform_bwd_input(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root), _ptr(relu_mask),
                                               _mask_for(graph, True, n, r), n, r, d_in, d_out, _ptr(gx), _stream())
@@ -1180,10 +1195,10 @@ def transform_first(g: torch.Tensor, packed: SplitWeights, amax: Optional[torch.
     if not split:
         raise ValueError("transform_first runs in split precision only")
     _check_amax("amax", amax, g.device)
-    lib = _lib.load()
+    lib = _L()
     n = g.size(0)
     with _on(g.device):
-        t = torch.empty(n, (r + int(packed.has_root)) * d_in, dtype=torch.float32, device=g.device)
+        t = _empty(n, (r + int(packed.has_root)) * d_in, dtype=torch.float32, device=g.device)
         ws = _workspace(2048, g.device)
         with _GemmBracket("bwd_input", n, d_out, t.size(1), "split" if split == 1 else "half"):
             rc = lib.rgcn_transform_first_split(_ptr(g), _ptr(packed.buf), int(packed.has_root), n, r, d_in, d_out,
@@ -1206,11 +1221,11 @@ def transform_bwd_params(agg, x, g, num_relations: int, want_root: bool = True, 
     r = int(num_relations)
     if tuple(agg.shape) != (n, r * d_in) or g.size(0) != n:
         raise ValueError("agg must be [N, R*d_in] and g [N, d_out]")
-    lib = _lib.load()
+    lib = _L()
     with _on(x.device):
-        gw = torch.empty(r, d_in, d_out, dtype=torch.float32, device=x.device)
-        groot = torch.empty(d_in, d_out, dtype=torch.float32, device=x.device) if want_root else None
-        gbias = torch.empty(d_out, dtype=torch.float32, device=x.device) if want_bias else None
+        gw = _empty(r, d_in, d_out, dtype=torch.float32, device=x.device)
+        groot = _empty(d_in, d_out, dtype=torch.float32, device=x.device) if want_root else None
+        gbias = _empty(d_out, dtype=torch.float32, device=x.device) if want_bias else None
         split = _use_split(precision, d_in, 64)
         if split and n > 0:
             a1, a2, a3 = amax if amax is not None else (None, None, None)
@@ -1272,9 +1287,9 @@ def distmult_fwd(h, h_idx, t, t_idx, r, r_idx, batch: int) -> torch.Tensor:
             raise ValueError("head / tail / relation embedding dims differ")
     if d % 4:
         raise ValueError("embedding dim must be a multiple of 4")
-    lib = _lib.load()
+    lib = _L()
     with _on(h.device):
-        scores = torch.empty(batch, dtype=torch.float32, device=h.device)
+        scores = _empty(batch, dtype=torch.float32, device=h.device)
         rc = lib.distmult_fwd(_ptr(h), _ptr(h_idx), h.size(0), _ptr(t), _ptr(t_idx), t.size(0), _ptr(r), _ptr(r_idx),
                               r.size(0), batch, d, _ptr(scores), _stream())
     _lib.check(rc, "distmult_fwd")
@@ -1289,7 +1304,7 @@ def check_indices(device=None) -> None:
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     flag = ctypes.c_int(0)
     with _on(device):
-        rc = _lib.load().rgcn_index_error_fetch(ctypes.byref(flag), _stream())
+        rc = _L().rgcn_index_error_fetch(ctypes.byref(flag), _stream())
     _lib.check(rc, "rgcn_index_error_fetch")
     if flag.value:
         raise IndexError("a head / tail / relation index was outside its embedding table "
@@ -1303,10 +1318,10 @@ def segment_sum(rows: torch.Tensor, idx: torch.Tensor, num_rows: int) -> torch.T
     _need_gpu("idx", idx, torch.int64)
     if rows.dim() != 2 or idx.shape != (rows.size(0),) or rows.size(1) % 4:
         raise ValueError("rows must be [B, d] (d % 4 == 0) and idx [B]")
-    lib = _lib.load()
+    lib = _L()
     b, d = rows.shape
     with _on(rows.device):
-        out = torch.empty(num_rows, d, dtype=torch.float32, device=rows.device)
+        out = _empty(num_rows, d, dtype=torch.float32, device=rows.device)
         nbytes = lib.rgcn_segment_sum_workspace_bytes(b, d, num_rows)
         ws = _workspace(nbytes, rows.device)
         rc = lib.rgcn_segment_sum(_ptr(rows), _ptr(idx), b, d, int(num_rows), _ptr(out), _ptr(ws), nbytes, _stream())
@@ -1335,7 +1350,7 @@ def adam_clip_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr: float, beta1
             _need_gpu(f"{name}[{i}]", t, torch.float32)
         if not (grads[i].shape == exp_avgs[i].shape == exp_avg_sqs[i].shape == params[i].shape) or steps[i].numel() != 1:
             raise ValueError(f"tensor {i}: param / grad / moments must have one shape, step one element")
-    lib = _lib.load()
+    lib = _L()
     dev = params[0].device
     arr = ctypes.c_void_p * n
     numels = (ctypes.c_int64 * n)(*[p.numel() for p in params])
@@ -1382,11 +1397,11 @@ def sample_batch(edge_index: torch.Tensor, edge_type: torch.Tensor, order: Optio
     if batch < 0 or num_neg < 0 or (batch > 0 and e == 0):
         raise ValueError("batch / num_neg must be >= 0 and the graph must have columns")
     total = batch * (1 + num_neg)
-    lib = _lib.load()
+    lib = _L()
     with _on(edge_index.device):
-        heads = torch.empty(total, dtype=torch.int64, device=edge_index.device)
+        heads = _empty(total, dtype=torch.int64, device=edge_index.device)
         tails, rels = torch.empty_like(heads), torch.empty_like(heads)
-        labels = torch.empty(total, dtype=torch.float32, device=edge_index.device)
+        labels = _empty(total, dtype=torch.float32, device=edge_index.device)
         rc = lib.rgcn_sample_batch(_ptr(edge_index), _ptr(edge_type), e, _ptr(order), _ptr(cursor), batch, num_neg,
                                    int(num_nodes), _ptr(rng), _ptr(heads), _ptr(tails), _ptr(rels), _ptr(labels),
                                    _stream())
@@ -1406,10 +1421,10 @@ def distmult_bce_fwd(h, h_idx, t, t_idx, r, r_idx, labels, batch: int):
     _need_gpu("labels", labels, torch.float32)
     if labels.shape != (batch,):
         raise ValueError(f"labels must be [{batch}], got {tuple(labels.shape)}")
-    lib = _lib.load()
+    lib = _L()
     with _on(h.device):
-        scores = torch.empty(batch, dtype=torch.float32, device=h.device)
-        loss = torch.empty(batch, dtype=torch.float32, device=h.device)
+        scores = _empty(batch, dtype=torch.float32, device=h.device)
+        loss = _empty(batch, dtype=torch.float32, device=h.device)
         rc = lib.distmult_bce_fwd(_ptr(h), _ptr(h_idx), h.size(0), _ptr(t), _ptr(t_idx), t.size(0), _ptr(r), _ptr(r_idx),
                                   r.size(0), _ptr(labels), batch, d, _ptr(scores), _ptr(loss), _stream())
     _lib.check(rc, "distmult_bce_fwd")
@@ -1429,7 +1444,7 @@ def distmult_bce_bwd(grad_mean_loss, scores, labels, h, h_idx, t, t_idx, r, r_id
     if grad_mean_loss.numel() != 1:
         raise ValueError("grad_mean_loss must hold one float")
     d = h.size(1)
-    lib = _lib.load()
+    lib = _L()
     with _on(h.device):
         ws, nbytes = _bwd_workspace(lib, batch, d, r, r_idx, h.device)
         rc = lib.distmult_bce_bwd(_ptr(grad_mean_loss), _ptr(scores), _ptr(labels), _ptr(h), _ptr(h_idx), h.size(0),
@@ -1444,7 +1459,7 @@ def distmult_bwd(gs, h, h_idx, t, t_idx, r, r_idx, batch: int, grad_h, grad_t, g
     buffers that are zero in the rows nobody touches; ``grad_h is grad_t`` (one table) is one key space."""
     _need_gpu("grad_scores", gs, torch.float32)
     d = h.size(1)
-    lib = _lib.load()
+    lib = _L()
     with _on(h.device):
         ws, nbytes = _bwd_workspace(lib, batch, d, r, r_idx, h.device)
         rc = lib.distmult_bwd(_ptr(gs), _ptr(h), _ptr(h_idx), h.size(0), _ptr(t), _ptr(t_idx), t.size(0), _ptr(r),
@@ -1467,10 +1482,315 @@ def distmult_rank_tails(hr: torch.Tensor, emb: torch.Tensor, true_score: torch.T
         raise ValueError("hr [B, d], emb [N, d], true_score [B], tail [B] expected")
     if d % 32:
         raise ValueError("embedding dim must be a multiple of 32 for the fused ranking kernel")
-    lib = _lib.load()
+    lib = _L()
     with _on(hr.device):
         beaten = torch.zeros(b, dtype=torch.int32, device=hr.device)
         rc = lib.distmult_rank_tails(_ptr(hr), _ptr(emb), _ptr(true_score), _ptr(tail), b, emb.size(0), d,
                                      _ptr(beaten), _stream())
     _lib.check(rc, "distmult_rank_tails")
     return beaten.to(torch.int64) + 1
+
+
+# ----------------------------------------------------------------------------------
+# Region: a pass (a fixed list of this library's launches) recorded once, then issued by ONE native call
+# ----------------------------------------------------------------------------------
+# The wrappers above cost 25-80 us of Python each (argument checks, ctypes marshalling, one torch.empty per output and
+# workspace); an encoder step is ~14 of them: 0.54 ms of host time per eager step against 0.29 ms of kernels.  On a
+# static graph the list of launches of a pass never changes - only the addresses of the step's tensors do - so a
+# Region runs the pass's Python twice (once to learn the sizes of its allocations, once more with every allocation
+# placed in ONE arena and every library call noted down with its arguments classified as constant / arena + offset /
+# input k + offset), checks that issuing the noted list natively (``rgcn_sequence_run``) reproduces the recorded
+# results bit for bit, and from then on a call is: one allocation, one C call, views for the tensors the caller looks
+# at.  Any pass that does something a Region cannot note (a torch op in the middle, an entry point the native runner
+# does not forward to, an allocation pattern that changes) keeps running through the wrappers - same kernels.
+class _NotRecordable(Exception):
+    pass
+
+
+_SEQ_INDEX = {name: i for i, name in enumerate(_lib.SEQ_FUNCTIONS)}
+_SEQ_STREAM_POS = {"rgcn_absmax": 5, "rgcn_absmax_multi": 6, "rgcn_absmax_pack": 13, "rgcn_weights_split_pack_multi": 10,
+                   "rgcn_aggregate": 7, "rgcn_aggregate_and_reduce": 8, "rgcn_aggregate_amax": 9, "rgcn_aggregate_deferred": 8,
+                   "rgcn_transform_fwd_split": 20, "rgcn_transform_bwd_input_split": 19, "rgcn_transform_first_split": 12,
+                   "rgcn_transform_bwd_params_split_begin": 18, "rgcn_slab_reduce": 1, "rgcn_layer_fwd_fused": 17,
+                   "rgcn_layer_bwd_input_fused": 17}
+_SEQ_PURE = ("rgcn_graph_tile_mask", "rgcn_graph_num_levels", "rgcn_graph_weight_bound", "rgcn_aggregate_deferrable",
+             "rgcn_graph_num_edges", "rgcn_graph_num_nodes", "rgcn_graph_num_relations", "rgcn_abi_version", "rgcn_strerror")
+REGIONS = os.environ.get("RGCN_NATIVE_STEP", "1") == "1"      # 0: always through the wrappers (A/B runs, debugging)
+
+
+def guard_torch_op(what: str) -> None:
+    """called where a pass falls back on a torch op: such a pass cannot be a Region"""
+    if _REC is not None:
+        raise _NotRecordable(what)
+
+
+class Lazy:
+    """a tensor of a replayed pass that nobody has looked at yet: arena + offset (``.tensor()`` makes the view)"""
+    __slots__ = ("arena", "offset", "shape", "dtype", "_t")
+
+    def __init__(self, arena, offset, shape, dtype):
+        self.arena, self.offset, self.shape, self.dtype, self._t = arena, offset, shape, dtype, None
+
+    def data_ptr(self) -> int:
+        return self.arena.data_ptr() + self.offset
+
+    def tensor(self) -> torch.Tensor:
+        if self._t is None:
+            n = 1
+            for s in self.shape:
+                n *= s
+            nbytes = n * torch.empty((), dtype=self.dtype).element_size() if n else 0
+            self._t = self.arena[self.offset: self.offset + nbytes].view(self.dtype).view(self.shape)
+        return self._t
+
+
+def materialize(t):
+    return t.tensor() if isinstance(t, Lazy) else t
+
+
+class _Proxy:
+    def __init__(self, rec):
+        self._rec, self._real = rec, _lib.load()
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if name in _SEQ_PURE or name.endswith(("_bytes", "_supported")):
+            return fn
+        if name not in _SEQ_INDEX:
+            raise _NotRecordable(f"{name} is not an entry point the native runner forwards to")
+        rec = self._rec
+
+        def call(*args):
+            rc = fn(*args)
+            rec.note(name, args)
+            return rc
+        return call
+
+
+class _Recorder:
+    ALIGN = 256
+
+    def __init__(self, device, sizes=None, inputs=()):
+        self.device, self.sizes, self.proxy = device, ([] if sizes is None else sizes), None
+        self.recording = sizes is not None
+        self.calls, self.jobs, self.cursor = [], {}, 0
+        self.keep = []                                      # sizing run: allocations stay alive (no address reuse)
+        if self.recording:
+            self.offsets, total = [], 0
+            for nb in sizes:
+                self.offsets.append(total)
+                total += (nb + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            self.arena = torch.empty(max(total, self.ALIGN), dtype=torch.uint8, device=device)
+            self.arena_bytes = max(total, self.ALIGN)
+            self.base = self.arena.data_ptr()
+            self.inputs = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) if t is not None else None
+                           for t in inputs]
+            self.proxy = _Proxy(self)
+
+    def alloc(self, shape, dtype, device):
+        shape = tuple(int(s) for s in shape)
+        n = 1
+        for s in shape:
+            n *= s
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        if not self.recording:
+            self.sizes.append(nbytes)
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self.keep.append(t)
+            return t
+        k = self.cursor
+        if k >= len(self.sizes) or self.sizes[k] != nbytes or torch.device(device) != self.arena.device:
+            raise _NotRecordable("the pass allocates differently from its first run")
+        self.cursor += 1
+        if nbytes == 0:
+            return torch.empty(shape, dtype=dtype, device=device)
+        off = self.offsets[k]
+        return self.arena[off: off + nbytes].view(dtype).view(shape)
+
+    def _classify(self, ptr: int):
+        if not ptr:
+            return (_lib.SEQ_IMM, 0, 0)
+        if self.base <= ptr < self.base + self.arena_bytes:
+            return (_lib.SEQ_BASE, 0, ptr - self.base)
+        for k, span in enumerate(self.inputs):
+            if span is not None and span[0] <= ptr < span[1]:
+                return (_lib.SEQ_BASE, k + 1, ptr - span[0])
+        return (_lib.SEQ_IMM, 0, ptr)                       # static: graph structures, handles, masks
+
+    @staticmethod
+    def _as_int(a) -> int:
+        if a is None:
+            return 0
+        if isinstance(a, ctypes.c_void_p):
+            return a.value or 0
+        return int(a)
+
+    def note(self, name, args):
+        proto = _lib.PROTOTYPES[name][1]
+        if len(args) != len(proto):
+            raise _NotRecordable(f"{name}: argument count")
+        arrays = _lib.SEQ_HOST_ARRAYS.get(name, {})
+        descs = []
+        for i, (a, ty) in enumerate(zip(args, proto)):
+            if i == _SEQ_STREAM_POS[name]:
+                descs.append((_lib.SEQ_STREAM, 0, 0))
+            elif i in arrays:
+                is_ptr, cnt_pos = arrays[i]
+                addr, n = self._as_int(a), int(args[cnt_pos])
+                if not addr:
+                    descs.append((_lib.SEQ_IMM, 0, 0))
+                    continue
+                raw = (ctypes.c_uint64 * n).from_address(addr)
+                descs.append(("array", [self._classify(int(v)) if is_ptr else (_lib.SEQ_IMM, 0, int(v)) for v in raw]))
+            elif ty is ctypes.c_float:
+                descs.append((_lib.SEQ_FLOAT, 0, float(a)))
+            elif ty is ctypes.POINTER(_lib.SlabJob):
+                if a is None:
+                    descs.append((_lib.SEQ_IMM, 0, 0))
+                else:
+                    job = a._obj
+                    slot = self.jobs.setdefault(id(job), len(self.jobs))
+                    self.keep.append(job)
+                    descs.append((_lib.SEQ_JOB, slot, 0))
+            elif ty is ctypes.c_void_p:
+                descs.append(self._classify(self._as_int(a)))
+            else:
+                descs.append((_lib.SEQ_IMM, 0, int(a)))
+        self.calls.append((_SEQ_INDEX[name], descs))
+
+
+class _Plan:
+    def __init__(self, rec: _Recorder, outputs):
+        flat, calls = [], []
+        tails = []                                           # array entries live behind the calls' own arguments
+        for fn, descs in rec.calls:
+            first = len(flat)
+            for d in descs:
+                if d[0] == "array":
+                    flat.append(["array", d[1]])
+                else:
+                    flat.append(list(d))
+            calls.append((fn, len(descs), first))
+        for slot in flat:
+            if slot[0] == "array":
+                entries = slot[1]
+                start = len(flat) + len(tails)
+                tails.extend(entries)
+                slot[:] = [_lib.SEQ_ARRAY, start, len(entries)]
+        allargs = [tuple(a) for a in flat] + [tuple(t) for t in tails]
+        self.num_calls, self.num_args = len(calls), len(allargs)
+        self.calls = (_lib.SeqCall * max(1, len(calls)))(*[_lib.SeqCall(fn, n, first) for fn, n, first in calls])
+        args = (_lib.SeqArg * max(1, len(allargs)))()
+        for i, (kind, index, value) in enumerate(allargs):
+            args[i].kind, args[i].index = kind, index
+            if kind == _lib.SEQ_FLOAT:
+                args[i].value = ctypes.c_int64.from_buffer_copy(ctypes.c_double(value)).value
+            else:
+                args[i].value = value
+        self.args = args
+        self.arena_bytes, self.device = rec.arena_bytes, rec.device
+        self.outputs = outputs                               # per output: ("arena", off, shape, dtype) | ("input", k) | None
+        self.num_jobs = len(rec.jobs)
+
+    def run(self, inputs, want):
+        """-> list of outputs: tensors for the positions in `want`, Lazy for the rest"""
+        lib = _lib.load()
+        with _on(self.device):
+            arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=self.device)
+            nb = len(inputs) + 1
+            bases = (ctypes.c_void_p * nb)(arena.data_ptr(), *[t.data_ptr() if t is not None else None for t in inputs])
+            rc = lib.rgcn_sequence_run(self.calls, self.num_calls, self.args, self.num_args, bases, nb, _stream())
+        _lib.check(rc, "rgcn_sequence_run")
+        outs = []
+        for i, spec in enumerate(self.outputs):
+            if spec is None:
+                outs.append(None)
+            elif spec[0] == "input":
+                outs.append(inputs[spec[1]])
+            else:
+                lz = Lazy(arena, spec[1], spec[2], spec[3])
+                outs.append(lz.tensor() if i in want else lz)
+        return outs
+
+
+class Region:
+    """``Region(name, fn)``: ``fn(*tensors, **static) -> tuple of tensors | None``, a pass made of library calls and
+    ``_empty`` allocations only.  ``run(owner, key, tensors, static, want)``: through the wrappers three times, natively from
+    then on; plans live on ``owner`` (the bucketed graph: they hold addresses of its structures) and die with it."""
+
+    DISABLED = "disabled"
+
+    def __init__(self, name: str, fn):
+        self.name, self.fn = name, fn
+
+    def run(self, owner, key, tensors, static, want=()):
+        global _REC
+        tensors = list(tensors)
+        if not REGIONS or GATHER_EVENTS is not None or GEMM_EVENTS is not None or FUSED_EVENTS is not None or _REC is not None:
+            return self._eager(tensors, static)
+        store = owner.__dict__.setdefault("_regions", {})
+        full_key = (self.name, key, GEMM_PRECISION)
+        state = store.get(full_key)
+        if isinstance(state, _Plan):
+            return state.run(tensors, want)
+        if state == self.DISABLED or torch.cuda.is_current_stream_capturing():
+            return self._eager(tensors, static)
+        if any(isinstance(t, Lazy) for t in tensors):
+            tensors = [materialize(t) for t in tensors]
+        if any(t is not None and not t.is_contiguous() for t in tensors):
+            return self._eager(tensors, static)
+        dev = next(t.device for t in tensors if t is not None)
+        if state is None:                                    # first run: plain (lazily built structures come into being)
+            store[full_key] = "warm"
+            return self._eager(tensors, static)
+        if state == "warm":                                  # second run: learn the allocation sizes
+            rec = _Recorder(dev)
+            _REC = rec
+            try:
+                outs = self.fn(*tensors, **static)
+            except _NotRecordable:
+                _REC = None
+                store[full_key] = self.DISABLED
+                return self._eager(tensors, static)
+            finally:
+                _REC = None
+            store[full_key] = ("sizes", rec.sizes)
+            return list(outs)
+        # third run: every allocation in one arena, every call noted; then the native replay must reproduce it
+        rec = _Recorder(dev, sizes=state[1], inputs=tensors)
+        _REC = rec
+        try:
+            outs = list(self.fn(*tensors, **static))
+        except _NotRecordable:
+            store[full_key] = self.DISABLED
+            _REC = None
+            return self._eager(tensors, static)
+        finally:
+            _REC = None
+        specs = []
+        for o in outs:
+            if o is None:
+                specs.append(None)
+                continue
+            kind = rec._classify(o.data_ptr()) if o.numel() else (_lib.SEQ_IMM, 0, 0)
+            if kind[0] == _lib.SEQ_BASE and kind[1] == 0 and o.is_contiguous():
+                specs.append(("arena", kind[2], tuple(o.shape), o.dtype))
+            elif kind[0] == _lib.SEQ_BASE and kind[2] == 0 and tensors[kind[1] - 1] is o:
+                specs.append(("input", kind[1] - 1))
+            else:
+                store[full_key] = self.DISABLED              # an output the record cannot place
+                return outs
+        if rec.cursor != len(rec.sizes) or len(rec.jobs) > 8:
+            store[full_key] = self.DISABLED
+            return outs
+        plan = _Plan(rec, specs)
+        try:
+            again = plan.run(tensors, want=set(range(len(specs))))
+            same = all((a is None and b is None) or (a is b) or torch.equal(a, b) for a, b in zip(outs, again))
+        except (RuntimeError, ValueError, IndexError):
+            same = False
+        store[full_key] = plan if same else self.DISABLED
+        return outs
+
+    def _eager(self, tensors, static):
+        return list(self.fn(*[materialize(t) for t in tensors], **static))

@@ -1564,9 +1564,72 @@ def test_dropout_factor_in_the_input_gradient_epilogue_equals_rescaled_weights(p
     if p == 0.5:
         assert torch.equal(new, old)
     else:
-        assert float((new - old).abs().max()) <= 2.0 ** -22 * float(old.abs().max())
+        assert float((new - old).abs().max()) <= 2e-6 * float(old.abs().max())    # fp32 roundings of w * s, K = 512 terms
     fp32 = ops.transform_bwd_input(gagg, g, weight, root, relu_mask=mask, graph=graph, precision="fp32", out_scale=s)
     assert float((new - fp32).abs().max()) <= 1e-5 * float(fp32.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,frozen_input", [(0.0, False), (0.5, False), (0.0, True)])
+def test_native_step_replays_the_recorded_pass_bit_for_bit(p, frozen_input, monkeypatch):
+    """``ops.Region``: after three steps on a graph the encoder's forward and backward are issued by ONE native call each
+    (``rgcn_sequence_run`` over the recorded launch list, tensors placed in one arena).  Every step - through the
+    wrappers, while recording, replayed - gives the bits of the wrappers-only run (RGCN_NATIVE_STEP=0), with fresh
+    inputs every step (a replay must follow the step's own tensors, not the recorded addresses), with dropout (two
+    forward passes around torch's dropout kernel), with an input that needs no gradient, and inside a captured HIP graph."""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=120000, seed=13)
+    eid, etd = ei.to(dev), et.to(dev)
+    torch.manual_seed(13)
+    convs = [RGCNConv(64, 128, r).to(dev), RGCNConv(128, 128, r).to(dev)]
+    for c in convs:
+        c.bias.data.uniform_(-0.1, 0.1)
+    steps = 6
+    gen = torch.Generator().manual_seed(1)
+    xs = [torch.randn(n, 64, generator=gen).to(dev) for _ in range(steps)]
+    cots = [torch.randn(n, 128, generator=gen).to(dev) * (10.0 ** -k) for k in range(steps)]
+
+    def run_all():
+        results = []
+        for k in range(steps):
+            torch.manual_seed(100 + k)                                  # the dropout mask of step k
+            x = xs[k].clone().requires_grad_(not frozen_input)
+            for c in convs:
+                c.zero_grad(set_to_none=True)
+            out = rgcn_encoder2(x, eid, etd, convs[0], convs[1], dropout_p=p)
+            out.backward(cots[k])
+            results.append([out.detach().clone(), None if frozen_input else x.grad.clone()]
+                           + [q.grad.clone() for c in convs for q in c.parameters()])
+        return results
+
+    graph = ops.bucket(eid, etd, n, r)
+    graph.__dict__.pop("_regions", None)
+    monkeypatch.setattr(ops, "REGIONS", False)
+    want = run_all()
+    assert not graph.__dict__.get("_regions")
+    monkeypatch.setattr(ops, "REGIONS", True)
+    got = run_all()
+    plans = graph.__dict__["_regions"]
+    names = sorted(k[0] for k, v in plans.items() if isinstance(v, ops._Plan))
+    assert names == (["encoder2.backward", "encoder2.forward"] if p == 0 else
+                     ["encoder2.backward", "encoder2.layer1", "encoder2.layer2"]), (names, {k[0]: type(v) for k, v in plans.items()})
+    for k in range(steps):
+        for a, b in zip(got[k], want[k]):
+            assert (a is None and b is None) or torch.equal(a, b), k
+    # a replayed pass inside a captured HIP graph
+    if p == 0 and not frozen_input:
+        x = xs[0].clone().requires_grad_(True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        hip_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(hip_graph, stream=side):
+                out = rgcn_encoder2(x, eid, etd, convs[0], convs[1])
+                gx, = torch.autograd.grad(out, [x], cots[0])
+        torch.cuda.current_stream().wait_stream(side)
+        hip_graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want[0][0]) and torch.equal(gx, want[0][1])
 
 
 @pytest.mark.gpu
