@@ -33,6 +33,18 @@
 #include "rgcn_hub_finish.h"
 #include "rgcn_split.h"
 
+// tools/gemm_stamps.hip includes this file with RGCN_STAMPS defined: thread 0 of every workgroup then leaves the 100 MHz
+// wall clock at four points of the kernel (entry, main loop reached, main loop left, end) - where a launch's time goes.
+#ifdef RGCN_STAMPS
+__device__ unsigned long long g_rgcn_stamps[8192 * 4];
+#define RGCN_STAMP(i)                                                                                               \
+  do {                                                                                                              \
+    if (threadIdx.x == 0) g_rgcn_stamps[((blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define RGCN_STAMP(i)
+#endif
+
 namespace {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
+  RGCN_STAMP(0);
 
   // Hub rows of this workgroup's row tiles whose partial rows the gather left unsummed: summed here, by the whole
   // workgroup, exactly as k_reduce_partials would (same function), written to A1 and only then read back by the
@@ -437,6 +450,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
       }
     }
   };
+  RGCN_STAMP(1);
   while (ktq[0] < K1) k_tile(sa1);
   if (K2 > 0) {                                  // sums so far -> A2's scale (two exact power-of-two factors)
     const float down = pow2f(-ea1);
@@ -447,38 +461,49 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
     while (ktq[0] < K) k_tile(sa2);
   }
 
+  RGCN_STAMP(2);
   // C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   // two exact power-of-two factors and the caller's output factor (1, or 1 / (1 - p) of a dropout whose backward
   // rides in this epilogue): ONE rounding of acc * (ia * out_scale), ib exact
   const float ia = pow2f(K2 > 0 ? -ea2 : -ea1) * out_scale, ib = b_inv_scale[0];
   float cmax = 0.f;
-  if (m0 + BM <= M && n0 + BN <= N) {            // interior tile: straight-line stores (see k_gemm_nt_dma)
-    float bv[TN];
-    float mk[TN][16];
+  if (m0 + BM <= M && n0 + BN <= N) {
+    // Interior tile.  An MFMA accumulator holds 4 consecutive ROWS of one column per lane: stored as it stands that
+    // is 16 TN one-dword stores per lane (and as many mask loads), and a store tail is bound by the number of store
+    // INSTRUCTIONS, not by bytes (MI355X guide, T21).  So the wave turns its 32 x (32 TN) block through LDS - the ring
+    // is free once every wave has left the k loop (one barrier) - and every lane ends up with 4 consecutive COLUMNS of
+    // a row: 4 TN 16-byte stores (and 16-byte mask loads).  Same values, same arithmetic per element.
+    constexpr int W = 32 * TN;                     // columns of this wave's block
+    constexpr int RPR = 64 / (W / 4);              // rows one 16-byte-per-lane instruction covers
+    constexpr int NV = 32 / RPR;                   // such instructions per block
+    __builtin_amdgcn_s_barrier();
+    float* tr = reinterpret_cast<float*>(lds) + wave * (32 * W);
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int n = n0 + (wn * TN + b) * 32 + li;
-      bv[b] = bias ? bias[n] : 0.f;
-      if (EPI == EPI_MASK) {
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          mk[b][r] = mask[(size_t)m * N + n];
-        }
-      }
+      for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * W + b * 32 + li] = acc[b][r];
+    const int trow = lane / (W / 4), tc4 = (lane % (W / 4)) * 4;
+    const int nq = n0 + wn * W + tc4;
+    float4 bv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv4 = *reinterpret_cast<const float4*>(bias + nq);
+    float4 mk4[NV];
+    if (EPI == EPI_MASK) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q)
+        mk4[q] = *reinterpret_cast<const float4*>(mask + (size_t)(m0 + wm * 32 + q * RPR + trow) * N + nq);
     }
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int n = n0 + (wn * TN + b) * 32 + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float v = acc[b][r] * ia * ib + bv[b];
-        if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
-        if (EPI == EPI_MASK) v = mk[b][r] > 0.f ? v : 0.f;
-        cmax = fmaxf(cmax, fabsf(v));
-        C[(size_t)m * N + n] = v;
+    for (int q = 0; q < NV; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(tr + (q * RPR + trow) * W + tc4);
+      float4 v;
+      v.x = a.x * ia * ib + bv4.x; v.y = a.y * ia * ib + bv4.y; v.z = a.z * ia * ib + bv4.z; v.w = a.w * ia * ib + bv4.w;
+      if (EPI == EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (EPI == EPI_MASK) {
+        v.x = mk4[q].x > 0.f ? v.x : 0.f; v.y = mk4[q].y > 0.f ? v.y : 0.f;
+        v.z = mk4[q].z > 0.f ? v.z : 0.f; v.w = mk4[q].w > 0.f ? v.w : 0.f;
       }
+      cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      *reinterpret_cast<float4*>(C + (size_t)(m0 + wm * 32 + q * RPR + trow) * N + nq) = v;
     }
   } else {
 #pragma unroll
@@ -500,6 +525,10 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
     }
   }
   if (amax_out) rgcn_amax_publish(amax_out, cmax, seen);
+#ifdef RGCN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RGCN_STAMP(3);
 }
 
 // max |x| of up to kPrepTensors tensors, each into its own amax buffer, in ONE launch - no atomics and no prior
@@ -830,6 +859,7 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const float* __re
   const int li = lane & 31, lh = lane >> 5;
   const bool bias_block = (bias_part != nullptr) && (kc_tile == (K2 > 0 ? kc_tiles - 1 : 0));
   const bool do_bias = bias_block && (tid < 128);
+  RGCN_STAMP(0);
   unsigned rel_bits = 0u;                                        // m-tiles without any of this kc tile's relations: skipped
   if (tile_mask != nullptr && !bias_block && kc0 + TKC <= K1)
     for (int c = kc0; c < kc0 + TKC; c += kseg) rel_bits |= 1u << (c / kseg);
@@ -948,6 +978,7 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const float* __re
     __builtin_amdgcn_s_barrier();
     convert(cur, 0, 0);
   }
+  RGCN_STAMP(1);
   for (; cur < mend; ++t) {
     // own plane writes of tile t done; own DMAs of tile t + 1 landed (tile t + 2's may still fly); then everybody's
     if (aft < mend) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
@@ -998,19 +1029,44 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const float* __re
     aft = fut;
   }
 
+  RGCN_STAMP(2);
   const float ia = pow2f(-ea), ig = pow2f(-eg);
   float* out = slab + (size_t)split * Kc * N;
+  if (kc0 + TKC <= Kc && n0 + 128 <= N) {
+    // whole tile inside the slab: the wave turns its 32 x 64 block through LDS (the ring is free: every wave has left
+    // the loop) so that a lane stores 4 consecutive columns - 8 sixteen-byte stores instead of 32 one-dword stores
+    // (a store tail is bound by the number of store instructions: MI355X guide, T21)
+    __builtin_amdgcn_s_barrier();
+    float* tr = reinterpret_cast<float*>(lds) + wave * (32 * 64);
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int nn = n0 + (wn * 2 + b) * 32 + li;
-    if (nn >= N) continue;
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kc = kc0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (kc < Kc) out[(size_t)kc * N + nn] = acc[b][r] * ia * ig;
+      for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + b * 32 + li] = acc[b][r];
+    const int trow = lane >> 4, tc4 = (lane & 15) * 4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(tr + (q * 4 + trow) * 64 + tc4);
+      float4 v;
+      v.x = a.x * ia * ig; v.y = a.y * ia * ig; v.z = a.z * ia * ig; v.w = a.w * ia * ig;
+      *reinterpret_cast<float4*>(out + (size_t)(kc0 + wk * 32 + q * 4 + trow) * N + n0 + wn * 64 + tc4) = v;
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int nn = n0 + (wn * 2 + b) * 32 + li;
+      if (nn >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kc = kc0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (kc < Kc) out[(size_t)kc * N + nn] = acc[b][r] * ia * ig;
+      }
     }
   }
   if (do_bias && n0 + tid < N) bias_part[(size_t)split * N + n0 + tid] = bsum;
+#ifdef RGCN_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RGCN_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------

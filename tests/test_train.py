@@ -210,7 +210,7 @@ def test_fp16_gather_training_reaches_the_same_auc(tmp_path):
         log["C5_auc_one_epoch_synthetic"] = {"auc_roc_fp32_run": float(aucs[0]), "auc_roc_fp16_run": float(aucs[1]),
                                              "abs_difference": abs(float(aucs[0]) - float(aucs[1])),
                                              "optimizer_steps": int(steps), "train_edge_columns": int(trainer.train_edge_index.size(1)),
-                                             "held_out_pairs_scored": int(labels.numel())}
+                                             "held_out_pairs_scored": int(len(labels))}
         json.dump(log, open(log_path, "w"), indent=1, sort_keys=True)
     except OSError:
         pass
