@@ -187,13 +187,17 @@ class Run:
                       RGCNConv(dims[1], dims[2], r, num_bases=self.bases, gather_dtype=gdt)]
         self.cot_cpu = torch.randn(n, dims[2])
         self.summary = None
+        self.hot_rows = {}                  # (weighted structure?, row width) -> rows of the table the gather keeps in LDS
         if world == 1:
             eid, etd = ei.to(dev), et.to(dev)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ops.bucket(eid, etd, n, r)
+            graph = ops.bucket(eid, etd, n, r)
             torch.cuda.synchronize()
             self.bucket_ms = (time.perf_counter() - t0) * 1e3
+            for dd in set(dims):
+                self.hot_rows[(False, dd)] = graph.hot_rows(False, dd)
+                self.hot_rows[(True, dd)] = graph.hot_rows(True, dd)
             emb = self.emb_cpu.to(dev).requires_grad_(True)
             convs = self.convs = [c.to(dev) for c in self.convs]
             cot = self.cot_cpu.to(dev)
@@ -338,7 +342,10 @@ def kernel_tables(run, events, event_steps):
         edges, segments, table_rows = shape[(transposed, d)]
         nbytes = gather_bytes(edges, segments, d, transposed)
         comp = gather_compulsory_bytes(edges, segments, table_rows, d, transposed)
-        kernels.append({"kernel": f"k_aggregate<{d // 4},{'true' if transposed else 'false'}>", "kind": "gather",
+        hot = run.hot_rows.get((transposed, d), 0)
+        kernels.append({"kernel": (f"k_aggregate_hot<{d // 4},{'true' if transposed else 'false'},{hot}>" if hot else
+                                   f"k_aggregate<{d // 4},{'true' if transposed else 'false'}>"), "kind": "gather",
+                        "hot_rows_in_lds": hot,
                         "d": d, "transposed": transposed, "launches_per_step": len(ts) // event_steps,
                         "avg_us": avg * 1e6, "bytes": nbytes, "gbs": nbytes / avg / 1e9,
                         "compulsory_hbm_bytes": comp, "table_bytes": 4 * table_rows * d,

@@ -13,7 +13,7 @@ from ctypes import c_float, POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -104,6 +104,8 @@ PROTOTYPES = {
     "rgcn_transform_bwd_input_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, c_int,
                                                _P, _P, _P, c_size_t, _P, c_void_p, c_int, _P, c_float]),
     "rgcn_aggregate_deferrable": (c_int, [c_void_p, c_int, _I64]),
+    "rgcn_aggregate_hot_rows": (c_int, [c_void_p, c_int, _I64]),
+    "rgcn_hot_rows_kb": (c_int, [c_int]),
     "rgcn_aggregate_deferred": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, POINTER(SlabJob), _P]),
     "rgcn_transform_first_split": (c_int, [_P, _P, c_int, _I64, _I64, _I64, _I64, _P, c_int, _P, _P, c_size_t, _P]),
     "rgcn_transform_bwd_params_split_workspace_bytes": (c_size_t, [_I64, _I64, _I64, _I64]),

@@ -19,6 +19,9 @@
 // of a segment with a whole workgroup per item (up to 512 rows: 256/G row slots in parallel, LDS
 // combine in slot order), so even a 100k-edge hub costs one extra short launch and the result is
 // run-to-run deterministic.
+#include <algorithm>
+#include <cstdlib>
+
 #include <hip/hip_fp16.h>
 
 #include "rgcn_common.h"
@@ -191,6 +194,95 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
   if (amax_out) rgcn_amax_publish(amax_out, lmax, seen);
 }
 
+// The same gather for degree-skewed structures (rgcn_csr::hot_ids): on the PrimeKG-shaped graph a third of all row
+// reads go to the 64 most read rows of the table.  A workgroup copies the first H hot rows into LDS once (H x d floats:
+// 32 KB at most) and then walks its items like k_aggregate, except that an edge whose id says "hot row of rank s" (the
+// structure's col_hot / head_col_hot arrays: -2 - s) takes the row from LDS - the L2 never sees that read.  To make the
+// copy worth its 32 KB the grid is PERSISTENT: as many workgroups as fit the chip, each taking every gridDim.x-th
+// chunk of 256 / G items (the items are sorted by length, so the workgroups stay balanced).  Same rows, same adds in
+// the same order as k_aggregate: the same bits.
+template <int G, bool WEIGHTED, int H>
+__global__ __launch_bounds__(kThreads) void k_aggregate_hot(
+    const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
+    const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
+    float* __restrict__ agg, float* __restrict__ partial, int d, const int32_t* __restrict__ head_col,
+    const float* __restrict__ head_w, const int32_t* __restrict__ hot_ids, const rgcn_slab_job job, int gather_blocks,
+    int chunks) {
+  __shared__ float4 red[kThreads];               // pack combine (see rgcn_common.h)
+  __shared__ float4 hot[H * G];                  // hot row s, float4 c: hot[s * G + c]
+  __shared__ int32_t hot_id[RGCN_HOT_MAX];
+  if ((int)blockIdx.x >= gather_blocks) {        // workgroups past the gather: a pending slab reduction rides along
+    rgcn_slab_reduce_block<RGCN_SLAB_OUTS, RGCN_SLAB_GROUPS>(job, (int64_t)blockIdx.x - gather_blocks, red);
+    return;
+  }
+  const int gl = (int)threadIdx.x % G;
+  const int c4 = gl * 4;
+  const bool live = c4 < d;                      // lanes past the row end still carry ids for their group
+  if (threadIdx.x < RGCN_HOT_MAX) hot_id[threadIdx.x] = hot_ids[threadIdx.x];
+  for (int i = threadIdx.x; i < H * G; i += kThreads) {
+    const int s = i / G, c = (i % G) * 4;
+    hot[i] = c < d ? *reinterpret_cast<const float4*>(src + (size_t)hot_ids[s] * d + c) : f4zero();
+  }
+  __syncthreads();
+  for (int chunk = blockIdx.x; chunk < chunks; chunk += gather_blocks) {
+    const int64_t item_id = (int64_t)chunk * (kThreads / G) + (int64_t)threadIdx.x / G;
+    const bool have = item_id < nitems;          // whole lane groups only
+    // packs come first in the item order: the chunk's first slot says whether any is in here (uniform over the workgroup)
+    const bool has_packs = (items[(int64_t)chunk * (kThreads / G)].flags & RGCN_ITEM_PACK) != 0;
+    rgcn_item it = rgcn_item{0, 0, 0, RGCN_ITEM_SKIP};
+    if (have) it = items[item_id];
+    float4 acc = f4zero();
+    if (have) {
+      IdWindow<G, WEIGHTED> win;
+      win.init(item_id, gl, it, col, w, head_col, head_w);
+      for (int e = it.begin; e < it.end; e += kUnroll) {
+        int idx[kUnroll];
+        float wt[kUnroll];
+        float4 v[kUnroll];
+        win.get(idx, wt);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          v[u] = f4zero();
+          const int id = idx[u];
+          if (live && id != -1) {
+            const int s = -2 - id;               // >= 0: hot row of rank s
+            if (id < -1 && s < H) v[u] = hot[s * G + gl];
+            else v[u] = *reinterpret_cast<const float4*>(src + (size_t)(id < -1 ? hot_id[s] : id) * d + c4);
+          }
+        }
+        win.advance(gl, col, w);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          if (WEIGHTED) f4fma(acc, v[u], wt[u]);
+          else f4add(acc, v[u]);
+        }
+      }
+    }
+    bool writer = have && live;
+    if (has_packs) {                             // the runs of a pack meet in LDS; its leader adds them in slot order
+      red[threadIdx.x] = acc;
+      __syncthreads();
+      if (it.flags & (RGCN_ITEM_MEMBER | RGCN_ITEM_SKIP)) writer = false;
+      else {
+        const int followers = (it.flags >> RGCN_ITEM_FOLLOW_SHIFT) & (RGCN_PACK - 1);
+        for (int f = 1; f <= followers; ++f) f4add(acc, red[threadIdx.x + f * G]);
+      }
+      __syncthreads();                           // everybody has read `red` before the next chunk writes it
+    }
+    if (writer) {
+      if (it.flags & RGCN_ITEM_FINAL) {
+        if (cnt) {  // mean: true division by max(1, segment size), as `sum / count` does
+          const float c = cnt[it.dst];
+          acc.x /= c; acc.y /= c; acc.z /= c; acc.w /= c;
+        }
+        *reinterpret_cast<float4*>(agg + (size_t)it.dst * d + c4) = acc;
+      } else {
+        *reinterpret_cast<float4*>(partial + (size_t)it.dst * d + c4) = acc;
+      }
+    }
+  }
+}
+
 // fp16 feature table, fp32 accumulate (BASELINE.json configs[4]): the same walk with 8 halves
 // (16 B) per lane, so a row costs half the bytes (132 / 260 B per edge at d = 64 / 128) and a
 // wave64 carries 64 / (d/8) items.  Sums, partial rows and the output stay fp32.
@@ -317,6 +409,71 @@ __global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* _
     rgcn_amax_publish(amax_out, lmax);
 }
 
+// LDS rows of the hot-row gather by row width (32 KB of rows; RGCN_HOT_KB=16 halves it, 0 turns the path off) and the
+// coverage below which the plain gather is kept
+int g_hot_kb = -1;                                   // rgcn_hot_rows_kb: -1 = not set (environment / default)
+int hot_kb() {
+  static const int env = [] {
+    const char* e = getenv("RGCN_HOT_KB");
+    const int k = e ? atoi(e) : 32;
+    return (k == 0 || k == 16) ? k : 32;
+  }();
+  return g_hot_kb >= 0 ? g_hot_kb : env;
+}
+int persistent_blocks(int lds_bytes_per_block) {
+  static const int cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }();
+  const int per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, lds_bytes_per_block)));
+  return cus * per_cu;
+}
+
+template <int G, int H>
+void launch_hot(const rgcn_csr* c, bool weighted, const float* x, const float* cnt, float* agg, float* partial, int d,
+                hipStream_t stream, const rgcn_slab_job* tail) {
+  const int64_t nitems = c->num_items[0];
+  const int chunks = (int)ceil_div64(nitems, kThreads / G);
+  const int lds = (int)sizeof(float4) * (kThreads + H * G) + RGCN_HOT_MAX * 4;
+  const int gather_blocks = std::min(chunks, persistent_blocks(lds));
+  const rgcn_slab_job job = tail ? *tail : rgcn_slab_job{};
+  dim3 grid((unsigned)gather_blocks + (tail ? (unsigned)rgcn_slab_reduce_blocks(job) : 0u));
+  if (weighted)
+    k_aggregate_hot<G, true, H><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col_hot, c->val, cnt, agg, partial, d,
+                                                               c->head_col_hot, c->head_w, c->hot_ids, job, gather_blocks, chunks);
+  else
+    k_aggregate_hot<G, false, H><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col_hot, nullptr, cnt, agg, partial,
+                                                                d, c->head_col_hot, nullptr, c->hot_ids, job, gather_blocks, chunks);
+}
+
+// the hot-row gather for this launch, if the structure is skewed enough for the rows that fit: true = launched
+// rows of the table a gather of d-wide rows over this structure keeps in LDS (0: the plain gather)
+int hot_rows_for(const rgcn_csr* c, int64_t d) {
+  const int kb = hot_kb();
+  if (!c->hot_count || kb == 0 || !(d == 64 || d == 128 || d == 256)) return 0;
+  const int h = kb * 1024 / (int)(4 * d);
+  int step = 0;
+  while (step < 3 && RGCN_HOT_STEPS[step] < h) ++step;
+  return c->hot_cover[step] >= 0.10f ? h : 0;
+}
+
+template <int G>
+bool try_hot(const rgcn_csr* c, bool weighted, const float* x, const float* cnt, float* agg, float* partial, int d,
+             hipStream_t stream, const rgcn_slab_job* tail, unsigned* amax_out) {
+  if constexpr (G == 16 || G == 32 || G == 64) {
+    if (amax_out || d != 4 * G) return false;
+    constexpr int H32 = 32 * 1024 / (16 * G), H16 = H32 / 2;    // rows in 32 KB / 16 KB
+    const int h = hot_rows_for(c, d);
+    if (h == 0) return false;
+    if (h == H32) launch_hot<G, H32>(c, weighted, x, cnt, agg, partial, d, stream, tail);
+    else launch_hot<G, H16>(c, weighted, x, cnt, agg, partial, d, stream, tail);
+    return true;
+  }
+  return false;
+}
+
 template <int G>
 void launch_level(const rgcn_csr* c, int level, bool weighted, const float* x, const float* cnt, float* agg,
                   float* partial, int d, hipStream_t stream, const rgcn_slab_job* tail = nullptr,
@@ -325,6 +482,7 @@ void launch_level(const rgcn_csr* c, int level, bool weighted, const float* x, c
   if (nitems == 0) return;
   const unsigned gy = (unsigned)ceil_div64(d, 4 * G);
   if (level == 0) {
+    if (gy == 1 && try_hot<G>(c, weighted, x, cnt, agg, partial, d, stream, tail, amax_out)) return;
     const unsigned gather_blocks = (unsigned)ceil_div64(nitems, kThreads / G);
     const rgcn_slab_job job = tail ? *tail : rgcn_slab_job{};
     dim3 grid(gather_blocks + (tail ? (unsigned)rgcn_slab_reduce_blocks(job) : 0u), gy);   // tail only with gy == 1
@@ -425,6 +583,18 @@ int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t 
   if (!g) return RGCN_ERR_ARG;
   return aggregate_levels(g, transposed, 0, g->dir[transposed ? 1 : 0].num_levels, x, d, agg, workspace,
                           workspace_bytes, stream);
+}
+
+int rgcn_aggregate_hot_rows(const rgcn_graph* g, int transposed, int64_t d) {
+  if (!g) return 0;
+  return hot_rows_for(&g->dir[transposed ? 1 : 0], d);
+}
+
+int rgcn_hot_rows_kb(int kb) {
+  const int before = hot_kb();
+  if (kb == 0 || kb == 16 || kb == 32) g_hot_kb = kb;
+  else if (kb < 0) g_hot_kb = -1;
+  return before;
 }
 
 int rgcn_aggregate_deferrable(const rgcn_graph* g, int transposed, int64_t d) {

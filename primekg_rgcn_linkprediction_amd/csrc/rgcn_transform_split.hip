@@ -269,6 +269,21 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
   RGCN_STAMP(0);
+  // Every workgroup of the launch starts at once and its first loads meet a cold memory system (2 us and more): the
+  // operand maxima, the relation mask of the row tile and the published maximum are all requested HERE, together,
+  // so that the prologue pays that latency once - the first DMAs below need the mask, the split needs the maxima.
+  const float amax1_v = amax_of(amax1, lane) * a1_mul;
+  const float amax2_v = amax2.slots ? amax_of(amax2, lane) : 0.f;
+  const unsigned seen = rgcn_amax_peek(amax_out);
+  unsigned rel_mask = 0xffffffffu;
+  if (tile_mask) {
+    const int t32 = m0 >> 5;
+    rel_mask = 0u;
+#pragma unroll
+    for (int q = 0; q < WM; ++q)
+      if ((t32 + q) * 32 < M) rel_mask |= tile_mask[t32 + q];
+    rel_mask = __builtin_amdgcn_readfirstlane(rel_mask);
+  }
 
   // Hub rows of this workgroup's row tiles whose partial rows the gather left unsummed: summed here, by the whole
   // workgroup, exactly as k_reduce_partials would (same function), written to A1 and only then read back by the
@@ -334,15 +349,6 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
     }
   };
 
-  unsigned rel_mask = 0xffffffffu;
-  if (tile_mask) {
-    const int t32 = m0 >> 5;
-    rel_mask = 0u;
-#pragma unroll
-    for (int q = 0; q < WM; ++q)
-      if ((t32 + q) * 32 < M) rel_mask |= tile_mask[t32 + q];
-    rel_mask = __builtin_amdgcn_readfirstlane(rel_mask);
-  }
   auto next_kt = [&](int kt) {                   // next k-tile whose relation some row of this tile has
     kt += BK;
     while (kt < K1 && !((rel_mask >> (kt / kseg)) & 1u)) kt = (kt / kseg + 1) * kseg;
@@ -356,13 +362,12 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
   for (int j = 0; j < D; ++j)
     if (ktq[j] < K) stage(ktq[j], j);
 
-  const unsigned seen = rgcn_amax_peek(amax_out);
-  // scales of the two A operands (behind the first DMA issue).  A1 (the aggregate) is scaled by a BOUND,
+  // scales of the two A operands.  A1 (the aggregate) is scaled by a BOUND,
   // a1_mul * max |table it was gathered from| (a mean of rows cannot exceed the table's maximum; a weighted
   // sum not the structure's largest sum of weights times it), A2 by its own maximum; the accumulator is
   // carried over from the one scale to the other where the k loop passes from A1 to A2 (powers of two: exact).
-  const int ea1 = scale_exponent(amax_of(amax1, lane) * a1_mul);
-  const int ea2 = amax2.slots ? scale_exponent(amax_of(amax2, lane)) : ea1;
+  const int ea1 = scale_exponent(amax1_v);
+  const int ea2 = amax2.slots ? scale_exponent(amax2_v) : ea1;
   const float sa1 = pow2f(ea1), sa2 = pow2f(ea2);
 
   // byte addresses inside one buffer for the two 16-k steps of a k-tile

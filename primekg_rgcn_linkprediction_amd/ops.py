@@ -516,6 +516,10 @@ class BucketedGraph:
             cache[key] = bool(_L().rgcn_aggregate_deferrable(handle, int(transposed), int(d)))
         return cache[key]
 
+    def hot_rows(self, transposed: bool, d: int) -> int:
+        """rows of the gathered table a gather of d-wide rows keeps in LDS (``rgcn_aggregate_hot_rows``; 0: plain)"""
+        return int(_lib.load().rgcn_aggregate_hot_rows(self.handle, int(transposed and not self.bipartite), int(d)))
+
     def weight_bound(self, transposed: bool) -> float:
         """``|aggregate(x) row| <= weight_bound * max |x|``: 1 for the mean structure, the largest
         per-segment sum of edge weights for a weighted one (memoised; fixed for the life of the handle)"""
@@ -1513,7 +1517,7 @@ _SEQ_STREAM_POS = {"rgcn_absmax": 5, "rgcn_absmax_multi": 6, "rgcn_absmax_pack":
                    "rgcn_transform_fwd_split": 20, "rgcn_transform_bwd_input_split": 19, "rgcn_transform_first_split": 12,
                    "rgcn_transform_bwd_params_split_begin": 18, "rgcn_slab_reduce": 1, "rgcn_layer_fwd_fused": 17,
                    "rgcn_layer_bwd_input_fused": 17}
-_SEQ_PURE = ("rgcn_graph_tile_mask", "rgcn_graph_num_levels", "rgcn_graph_weight_bound", "rgcn_aggregate_deferrable",
+_SEQ_PURE = ("rgcn_aggregate_hot_rows", "rgcn_graph_tile_mask", "rgcn_graph_num_levels", "rgcn_graph_weight_bound", "rgcn_aggregate_deferrable",
              "rgcn_graph_num_edges", "rgcn_graph_num_nodes", "rgcn_graph_num_relations", "rgcn_abi_version", "rgcn_strerror")
 REGIONS = os.environ.get("RGCN_NATIVE_STEP", "1") == "1"      # 0: always through the wrappers (A/B runs, debugging)
 

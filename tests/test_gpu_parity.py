@@ -1529,6 +1529,59 @@ def test_fused_input_gradient_is_bit_identical_to_gather_then_transform(n, e, r,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_hot_rows_in_lds_change_no_bit(d):
+    """the gather of a degree-skewed structure keeps the most read rows of its table in LDS (persistent workgroups,
+    ids of such edges replaced by the row's rank): forward, transposed and the merged / weighted structures give the
+    bits of the plain gather - with 32 KB of rows, with 16 KB, and switched off; a uniform graph never takes the path;
+    hub-heavy segments (packs, partial rows, deferred tails) and a riding slab reduction go through it unchanged"""
+    from primekg_rgcn_linkprediction_amd import _lib
+    dev = need_gpu()
+    lib = _lib.load()
+    ei, et, n, r = synth.primekg_like(num_edges=300000, seed=21)
+    graph = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
+    flat, _, fn, fr = synth.uniform_graph(20000, 300000, 3, seed=3)
+    uniform = ops.BucketedGraph(flat.to(dev), _.to(dev), fn, fr)
+    gen = torch.Generator().manual_seed(d)
+    x = torch.randn(n, d, generator=gen).to(dev)
+    prev = lib.rgcn_hot_rows_kb(0)
+    try:
+        assert graph.hot_rows(False, d) == 0
+        want = {t: ops.aggregate(graph, x, transposed=t) for t in (False, True)}
+        merged = graph.merged_transposed()
+        tm = torch.randn(n * (r + 1), d, generator=gen).to(dev)
+        want_m = ops.aggregate(merged, tm)
+        want_def, hubs0 = ops.aggregate_deferred(graph, x)
+        for kb in (32, 16):
+            lib.rgcn_hot_rows_kb(kb)
+            rows = kb * 1024 // (4 * d)
+            assert graph.hot_rows(False, d) == rows and graph.hot_rows(True, d) == rows, (kb, graph.hot_rows(False, d))
+            assert uniform.hot_rows(False, d) == 0                     # no skew: the plain gather
+            for t in (False, True):
+                assert torch.equal(ops.aggregate(graph, x, transposed=t), want[t]), (kb, t)
+            assert torch.equal(ops.aggregate(merged, tm), want_m)
+            got_def, hubs = ops.aggregate_deferred(graph, x)
+            assert (hubs is None) == (hubs0 is None)
+            if hubs is not None:                                       # the rows the gather itself finished
+                rowptr = graph.arrays(False)[0].long()
+                short = (rowptr[1:] - rowptr[:-1]) <= 256
+                assert torch.equal(got_def.view(n * r, d)[short], want_def.view(n * r, d)[short])
+        # a pending slab reduction riding in the persistent grid
+        if d <= 128:
+            agg = want[False]
+            g = torch.randn(n, 128, generator=gen).to(dev)
+            ref = ops.transform_bwd_params(agg, x, g, r, precision="split")
+            pend = ops.transform_bwd_params(agg, x, g, r, precision="split", defer=True)
+            got = ops.aggregate(graph, g, transposed=True, tail=pend)
+            assert pend.done and all(torch.equal(a, b) for a, b in zip(pend.grads, ref))
+            lib.rgcn_hot_rows_kb(0)
+            assert torch.equal(got, ops.aggregate(graph, g, transposed=True))
+    finally:
+        lib.rgcn_hot_rows_kb(prev if prev in (0, 16, 32) else -1)
+        lib.rgcn_hot_rows_kb(-1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("p", [0.5, 0.1])
 def test_dropout_factor_in_the_input_gradient_epilogue_equals_rescaled_weights(p):
     """``out_scale`` (the 1 / (1 - p) of the dropout between the layers, src/models/rgcn.py:125, whose backward
