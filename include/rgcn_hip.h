@@ -178,13 +178,14 @@ int rgcn_aggregate_amax(const rgcn_graph* g, int transposed, const float* x, int
 int rgcn_aggregate_deferrable(const rgcn_graph* g, int transposed, int64_t d);
 int rgcn_aggregate_deferred(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
                             void* workspace, size_t workspace_bytes, const rgcn_slab_job* job, void* stream);
-/* Hot rows.  Bucketing also counts how often each row of the gathered table is read: on a degree-skewed graph (PrimeKG:
- * hub genes) the 64 most read rows are a third of all row reads.  Where the 128 most read rows take >= 10 % of a
- * structure's edges, the fp32 gathers of 64 / 128 / 256-wide rows keep the first 128 / 64 / 32 of them (32 KB) in LDS
- * for the life of a (persistent) workgroup and serve those edges from there; same sums in the same order, same bits.
- * rgcn_aggregate_hot_rows: how many rows such a gather keeps (0: the plain gather - no skew, another width, a uniform
- * graph).  rgcn_hot_rows_kb: LDS budget of the path for the process, 32 (default), 16 or 0 (off); < 0 restores the
- * default / RGCN_HOT_KB; returns the previous value.  An A/B switch, not part of the arithmetic. */
+/* Hot rows (OFF by default: measured slower than the plain gather on the MI355X, kept as an A/B path).  While switched
+ * on, bucketing also counts how often each row of the gathered table is read: on a degree-skewed graph (PrimeKG: hub
+ * genes) the 64 most read rows are a third of all row reads.  Where the 128 most read rows take >= 10 % of a structure's
+ * edges, the fp32 gathers of 64 / 128 / 256-wide rows keep the first 128 / 64 / 32 of them (32 KB) in LDS for the life
+ * of a (persistent) workgroup and serve those edges from there; same sums in the same order, same bits.
+ * rgcn_aggregate_hot_rows: how many rows such a gather keeps (0: the plain gather).  rgcn_hot_rows_kb: LDS budget of
+ * the path for the process - 0 (off, the default), 16 or 32; -1 restores RGCN_HOT_KB / the default; any other value
+ * only queries; returns the previous value.  Set it BEFORE the graph is bucketed. */
 int rgcn_aggregate_hot_rows(const rgcn_graph* g, int transposed, int64_t d);
 int rgcn_hot_rows_kb(int kb);
 /* One launch of the above (level in [0, rgcn_graph_num_levels)); calling the levels in order

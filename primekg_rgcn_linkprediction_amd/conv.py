@@ -437,17 +437,30 @@ def _layer_eval_blocked(graph: "ops.BucketedGraph", x: Tensor, table: Tensor, we
     return out
 
 
-def encoder2_eval(x: Tensor, graph: "ops.BucketedGraph", w1, root1, b1, w2, root2, b2, gather_dtype=None) -> Tensor:
-    """conv2(relu(conv1(x))) with nothing kept for a backward and no whole-graph aggregate (see above)"""
-    x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
-    root1 = root1.contiguous() if root1 is not None else None
-    root2 = root2.contiguous() if root2 is not None else None
+def _enc2_eval(x, w1, root1, b1, w2, root2, b2, *, graph, gather_dtype):
     half = gather_dtype == torch.float16
     scales = _Scales(x, layers=[(w1, root1), (w2, root2)])
     x_amax, h_amax = scales.first, scales.slot()
     pk1, pk2 = scales.packed
     h = _layer_eval_blocked(graph, x, _table(x, gather_dtype), w1, root1, b1, True, half, (x_amax, x_amax), h_amax, pk1)
-    return _layer_eval_blocked(graph, h, _table(h, gather_dtype), w2, root2, b2, False, half, (h_amax, h_amax), None, pk2)
+    return (_layer_eval_blocked(graph, h, _table(h, gather_dtype), w2, root2, b2, False, half, (h_amax, h_amax), None, pk2),)
+
+
+_R_EVAL = ops.Region("encoder2.eval", _enc2_eval)
+
+
+def encoder2_eval(x: Tensor, graph: "ops.BucketedGraph", w1, root1, b1, w2, root2, b2, gather_dtype=None) -> Tensor:
+    """conv2(relu(conv1(x))) with nothing kept for a backward and no whole-graph aggregate (see above); a Region:
+    one native call per forward once recorded (``Trainer.validate`` re-runs it for every validation batch,
+    src/train.py:389-395)"""
+    x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
+    root1 = root1.contiguous() if root1 is not None else None
+    root2 = root2.contiguous() if root2 is not None else None
+    b1 = b1.contiguous() if b1 is not None else None
+    b2 = b2.contiguous() if b2 is not None else None
+    key = (tuple(x.shape), tuple(w1.shape), tuple(w2.shape), root1 is not None, b1 is not None, root2 is not None,
+           b2 is not None, gather_dtype, _EVAL_FUSED, _EVAL_BLOCK_BYTES, _EVAL_INLINE_LIMIT)
+    return _R_EVAL.run(graph, key, (x, w1, root1, b1, w2, root2, b2), dict(graph=graph, gather_dtype=gather_dtype), want={0})[0]
 
 
 def _check_x(x: Tensor) -> None:

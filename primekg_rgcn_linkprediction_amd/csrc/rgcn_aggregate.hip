@@ -199,31 +199,45 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
 // 32 KB at most) and then walks its items like k_aggregate, except that an edge whose id says "hot row of rank s" (the
 // structure's col_hot / head_col_hot arrays: -2 - s) takes the row from LDS - the L2 never sees that read.  To make the
 // copy worth its 32 KB the grid is PERSISTENT: as many workgroups as fit the chip, each taking every gridDim.x-th
-// chunk of 256 / G items (the items are sorted by length, so the workgroups stay balanced).  Same rows, same adds in
-// the same order as k_aggregate: the same bits.
+// chunk of 256 / G items (the items are sorted by length, so the workgroups stay balanced).
+// Straight-line inner loop (a per-edge branch made hipcc serialise the eight row loads of a round: 2x slower than the
+// plain gather): every edge issues BOTH a buffer load of the table row and an LDS read of a hot row - the buffer load
+// with an out-of-range offset where the row is hot or the edge does not exist (the hardware returns zeros and sends no
+// request), the LDS read from an all-zero row where the edge is not hot - and the row is the bitwise OR of the two.
+// Same rows, same adds in the same order as k_aggregate: the same bits.
+// MEASURED (MI355X, C2, profiles/r03_hot_rows.txt): SLOWER than the plain gather - d = 128: 50.5 us against 33.6 us with
+// 64 rows (a third of the reads) in LDS, d = 64: 36.4 against 22.5 - so the path is OFF by default (RGCN_HOT_KB=32 /
+// rgcn_hot_rows_kb(32) before the graph is bucketed turns it on).  The gather is not bound by the bytes the L2 delivers
+// but by memory instructions in flight: the variant issues as many per edge, and its 32 KB of rows + 93-108 registers
+// leave 4 waves per SIMD where the plain kernel keeps 8.  Kept as the measured negative result it is.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kNoRow = 0xfffffff0u;         // a byte offset no table reaches (tables up to 4 GB - 16 take this path)
+
 template <int G, bool WEIGHTED, int H>
 __global__ __launch_bounds__(kThreads) void k_aggregate_hot(
-    const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
+    const float* __restrict__ src, unsigned table_bytes, const rgcn_item* __restrict__ items, int64_t nitems,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
     float* __restrict__ agg, float* __restrict__ partial, int d, const int32_t* __restrict__ head_col,
     const float* __restrict__ head_w, const int32_t* __restrict__ hot_ids, const rgcn_slab_job job, int gather_blocks,
     int chunks) {
   __shared__ float4 red[kThreads];               // pack combine (see rgcn_common.h)
-  __shared__ float4 hot[H * G];                  // hot row s, float4 c: hot[s * G + c]
+  __shared__ u32x4 hot[(H + 1) * G];             // hot row s, float4 c: hot[s * G + c]; row H: zeros
   __shared__ int32_t hot_id[RGCN_HOT_MAX];
   if ((int)blockIdx.x >= gather_blocks) {        // workgroups past the gather: a pending slab reduction rides along
     rgcn_slab_reduce_block<RGCN_SLAB_OUTS, RGCN_SLAB_GROUPS>(job, (int64_t)blockIdx.x - gather_blocks, red);
     return;
   }
   const int gl = (int)threadIdx.x % G;
-  const int c4 = gl * 4;
-  const bool live = c4 < d;                      // lanes past the row end still carry ids for their group
+  const int c4 = gl * 4;                         // d == 4 G: every lane of a group carries columns of the row
   if (threadIdx.x < RGCN_HOT_MAX) hot_id[threadIdx.x] = hot_ids[threadIdx.x];
-  for (int i = threadIdx.x; i < H * G; i += kThreads) {
+  for (int i = threadIdx.x; i < (H + 1) * G; i += kThreads) {
     const int s = i / G, c = (i % G) * 4;
-    hot[i] = c < d ? *reinterpret_cast<const float4*>(src + (size_t)hot_ids[s] * d + c) : f4zero();
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (s < H) v = *reinterpret_cast<const u32x4*>(src + (size_t)hot_ids[s] * d + c);
+    hot[i] = v;
   }
   __syncthreads();
+  const __amdgpu_buffer_rsrc_t table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)table_bytes, 0x00020000);
   for (int chunk = blockIdx.x; chunk < chunks; chunk += gather_blocks) {
     const int64_t item_id = (int64_t)chunk * (kThreads / G) + (int64_t)threadIdx.x / G;
     const bool have = item_id < nitems;          // whole lane groups only
@@ -238,27 +252,29 @@ __global__ __launch_bounds__(kThreads) void k_aggregate_hot(
       for (int e = it.begin; e < it.end; e += kUnroll) {
         int idx[kUnroll];
         float wt[kUnroll];
-        float4 v[kUnroll];
+        u32x4 ga[kUnroll], hv[kUnroll];
         win.get(idx, wt);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-          v[u] = f4zero();
           const int id = idx[u];
-          if (live && id != -1) {
-            const int s = -2 - id;               // >= 0: hot row of rank s
-            if (id < -1 && s < H) v[u] = hot[s * G + gl];
-            else v[u] = *reinterpret_cast<const float4*>(src + (size_t)(id < -1 ? hot_id[s] : id) * d + c4);
-          }
+          const int s = -2 - id;                 // >= 0: hot row of rank s
+          const bool in_lds = id < -1 && s < H;
+          const int row = id < -1 ? hot_id[s & (RGCN_HOT_MAX - 1)] : id;      // a hot row beyond the H kept ones: by its id
+          const unsigned off = (id == -1 || in_lds) ? kNoRow : ((unsigned)row * (unsigned)d + (unsigned)c4) * 4u;
+          ga[u] = __builtin_amdgcn_raw_buffer_load_b128(table, off, 0, 0);
+          hv[u] = hot[(in_lds ? s : H) * G + gl];
         }
         win.advance(gl, col, w);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-          if (WEIGHTED) f4fma(acc, v[u], wt[u]);
-          else f4add(acc, v[u]);
+          const u32x4 b = ga[u] | hv[u];
+          const float4 v = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
+          if (WEIGHTED) f4fma(acc, v, wt[u]);
+          else f4add(acc, v);
         }
       }
     }
-    bool writer = have && live;
+    bool writer = have;
     if (has_packs) {                             // the runs of a pack meet in LDS; its leader adds them in slot order
       red[threadIdx.x] = acc;
       __syncthreads();
@@ -411,12 +427,14 @@ __global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* _
 
 // LDS rows of the hot-row gather by row width (32 KB of rows; RGCN_HOT_KB=16 halves it, 0 turns the path off) and the
 // coverage below which the plain gather is kept
+// LDS budget of the hot-row gather: 0 = off (the DEFAULT - measured on the MI355X the path is slower than the plain
+// gather, see the kernel's header), 16 or 32 KB; from RGCN_HOT_KB or rgcn_hot_rows_kb().
 int g_hot_kb = -1;                                   // rgcn_hot_rows_kb: -1 = not set (environment / default)
 int hot_kb() {
   static const int env = [] {
     const char* e = getenv("RGCN_HOT_KB");
-    const int k = e ? atoi(e) : 32;
-    return (k == 0 || k == 16) ? k : 32;
+    const int k = e ? atoi(e) : 0;
+    return (k == 16 || k == 32) ? k : 0;
   }();
   return g_hot_kb >= 0 ? g_hot_kb : env;
 }
@@ -436,15 +454,16 @@ void launch_hot(const rgcn_csr* c, bool weighted, const float* x, const float* c
                 hipStream_t stream, const rgcn_slab_job* tail) {
   const int64_t nitems = c->num_items[0];
   const int chunks = (int)ceil_div64(nitems, kThreads / G);
-  const int lds = (int)sizeof(float4) * (kThreads + H * G) + RGCN_HOT_MAX * 4;
+  const int lds = (int)sizeof(float4) * (kThreads + (H + 1) * G) + RGCN_HOT_MAX * 4;
+  const unsigned table_bytes = (unsigned)((size_t)c->n_other * (size_t)d * sizeof(float));
   const int gather_blocks = std::min(chunks, persistent_blocks(lds));
   const rgcn_slab_job job = tail ? *tail : rgcn_slab_job{};
   dim3 grid((unsigned)gather_blocks + (tail ? (unsigned)rgcn_slab_reduce_blocks(job) : 0u));
   if (weighted)
-    k_aggregate_hot<G, true, H><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col_hot, c->val, cnt, agg, partial, d,
+    k_aggregate_hot<G, true, H><<<grid, kThreads, 0, stream>>>(x, table_bytes, c->items[0], nitems, c->col_hot, c->val, cnt, agg, partial, d,
                                                                c->head_col_hot, c->head_w, c->hot_ids, job, gather_blocks, chunks);
   else
-    k_aggregate_hot<G, false, H><<<grid, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col_hot, nullptr, cnt, agg, partial,
+    k_aggregate_hot<G, false, H><<<grid, kThreads, 0, stream>>>(x, table_bytes, c->items[0], nitems, c->col_hot, nullptr, cnt, agg, partial,
                                                                 d, c->head_col_hot, nullptr, c->hot_ids, job, gather_blocks, chunks);
 }
 
@@ -453,6 +472,7 @@ void launch_hot(const rgcn_csr* c, bool weighted, const float* x, const float* c
 int hot_rows_for(const rgcn_csr* c, int64_t d) {
   const int kb = hot_kb();
   if (!c->hot_count || kb == 0 || !(d == 64 || d == 128 || d == 256)) return 0;
+  if ((size_t)c->n_other * (size_t)d * sizeof(float) > (size_t)kNoRow) return 0;      // 32-bit buffer offsets
   const int h = kb * 1024 / (int)(4 * d);
   int step = 0;
   while (step < 3 && RGCN_HOT_STEPS[step] < h) ++step;
@@ -593,7 +613,7 @@ int rgcn_aggregate_hot_rows(const rgcn_graph* g, int transposed, int64_t d) {
 int rgcn_hot_rows_kb(int kb) {
   const int before = hot_kb();
   if (kb == 0 || kb == 16 || kb == 32) g_hot_kb = kb;
-  else if (kb < 0) g_hot_kb = -1;
+  else if (kb == -1) g_hot_kb = -1;                  // back to RGCN_HOT_KB / the default; any other value: query only
   return before;
 }
 

@@ -322,13 +322,11 @@ __global__ void k_hot_encode(const int32_t* __restrict__ ids, int64_t n, const i
   out[i] = rk >= 0 ? -2 - rk : id;
 }
 
-// RGCN_HOT_ROWS=0 turns the detection off (A/B runs); the minimum coverage a structure needs is 10 % of its edges
-// on its RGCN_HOT_MAX most read rows - a uniform graph (C4) never gets there and keeps the plain gather.
+// Runs only while the hot-row gather is switched on (rgcn_hot_rows_kb() != 0 when the structure is bucketed: off by
+// default); the minimum coverage a structure needs is 10 % of its edges on its RGCN_HOT_MAX most read rows - a uniform
+// graph (C4) never gets there and keeps the plain gather.
 int find_hot_rows(rgcn_csr* c, int64_t E, hipStream_t stream) {
-  static const bool enabled = [] {
-    const char* e = getenv("RGCN_HOT_ROWS");
-    return !(e && e[0] == '0');
-  }();
+  const bool enabled = rgcn_hot_rows_kb(-2) != 0;            // -2: query only
   const int64_t n = c->n_other;
   if (!enabled || E < 4096 || n < 4 * RGCN_HOT_MAX || n > (int64_t)1 << 30 || c->num_items[0] <= 0) return RGCN_OK;
   struct Tmp {

@@ -62,11 +62,18 @@ SCHEMES = ("pull", "push")
 
 
 class HipBackend:
-    """The product compute path: every call lands in librgcn_hip.so."""
+    """The product compute path: every call lands in librgcn_hip.so.  The per-layer segments between two exchanges
+    (gather + transform of a row range; gather + input-gradient transform) are ``ops.Region`` passes: recorded on
+    their second and third run over a shard structure, then issued by one native call each - at N > 1 a rank's
+    kernels shrink with 1 / N while the host cost of issuing them does not."""
 
     def __init__(self):
         from . import ops
         self.ops = ops
+        self._fwd = ops.Region("dist.layer_fwd", self._fwd_pass)
+        self._fwd_rows = ops.Region("dist.layer_fwd_rows", self._fwd_rows_pass)
+        self._bwd = ops.Region("dist.input_grad", self._bwd_pass)
+        self._bwd_rows = ops.Region("dist.input_grad_rows", self._bwd_rows_pass)
 
     def make_shard(self, key, other, etype, n_key, n_other, num_relations, edge_weight=None):
         return self.ops.BucketedGraph.from_shard(key, other, etype, n_key, n_other, num_relations,
@@ -96,11 +103,53 @@ class HipBackend:
         gx = self.ops.transform_bwd_input(gagg, g, weight, root, relu_mask, shard, amax=amax, amax_mul=mul)
         if out is None:
             return gx
+        self.ops.guard_torch_op("row-range copy of an input gradient")
         out.copy_(gx)                     # (the input-gradient entry points allocate their result: one row-range copy)
         return out
 
     def transform_bwd_params(self, agg, x, g, num_relations, want_root, want_bias, shard=None):
         return self.ops.transform_bwd_params(agg, x, g, num_relations, want_root, want_bias, shard)
+
+    # ---- whole segments (what _layer_fwd / _input_grad call when the backend has them) ------------------------
+    def _fwd_pass(self, tbl, x, weight, root, bias, *, shard, relu):
+        agg = self.ops.aggregate(shard, tbl)
+        return self.transform_fwd(agg, x, weight, root, bias, relu, shard, table=tbl), agg
+
+    def _fwd_rows_pass(self, tbl, x, weight, root, bias, agg, out, *, shard, relu, lo, hi):
+        """rows [lo, hi) of `agg` / `out` (allocated by the caller when lo == 0 is not the first call)"""
+        self.ops.aggregate(shard, tbl, out=agg[lo:hi])
+        self.transform_fwd(agg[lo:hi], x[lo:hi], weight, root, bias, relu, shard, table=tbl, out=out[lo:hi])
+        return ()
+
+    def _bwd_pass(self, tbl, g, weight, root, mask, *, shard):
+        gagg = self.ops.aggregate(shard, tbl)
+        return (self.transform_bwd_input(gagg, g, weight, root, mask, shard, table=tbl),)
+
+    def _bwd_rows_pass(self, tbl, g, weight, root, mask, gagg, *, shard, lo, hi):
+        self.ops.aggregate(shard, tbl, out=gagg[lo:hi])
+        m = mask[lo:hi] if mask is not None else None
+        return (self.transform_bwd_input(gagg[lo:hi], g[lo:hi], weight, root, m, shard, table=tbl),)
+
+    @staticmethod
+    def _key(*tensors, extra=()):
+        return tuple(tuple(t.shape) if t is not None else None for t in tensors) + tuple(extra)
+
+    def layer_fwd(self, shard, tbl, x, weight, root, bias, relu):
+        out, agg = self._fwd.run(shard, self._key(tbl, x, weight, root, bias, extra=(relu,)), (tbl, x, weight, root, bias),
+                                 dict(shard=shard, relu=relu), want={0, 1})
+        return out, agg
+
+    def layer_fwd_rows(self, shard, tbl, x, weight, root, bias, relu, agg, out, lo, hi):
+        self._fwd_rows.run(shard, self._key(tbl, x, weight, root, bias, agg, out, extra=(relu, lo, hi)),
+                           (tbl, x, weight, root, bias, agg, out), dict(shard=shard, relu=relu, lo=lo, hi=hi))
+
+    def input_grad(self, shard, tbl, g, weight, root, mask):
+        return self._bwd.run(shard, self._key(tbl, g, weight, root, mask), (tbl, g, weight, root, mask), dict(shard=shard),
+                             want={0})[0]
+
+    def input_grad_rows(self, shard, tbl, g, weight, root, mask, gagg, lo, hi):
+        return self._bwd_rows.run(shard, self._key(tbl, g, weight, root, mask, gagg, extra=(lo, hi)),
+                                  (tbl, g, weight, root, mask, gagg), dict(shard=shard, lo=lo, hi=hi), want={0})[0]
 
 
 # ------------------------------------------------------------------------------------------
@@ -513,8 +562,11 @@ def _layer_fwd(x, weight, root, bias, relu, shard: RankShard, backend, group):
     """one layer on this rank's rows -> (out, agg as the parameter-gradient GEMM needs it)"""
     if shard.scheme == "pull":
         halo = _Halo(x, shard.halo_in, group)                              # in flight ...
+        native = hasattr(backend, "layer_fwd")                             # whole segments as one native call each
         if not shard.split:
             tbl = halo.table()
+            if native:
+                return backend.layer_fwd(shard.g_in, tbl, x, weight, root, bias, relu)
             agg = backend.aggregate(shard.g_in, tbl)
             return backend.transform_fwd(agg, x, weight, root, bias, relu, shard.g_in, table=tbl), agg
         # ... behind the interior rows, which read own rows only; the boundary rows follow the wait.  Both halves
@@ -522,6 +574,10 @@ def _layer_fwd(x, weight, root, bias, relu, shard: RankShard, backend, group):
         k = shard.num_interior
         agg = x.new_empty(shard.cap, shard.num_relations * x.size(1))
         out = x.new_empty(shard.cap, weight.size(2))
+        if native:
+            backend.layer_fwd_rows(shard.g_in_int, x, x, weight, root, bias, relu, agg, out, 0, k)
+            backend.layer_fwd_rows(shard.g_in_bnd, halo.table(), x, weight, root, bias, relu, agg, out, k, shard.cap)
+            return out, agg
         backend.aggregate(shard.g_in_int, x, out=agg[:k])
         backend.transform_fwd(agg[:k], x[:k], weight, root, bias, relu, shard.g_in_int, table=x, out=out[:k])
         tbl = halo.table()
@@ -563,12 +619,19 @@ def _input_grad(g, weight, root, relu_mask, shard: RankShard, backend, group, ha
     """``halo``: the exchange of g's rows if the caller issued it already (so that work that needs own rows only -
     the parameter-gradient GEMM - runs while it is in flight)"""
     halo = halo if halo is not None else _Halo(g, shard.halo_out, group)
+    native = hasattr(backend, "input_grad")
     if not shard.split:
         tbl = halo.table()
+        if native:
+            return backend.input_grad(shard.g_out, tbl, g, weight, root, relu_mask)
         gagg = backend.aggregate(shard.g_out, tbl)
         return backend.transform_bwd_input(gagg, g, weight, root, relu_mask, shard.g_out, table=tbl)
     k = shard.num_interior
     gagg = g.new_empty(shard.cap, shard.num_relations * g.size(1))
+    if native:
+        gx_i = backend.input_grad_rows(shard.g_out_int, g, g, weight, root, relu_mask, gagg, 0, k)
+        gx_b = backend.input_grad_rows(shard.g_out_bnd, halo.table(), g, weight, root, relu_mask, gagg, k, shard.cap)
+        return torch.cat([gx_i, gx_b])
     gx = g.new_empty(shard.cap, weight.size(1))
     mask_i = relu_mask[:k] if relu_mask is not None else None
     mask_b = relu_mask[k:] if relu_mask is not None else None

@@ -139,6 +139,16 @@ def _worker(rank, world, port, n, e, r, dims, seed, q, use_hip=False, scheme="pu
         cot_own = enc.shard_rows(cot).to(dev)
         cot_own[enc.shard.num_own:] = 7.0            # junk in the padding slots must not reach any gradient
         out_own = enc.step(cot_own)
+        if use_hip:        # the segments between exchanges become recorded passes (ops.Region) on their second and third
+            first = [out_own.clone(), enc.emb.grad.clone()] + [p.grad.clone() for c in enc.convs for p in c.parameters()]
+            for _ in range(4):                      # run: every later step - recorded, then replayed natively - same bits
+                again = enc.step(cot_own)
+                now = [again, enc.emb.grad] + [p.grad for c in enc.convs for p in c.parameters()]
+                assert all(torch.equal(a, b) for a, b in zip(first, now))
+            if scheme == "pull":
+                plans = [v for g in (enc.shard.g_in, enc.shard.g_out, enc.shard.g_in_int, enc.shard.g_out_bnd) if g is not None
+                         for v in g.__dict__.get("_regions", {}).values()]
+                assert plans and all(isinstance(v, enc.backend.ops._Plan) for v in plans), [type(v) for v in plans]
         with torch.no_grad():                       # the per-layer nodes give the same rows
             assert torch.allclose(enc.forward_layers(), out_own, rtol=1e-6, atol=1e-6)
         out = enc.gather_output(out_own).cpu()

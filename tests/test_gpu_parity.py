@@ -1539,16 +1539,19 @@ def test_hot_rows_in_lds_change_no_bit(d):
     dev = need_gpu()
     lib = _lib.load()
     ei, et, n, r = synth.primekg_like(num_edges=300000, seed=21)
-    graph = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
     flat, _, fn, fr = synth.uniform_graph(20000, 300000, 3, seed=3)
-    uniform = ops.BucketedGraph(flat.to(dev), _.to(dev), fn, fr)
+    prev = lib.rgcn_hot_rows_kb(32)                    # the path is off by default: on while these graphs are bucketed
+    try:
+        graph = ops.BucketedGraph(ei.to(dev), et.to(dev), n, r)
+        uniform = ops.BucketedGraph(flat.to(dev), _.to(dev), fn, fr)
+        merged = graph.merged_transposed()
+    finally:
+        lib.rgcn_hot_rows_kb(0)
     gen = torch.Generator().manual_seed(d)
     x = torch.randn(n, d, generator=gen).to(dev)
-    prev = lib.rgcn_hot_rows_kb(0)
     try:
         assert graph.hot_rows(False, d) == 0
         want = {t: ops.aggregate(graph, x, transposed=t) for t in (False, True)}
-        merged = graph.merged_transposed()
         tm = torch.randn(n * (r + 1), d, generator=gen).to(dev)
         want_m = ops.aggregate(merged, tm)
         want_def, hubs0 = ops.aggregate_deferred(graph, x)
@@ -1577,8 +1580,8 @@ def test_hot_rows_in_lds_change_no_bit(d):
             lib.rgcn_hot_rows_kb(0)
             assert torch.equal(got, ops.aggregate(graph, g, transposed=True))
     finally:
-        lib.rgcn_hot_rows_kb(prev if prev in (0, 16, 32) else -1)
         lib.rgcn_hot_rows_kb(-1)
+        assert prev in (0, 16, 32)
 
 
 @pytest.mark.gpu
