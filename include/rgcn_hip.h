@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 18
+#define RGCN_ABI_VERSION 19
 
 enum {
   RGCN_OK = 0,
@@ -178,6 +178,17 @@ int rgcn_aggregate_amax(const rgcn_graph* g, int transposed, const float* x, int
 int rgcn_aggregate_deferrable(const rgcn_graph* g, int transposed, int64_t d);
 int rgcn_aggregate_deferred(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
                             void* workspace, size_t workspace_bytes, const rgcn_slab_job* job, void* stream);
+/* The first gather of a forward pass with the pass's first launch (rgcn_absmax_pack: max |x| into x_amax, the cleared
+ * amax buffers, the layers' split weight images) riding in its grid as extra workgroups: the gather reads x but needs
+ * neither result, the transform after it needs both - the 12 us latency chain of the stand-alone launch then runs beside
+ * the gather instead of before it.  x is both the gathered table [n_other, d] and the tensor whose maximum is taken;
+ * mean structures, d in {64, 128, 256}; deferred != 0: as rgcn_aggregate_deferred (hub tails left to the transform).
+ * The prep arguments are those of rgcn_absmax_pack (HOST arrays of `count` entries).  Same bits as the two launches. */
+int rgcn_aggregate_prep(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg, void* workspace,
+                        size_t workspace_bytes, int deferred, float* x_amax, float* zero_buffers, int zero_count,
+                        int count, const float* const* weights, const float* const* roots, const int64_t* num_relations,
+                        const int64_t* d_in, const int64_t* d_out, void* const* packed, const size_t* packed_bytes,
+                        void* stream);
 /* Hot rows (OFF by default: measured slower than the plain gather on the MI355X, kept as an A/B path).  While switched
  * on, bucketing also counts how often each row of the gathered table is read: on a degree-skewed graph (PrimeKG: hub
  * genes) the 64 most read rows are a third of all row reads.  Where the 128 most read rows take >= 10 % of a structure's
@@ -509,7 +520,7 @@ enum {
   RGCN_FN_ABSMAX = 0, RGCN_FN_ABSMAX_MULTI, RGCN_FN_ABSMAX_PACK, RGCN_FN_WEIGHTS_SPLIT_PACK_MULTI, RGCN_FN_AGGREGATE,
   RGCN_FN_AGGREGATE_AND_REDUCE, RGCN_FN_AGGREGATE_AMAX, RGCN_FN_AGGREGATE_DEFERRED, RGCN_FN_TRANSFORM_FWD_SPLIT,
   RGCN_FN_TRANSFORM_BWD_INPUT_SPLIT, RGCN_FN_TRANSFORM_FIRST_SPLIT, RGCN_FN_TRANSFORM_BWD_PARAMS_SPLIT_BEGIN,
-  RGCN_FN_SLAB_REDUCE, RGCN_FN_LAYER_FWD_FUSED, RGCN_FN_LAYER_BWD_INPUT_FUSED, RGCN_FN_COUNT
+  RGCN_FN_SLAB_REDUCE, RGCN_FN_LAYER_FWD_FUSED, RGCN_FN_LAYER_BWD_INPUT_FUSED, RGCN_FN_AGGREGATE_PREP, RGCN_FN_COUNT
 };
 typedef struct rgcn_seq_arg {
   int32_t kind;  /* RGCN_SEQ_* */

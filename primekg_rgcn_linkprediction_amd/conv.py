@@ -71,15 +71,21 @@ class _Scales:
     slot - and, in a forward pass, splits the layers' weights.  In fp32 mode nothing is allocated and every
     slot is None."""
 
-    def __init__(self, t: Tensor, slots: int = 2, layers=()):
+    def __init__(self, t: Tensor, slots: int = 2, layers=(), ride=None):
         """``layers``: ``[(weight, root | None), ...]`` of the pass (forward passes): their split images are made
-        by the SAME first launch - ``self.packed[i]`` (None for widths the split kernels do not tile)"""
+        by the SAME first launch - ``self.packed[i]`` (None for widths the split kernels do not tile).
+        ``ride`` (a bucketed graph): that launch rides in the first gather over ``t`` instead
+        (``ops.aggregate_with_prep``) where that applies - ``self.first_gather`` then holds ``(agg, hubs)``."""
         self._buf, self._next, self.first = None, 1, None
         self.packed = [None] * len(layers)
+        self.first_gather = None
         if ops.GEMM_PRECISION == "split":
             self._buf = ops._empty(slots, ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
             self.first = self._buf[0]
-            if layers:
+            rode = ops.aggregate_with_prep(ride, t, self.first, self._buf[1:slots], list(layers)) if (ride is not None and layers) else None
+            if rode is not None:
+                self.first_gather, self.packed = (rode[0], rode[1]), rode[2]
+            elif layers:
                 self.packed = ops.absmax_and_split(t, self.first, self._buf[1:slots], list(layers))
             else:
                 ops.absmax(t, self.first, self._buf[1:slots])
@@ -168,13 +174,24 @@ def _defer_hubs(half: bool, packed, amax, k: int, n_out: int) -> bool:
 _DEFER_HUBS = _os.environ.get("RGCN_DEFER_HUBS", "1") == "1"
 
 
-def _layer_train_forward(graph: "ops.BucketedGraph", x: Tensor, gather_dtype, weight, root, bias, relu: bool,
-                         half: bool, x_amax, amax_out, packed):
-    """-> (agg, out) of one layer's training forward"""
-    n, r, d_in, d_out = x.size(0), graph.num_relations, x.size(1), weight.size(2)
+def _train_fused(graph, n, r, d_in, d_out, half) -> bool:
+    """the one-kernel training layer by the size policy (see above)"""
     fused = _TRAIN_FUSED == "1" or (_TRAIN_FUSED == "auto" and n * r * d_in * 4 >= _TRAIN_FUSED_MIN_BYTES)
-    if (fused and not half and packed is not None and x_amax is not None and not graph.weighted_shard
-            and n == graph.num_other_nodes and ops.fused_supported(r, d_in, d_out)):
+    return bool(fused and not half and not graph.weighted_shard and n == graph.num_other_nodes
+                and ops.GEMM_PRECISION == "split" and ops.fused_supported(r, d_in, d_out))
+
+
+def _layer_train_forward(graph: "ops.BucketedGraph", x: Tensor, gather_dtype, weight, root, bias, relu: bool,
+                         half: bool, x_amax, amax_out, packed, gathered=None):
+    """-> (agg, out) of one layer's training forward; ``gathered``: ``(agg, hubs)`` when the pass's first launch
+    already carried this layer's gather (``_Scales(ride=)``)"""
+    n, r, d_in, d_out = x.size(0), graph.num_relations, x.size(1), weight.size(2)
+    if gathered is not None:
+        agg, hubs = gathered
+        out = ops.transform_fwd(agg, x, weight, root, bias, relu=relu, graph=graph, half=half, amax=(x_amax, x_amax),
+                                amax_out=amax_out, packed=packed, hubs=hubs)
+        return agg, out
+    if (_train_fused(graph, n, r, d_in, d_out, half) and packed is not None and x_amax is not None):
         agg = ops._empty(n, r * d_in, dtype=torch.float32, device=x.device)
         out = ops.layer_fwd_fused(graph, x, packed, bias, relu, x_amax, amax_out, inline_limit=_EVAL_INLINE_LIMIT,
                                   agg_out=agg)
@@ -244,10 +261,16 @@ def _packs(bufs, layers):
 def _enc2_layer1(x, w1, root1, b1, w2, root2, *, graph, gather_dtype, half):
     """first launch of the pass (max |x|, cleared amax slots, both layers' split weights) + conv1 with its ReLU
     -> (h, agg1, amax buffers [x | h], split images of conv1, of conv2)"""
-    scales = _Scales(x, layers=[(w1, root1), (w2, root2)])       # ONE launch
+    # the pass's first launch (max |x|, cleared slots, both layers' split weights) rides in conv1's gather where the
+    # layer takes the separate gather / transform kernels with the hub tails left to the transform
+    n, r, d_in, d_out = x.size(0), graph.num_relations, x.size(1), w1.size(2)
+    ride = graph if (not half and gather_dtype in (None, torch.float32) and not _train_fused(graph, n, r, d_in, d_out, half)
+                     and _DEFER_HUBS and d_in in (64, 128) and d_out <= 128) else None
+    scales = _Scales(x, layers=[(w1, root1), (w2, root2)], ride=ride)
     x_amax, h_amax = scales.first, scales.slot()
     pk1, pk2 = scales.packed                                      # once, for forward and backward
-    agg1, h = _layer_train_forward(graph, x, gather_dtype, w1, root1, b1, True, half, x_amax, h_amax, pk1)
+    agg1, h = _layer_train_forward(graph, x, gather_dtype, w1, root1, b1, True, half, x_amax, h_amax, pk1,
+                                   gathered=scales.first_gather)
     return h, agg1, scales._buf, (pk1.buf if pk1 is not None else None), (pk2.buf if pk2 is not None else None)
 
 

@@ -21,12 +21,14 @@
 // run-to-run deterministic.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include <hip/hip_fp16.h>
 
 #include "rgcn_common.h"
 #include "rgcn_slab_reduce.h"
 #include "rgcn_hub_finish.h"
+#include "rgcn_prep.h"
 
 namespace {
 
@@ -94,25 +96,21 @@ struct IdWindow {
   }
 };
 
+// workgroup `bx` of the gather proper (the kernels below put riders before / behind it in their grids)
 template <int G, bool WEIGHTED>
-__global__ __launch_bounds__(kThreads) void k_aggregate(
-    const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
+__device__ inline void aggregate_block(
+    const int bx, float4* red, const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
     float* __restrict__ agg, float* __restrict__ partial, int d, const int32_t* __restrict__ head_col,
-    const float* __restrict__ head_w, const rgcn_slab_job job, int gather_blocks, unsigned* __restrict__ amax_out) {
-  __shared__ float4 red[kThreads];               // pack combine (see rgcn_common.h)
-  if ((int)blockIdx.x >= gather_blocks) {        // workgroups past the gather: a pending slab reduction rides along
-    rgcn_slab_reduce_block<RGCN_SLAB_OUTS, RGCN_SLAB_GROUPS>(job, (int64_t)blockIdx.x - gather_blocks, red);
-    return;
-  }
-  const int64_t item_id = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
+    const float* __restrict__ head_w, unsigned* __restrict__ amax_out) {
+  const int64_t item_id = ((int64_t)bx * kThreads + threadIdx.x) / G;
   const int c4 = ((int)threadIdx.x % G + (int)blockIdx.y * G) * 4;
   if (item_id >= nitems) return;                 // whole lane groups only
   const unsigned seen = rgcn_amax_peek(amax_out);
   const bool live = c4 < d;                      // lanes past the row end still carry ids for their group
   const rgcn_item it = items[item_id];
   // packs come first in the item order: the workgroup's first slot says whether any is in here
-  const bool has_packs = (items[(int64_t)blockIdx.x * (kThreads / G)].flags & RGCN_ITEM_PACK) != 0;
+  const bool has_packs = (items[(int64_t)bx * (kThreads / G)].flags & RGCN_ITEM_PACK) != 0;
 
   float4 acc = f4zero();
   if constexpr (G >= RGCN_HEAD) {
@@ -192,6 +190,41 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
     *reinterpret_cast<float4*>(partial + (size_t)it.dst * d + c4) = acc;
   }
   if (amax_out) rgcn_amax_publish(amax_out, lmax, seen);
+}
+
+template <int G, bool WEIGHTED>
+__global__ __launch_bounds__(kThreads) void k_aggregate(
+    const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
+    const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
+    float* __restrict__ agg, float* __restrict__ partial, int d, const int32_t* __restrict__ head_col,
+    const float* __restrict__ head_w, const rgcn_slab_job job, int gather_blocks, unsigned* __restrict__ amax_out) {
+  __shared__ float4 red[kThreads];               // pack combine (see rgcn_common.h)
+  if ((int)blockIdx.x >= gather_blocks) {        // workgroups past the gather: a pending slab reduction rides along
+    rgcn_slab_reduce_block<RGCN_SLAB_OUTS, RGCN_SLAB_GROUPS>(job, (int64_t)blockIdx.x - gather_blocks, red);
+    return;
+  }
+  aggregate_block<G, WEIGHTED>((int)blockIdx.x, red, src, items, nitems, col, w, cnt, agg, partial, d, head_col, head_w, amax_out);
+}
+
+// The first gather of a forward pass with the pass's first launch riding at the FRONT of its grid (rgcn_prep.h: max |x|,
+// cleared amax buffers, the layers' split weights): the gather reads x but needs neither result, its successor - the
+// transform - needs both, so the rider's latency chain (12 us as a launch of its own) runs beside the gather's.
+template <int G>
+__global__ __launch_bounds__(kThreads) void k_aggregate_prep(
+    const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
+    const int32_t* __restrict__ col, const float* __restrict__ cnt, float* __restrict__ agg, float* __restrict__ partial,
+    int d, const int32_t* __restrict__ head_col, const rgcn_prep prep, int prep_blocks) {
+  __shared__ float4 red[kThreads];
+  const int b = (int)blockIdx.x;
+  if (b < prep_blocks) {                         // uniform over the workgroup
+    float* fred = reinterpret_cast<float*>(red);
+    const int npack = prep.pack_blocks * prep.layers;
+    if (b < npack) rgcn_pack_body<kThreads>(prep.JJ.j[b / prep.pack_blocks], fred, prep.pack_blocks, b % prep.pack_blocks);
+    else rgcn_absmax_body<kThreads>(prep.J, prep.zero, prep.zero_count, fred, b - npack, RGCN_AMAX_HEADS);
+    return;
+  }
+  aggregate_block<G, false>(b - prep_blocks, red, src, items, nitems, col, nullptr, cnt, agg, partial, d, head_col, nullptr,
+                            nullptr);
 }
 
 // The same gather for degree-skewed structures (rgcn_csr::hot_ids): on the PrimeKG-shaped graph a third of all row
@@ -603,6 +636,39 @@ int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t 
   if (!g) return RGCN_ERR_ARG;
   return aggregate_levels(g, transposed, 0, g->dir[transposed ? 1 : 0].num_levels, x, d, agg, workspace,
                           workspace_bytes, stream);
+}
+
+int rgcn_aggregate_prep(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg, void* workspace,
+                        size_t workspace_bytes, int deferred, float* x_amax, float* zero_buffers, int zero_count, int count,
+                        const float* const* weights, const float* const* roots, const int64_t* R, const int64_t* d_in,
+                        const int64_t* d_out, void* const* packed, const size_t* packed_bytes, void* stream_) {
+  if (!g || !agg || !x || !(d == 64 || d == 128 || d == 256)) return RGCN_ERR_ARG;
+  const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
+  if (!c->rowptr || c->weighted || c->num_items[0] <= 0) return RGCN_ERR_UNSUPPORTED;      // mean structures with work
+  if (deferred && !rgcn_aggregate_deferrable(g, transposed, d)) return RGCN_ERR_UNSUPPORTED;
+  if (c->num_partials > 0 && (!workspace || workspace_bytes < (size_t)c->num_partials * (size_t)d * sizeof(float)))
+    return RGCN_ERR_WORKSPACE;
+  rgcn_prep p;
+  const int rc = rgcn_prep_fill(x, c->n_other * d, x_amax, zero_buffers, zero_count, count, weights, roots, R, d_in, d_out,
+                                packed, packed_bytes, kThreads, &p);
+  if (rc != RGCN_OK) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int prep_blocks = p.pack_blocks * p.layers + RGCN_AMAX_HEADS;
+  const int64_t nitems = c->num_items[0];
+  float* partial = (float*)workspace;
+  auto launch = [&](auto gtag) {
+    constexpr int G = decltype(gtag)::value;
+    const unsigned gather_blocks = (unsigned)ceil_div64(nitems, kThreads / G);
+    k_aggregate_prep<G><<<gather_blocks + (unsigned)prep_blocks, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, c->val,
+                                                                                      agg, partial, (int)d, c->head_col, p,
+                                                                                      prep_blocks);
+  };
+  if (d == 64) launch(std::integral_constant<int, 16>{});
+  else if (d == 128) launch(std::integral_constant<int, 32>{});
+  else launch(std::integral_constant<int, 64>{});
+  RGCN_HIP_TRY(hipGetLastError());
+  if (deferred) return RGCN_OK;
+  return aggregate_levels(g, transposed, 1, c->num_levels, x, d, agg, workspace, workspace_bytes, stream_);
 }
 
 int rgcn_aggregate_hot_rows(const rgcn_graph* g, int transposed, int64_t d) {

@@ -1005,6 +1005,54 @@ def aggregate_deferred(graph: BucketedGraph, x: torch.Tensor, transposed: bool =
     return out, DeferredHubs(graph, transposed, ws)
 
 
+PREP_RIDES = os.environ.get("RGCN_PREP_RIDES", "1") == "1"       # 0: the pass's first launch stays a launch of its own (A/B)
+
+
+def aggregate_with_prep(graph: BucketedGraph, x: torch.Tensor, x_amax: torch.Tensor, clear: Optional[torch.Tensor],
+                        layers, deferred: bool = True):
+    """The first gather of a forward pass with the pass's first launch riding in its grid (``rgcn_aggregate_prep``):
+    ``absmax_and_split(x, x_amax, clear, layers)`` and ``aggregate[_deferred](graph, x)`` as ONE launch ->
+    ``(agg, hubs | None, [SplitWeights, ...])``, or None where the combination does not apply (the caller then issues
+    the two launches): measurement mode, a weighted / fp16 / wide structure, a layer the split kernels do not tile,
+    weights too large for the merged launch."""
+    d = x.size(1) if x.dim() == 2 else 0
+    if (not PREP_RIDES or GATHER_EVENTS is not None or GEMM_PRECISION != "split" or x.dtype != torch.float32
+            or d not in (64, 128, 256) or graph.weighted_shard or x.size(0) != graph.num_other_nodes or graph.num_edges == 0
+            or not layers or len(layers) > 4):
+        return None
+    for weight, root in layers:
+        if weight.dim() != 3 or weight.size(1) % 32 or weight.size(2) % 32:
+            return None
+        if weight.numel() + (root.numel() if root is not None else 0) > _MERGED_PACK_MAX:
+            return None
+    _need_gpu("x", x, torch.float32)
+    _check_amax("x_amax", x_amax, x.device)
+    defer = bool(deferred and graph.num_levels(False) == 2 and graph.deferrable(False, d))
+    count = 0
+    if clear is not None:
+        _need_gpu("clear", clear, torch.float32)
+        count = clear.numel() // AMAX_FLOATS
+    lib = _L()
+    n = len(layers)
+    with _on(x.device):
+        out = _empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
+        nbytes = graph.workspace_bytes(False, d)
+        ws = _workspace(nbytes, x.device)
+        sizes = [_query("rgcn_weights_split_bytes", *w.shape) for w, _ in layers]
+        bufs = [_empty(sz, dtype=torch.uint8, device=x.device) for sz in sizes]
+        arr, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)                                   # noqa: E731
+        rc = lib.rgcn_aggregate_prep(
+            graph.handle, 0, _ptr(x), d, _ptr(out), _ptr(ws), nbytes, int(defer), _ptr(x_amax), _ptr(clear), count, n,
+            cast(arr(*[_ptr(w) for w, _ in layers])), cast(arr(*[_ptr(r) for _, r in layers])),
+            cast(i64(*[w.size(0) for w, _ in layers])), cast(i64(*[w.size(1) for w, _ in layers])),
+            cast(i64(*[w.size(2) for w, _ in layers])), cast(arr(*[_ptr(b) for b in bufs])),
+            cast((ctypes.c_size_t * n)(*sizes)), _stream())
+    _lib.check(rc, "rgcn_aggregate_prep")
+    packs = [SplitWeights(b, w, r) for b, (w, r) in zip(bufs, layers)]
+    return out, (DeferredHubs(graph, False, ws) if defer else None), packs
+
+
 def _hub_args(hubs: Optional[DeferredHubs], n: int, r: int):
     if hubs is None:
         return None, 0, None
@@ -1516,7 +1564,7 @@ _SEQ_STREAM_POS = {"rgcn_absmax": 5, "rgcn_absmax_multi": 6, "rgcn_absmax_pack":
                    "rgcn_aggregate": 7, "rgcn_aggregate_and_reduce": 8, "rgcn_aggregate_amax": 9, "rgcn_aggregate_deferred": 8,
                    "rgcn_transform_fwd_split": 20, "rgcn_transform_bwd_input_split": 19, "rgcn_transform_first_split": 12,
                    "rgcn_transform_bwd_params_split_begin": 18, "rgcn_slab_reduce": 1, "rgcn_layer_fwd_fused": 17,
-                   "rgcn_layer_bwd_input_fused": 17}
+                   "rgcn_layer_bwd_input_fused": 17, "rgcn_aggregate_prep": 19}
 _SEQ_PURE = ("rgcn_aggregate_hot_rows", "rgcn_graph_tile_mask", "rgcn_graph_num_levels", "rgcn_graph_weight_bound", "rgcn_aggregate_deferrable",
              "rgcn_graph_num_edges", "rgcn_graph_num_nodes", "rgcn_graph_num_relations", "rgcn_abi_version", "rgcn_strerror")
 REGIONS = os.environ.get("RGCN_NATIVE_STEP", "1") == "1"      # 0: always through the wrappers (A/B runs, debugging)

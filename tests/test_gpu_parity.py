@@ -1529,6 +1529,52 @@ def test_fused_input_gradient_is_bit_identical_to_gather_then_transform(n, e, r,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(64, 128, 128), (128, 128, 64)])
+def test_first_launch_riding_in_the_first_gather_changes_no_bit(dims, monkeypatch):
+    """``rgcn_aggregate_prep``: max |x|, the cleared amax slots and both layers' split weight images as extra workgroups
+    (256 threads each) at the front of conv1's gather instead of a launch of their own (1,024 threads each): the same
+    amax value, the same images, the same aggregate, and the same encoder output and gradients bit for bit"""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=160000, seed=17)
+    eid, etd = ei.to(dev), et.to(dev)
+    graph = ops.bucket(eid, etd, n, r)
+    torch.manual_seed(17)
+    x = torch.randn(n, dims[0], device=dev)
+    convs = [RGCNConv(dims[0], dims[1], r).to(dev), RGCNConv(dims[1], dims[2], r).to(dev)]
+    layers = [(c.weight.detach(), c.root.detach()) for c in convs]
+    bufs = torch.zeros(2, ops.AMAX_FLOATS, device=dev)
+    want_packs = ops.absmax_and_split(x, bufs[0], bufs[1:2], layers)
+    want_agg, want_hubs = ops.aggregate_deferred(graph, x)
+    bufs2 = torch.full((2, ops.AMAX_FLOATS), 3.0, device=dev)
+    got = ops.aggregate_with_prep(graph, x, bufs2[0], bufs2[1:2], layers)
+    assert got is not None
+    agg, hubs, packs = got
+    assert float(ops.amax_value(bufs2[0])) == float(ops.amax_value(bufs[0])) == float(x.abs().max())
+    assert float(bufs2[1].view(-1)[::ops.AMAX_HEAD_STRIDE].abs().max()) == 0.0            # the slot the pass publishes into: cleared
+    assert (hubs is None) == (want_hubs is None)
+    rowptr = graph.arrays(False)[0].long()
+    short = (rowptr[1:] - rowptr[:-1]) <= 256                                              # rows the gather itself finished
+    assert torch.equal(agg.view(n * r, -1)[short], want_agg.view(n * r, -1)[short])
+    for a, b in zip(packs, want_packs):
+        one = ((a.shape[0] + 1) * a.shape[1] * a.shape[2] * 2 + 255) // 256 * 256
+        img = 10 * one                                                                     # the ten fp16 images (+ the scale)
+        assert torch.equal(a.buf[: img + 4], b.buf[: img + 4])
+    cot = torch.randn(n, dims[2], device=dev)
+    monkeypatch.setattr(ops, "REGIONS", False)
+    results = []
+    for rides in (False, True):
+        monkeypatch.setattr(ops, "PREP_RIDES", rides)
+        e = x.clone().requires_grad_(True)
+        for c in convs:
+            c.zero_grad(set_to_none=True)
+        out = rgcn_encoder2(e, eid, etd, convs[0], convs[1])
+        out.backward(cot)
+        results.append([out.detach(), e.grad] + [q.grad.clone() for c in convs for q in c.parameters()])
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("d", [64, 128, 256])
 def test_hot_rows_in_lds_change_no_bit(d):
     """the gather of a degree-skewed structure keeps the most read rows of its table in LDS (persistent workgroups,

@@ -1,5 +1,14 @@
-"""Where the host time of one eager encoder step goes (cProfile over 200 steps of the C2 workload).
-python tools/host_profile.py [n_lines]"""
+"""Host time of one eager encoder step (forward + backward of ``rgcn_encoder2``), with and without the native step
+(``ops.Region`` -> ``rgcn_sequence_run``).  Two measurements each:
+
+  * C2 (30,926 / 849,456 / 3, 64 -> 128 -> 128): wall time per step of a long eager loop - the larger of what the host
+    needs to issue a step and what the GPU needs to run it (0.28 ms of kernels);
+  * the same encoder over a 1k-node / 10k-edge graph, whose kernels take a few microseconds each: the loop is then
+    bound by the host alone, so its time per step IS the host cost of a step (launch list and argument handling do
+    not depend on the graph's size).
+
+    python tools/host_profile.py [n_lines_of_cProfile]
+"""
 import cProfile
 import os
 import pstats
@@ -12,34 +21,47 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from primekg_rgcn_linkprediction_amd import RGCNConv, ops, rgcn_encoder2, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
-ei, et, n, r = synth.primekg_like(seed=42)
-eid, etd = ei.to(dev), et.to(dev)
-torch.manual_seed(0)
-emb = torch.nn.init.xavier_uniform_(torch.empty(n, 64)).to(dev).requires_grad_(True)
-convs = [RGCNConv(64, 128, r).to(dev), RGCNConv(128, 128, r).to(dev)]
-cot = torch.randn(n, 128, device=dev)
 
 
-def step():
-    out = rgcn_encoder2(emb, eid, etd, convs[0], convs[1])
-    out.backward(cot)
+def make(ei, et, n, r):
+    eid, etd = ei.to(dev), et.to(dev)
+    torch.manual_seed(0)
+    emb = torch.nn.init.xavier_uniform_(torch.empty(n, 64)).to(dev).requires_grad_(True)
+    convs = [RGCNConv(64, 128, r).to(dev), RGCNConv(128, 128, r).to(dev)]
+    cot = torch.randn(n, 128, device=dev)
+
+    def step():
+        out = rgcn_encoder2(emb, eid, etd, convs[0], convs[1])
+        out.backward(cot)
+    return step
 
 
-for _ in range(20):
-    step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(200):
-    step()
-host = (time.perf_counter() - t0) / 200
-torch.cuda.synchronize()
-total = (time.perf_counter() - t0) / 200
-print(f"host time per eager step {host * 1e6:.0f} us (issue only), {total * 1e6:.0f} us with the final sync")
+def per_step(step, steps):
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    issue = (time.perf_counter() - t0) / steps
+    torch.cuda.synchronize()
+    return issue, (time.perf_counter() - t0) / steps
+
+
+big = make(*synth.primekg_like(seed=42))
+small = make(*synth.uniform_graph(1000, 10000, 3, seed=1))
+for native in (True, False):
+    ops.REGIONS = native
+    label = "native step (one C call per pass)" if native else "wrappers (one ctypes call per launch)"
+    issue, total = per_step(big, 200)
+    print(f"{label}: C2 {issue * 1e6:.0f} us per step issued, {total * 1e6:.0f} us with the final sync")
+    issue, total = per_step(small, 2000)
+    print(f"{label}: 1k-node graph (host-bound) {total * 1e6:.0f} us per step = host cost of an eager encoder step")
+ops.REGIONS = True
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(200):
-    step()
+for _ in range(2000):
+    small()
 pr.disable()
 torch.cuda.synchronize()
-st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 30)
+pstats.Stats(pr).sort_stats("tottime").print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 25)
