@@ -36,22 +36,22 @@ __device__ inline void rgcn_pack_body(const rgcn_pack_job& J, float* red, int nb
     if (Rt) m = fmaxf(m, rgcn_amax_value(J.r_amax, lane));
   } else {
     const int64_t wn4 = (int64_t)R * d_in * d_out / 4, rn4 = Rt ? (int64_t)d_in * d_out / 4 : 0;   // d_out % 4 == 0
-    auto scan = [&](const float* __restrict__ p, int64_t n4) {     // 8 independent loads per thread and round
-      const float4* p4 = reinterpret_cast<const float4*>(p);
-      for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 8 * THREADS) {
-        float4 v[8];
+    // W and root as ONE index range, 16 independent loads per thread and round: [W ; root] of a 128 x 128 layer is a
+    // single round (the scan is the head of this workgroup's latency chain: every round is a memory round trip)
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(W);
+    const float4* __restrict__ r4 = reinterpret_cast<const float4*>(Rt);
+    const int64_t n4 = wn4 + rn4;
+    for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 16 * THREADS) {
+      float4 v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int64_t i = i0 + (int64_t)u * THREADS;
-          v[u] = i < n4 ? p4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+      for (int u = 0; u < 16; ++u) {
+        const int64_t i = i0 + (int64_t)u * THREADS;
+        v[u] = i < wn4 ? w4[i] : (i < n4 ? r4[i - wn4] : make_float4(0.f, 0.f, 0.f, 0.f));
       }
-    };
-    scan(W, wn4);
-    if (Rt) scan(Rt, rn4);
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if (lane == 0) red[threadIdx.x >> 6] = m;

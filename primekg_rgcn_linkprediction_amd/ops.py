@@ -1005,7 +1005,10 @@ def aggregate_deferred(graph: BucketedGraph, x: torch.Tensor, transposed: bool =
     return out, DeferredHubs(graph, transposed, ws)
 
 
-PREP_RIDES = os.environ.get("RGCN_PREP_RIDES", "1") == "1"       # 0: the pass's first launch stays a launch of its own (A/B)
+# 1: the pass's first launch rides in conv1's gather (rgcn_aggregate_prep).  OFF by default: measured on the MI355X the
+# step gets 5 us SLOWER (0.286 against 0.281 ms, profiles/r03_prep_rides.txt) - in 256-thread workgroups the riders' scan
+# of the weights takes 8 rounds of loads instead of 2 and outlasts the gather it was meant to hide behind.
+PREP_RIDES = os.environ.get("RGCN_PREP_RIDES", "0") == "1"
 
 
 def aggregate_with_prep(graph: BucketedGraph, x: torch.Tensor, x_amax: torch.Tensor, clear: Optional[torch.Tensor],
@@ -1576,23 +1579,35 @@ def guard_torch_op(what: str) -> None:
         raise _NotRecordable(what)
 
 
-class Lazy:
-    """a tensor of a replayed pass that nobody has looked at yet: arena + offset (``.tensor()`` makes the view)"""
-    __slots__ = ("arena", "offset", "shape", "dtype", "_t")
+def _strides(shape):
+    st, acc = [], 1
+    for n in reversed(shape):
+        st.append(acc)
+        acc *= n
+    return tuple(reversed(st))
 
-    def __init__(self, arena, offset, shape, dtype):
-        self.arena, self.offset, self.shape, self.dtype, self._t = arena, offset, shape, dtype, None
+
+class Lazy:
+    """a tensor of a replayed pass that nobody has looked at yet: arena + offset (``.tensor()`` makes the view - one
+    ``as_strided`` on the arena's float32 alias, which the pass's outputs share)"""
+    __slots__ = ("arena", "offset", "shape", "dtype", "_t", "alias")
+
+    def __init__(self, arena, offset, shape, dtype, alias=None):
+        self.arena, self.offset, self.shape, self.dtype, self._t, self.alias = arena, offset, shape, dtype, None, alias
 
     def data_ptr(self) -> int:
         return self.arena.data_ptr() + self.offset
 
     def tensor(self) -> torch.Tensor:
         if self._t is None:
-            n = 1
-            for s in self.shape:
-                n *= s
-            nbytes = n * torch.empty((), dtype=self.dtype).element_size() if n else 0
-            self._t = self.arena[self.offset: self.offset + nbytes].view(self.dtype).view(self.shape)
+            if self.dtype == torch.float32 and self.alias is not None and self.offset % 4 == 0:
+                self._t = torch.as_strided(self.alias, self.shape, _strides(self.shape), self.offset // 4)
+            else:
+                n = 1
+                for s in self.shape:
+                    n *= s
+                nbytes = n * torch.empty((), dtype=self.dtype).element_size() if n else 0
+                self._t = self.arena[self.offset: self.offset + nbytes].view(self.dtype).view(self.shape)
         return self._t
 
 
@@ -1634,8 +1649,8 @@ class _Recorder:
                 total += (nb + self.ALIGN - 1) // self.ALIGN * self.ALIGN
             # zero filled, like the arena of the check replay: bytes no launch writes (the unused entries of an amax
             # buffer, alignment gaps of the split weight images) then compare equal
-            self.arena = torch.zeros(max(total, self.ALIGN), dtype=torch.uint8, device=device)
-            self.arena_bytes = max(total, self.ALIGN)
+            self.arena = torch.zeros((max(total, self.ALIGN) + 3) // 4 * 4, dtype=torch.uint8, device=device)
+            self.arena_bytes = (max(total, self.ALIGN) + 3) // 4 * 4
             self.base = self.arena.data_ptr()
             self.inputs = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) if t is not None else None
                            for t in inputs]
@@ -1756,13 +1771,14 @@ class _Plan:
             rc = lib.rgcn_sequence_run(self.calls, self.num_calls, self.args, self.num_args, bases, nb, _stream())
         _lib.check(rc, "rgcn_sequence_run")
         outs = []
+        alias = arena.view(torch.float32) if want else None          # one alias for all the float32 views of this pass
         for i, spec in enumerate(self.outputs):
             if spec is None:
                 outs.append(None)
             elif spec[0] == "input":
                 outs.append(inputs[spec[1]])
             else:
-                lz = Lazy(arena, spec[1], spec[2], spec[3])
+                lz = Lazy(arena, spec[1], spec[2], spec[3], alias)
                 outs.append(lz.tensor() if i in want else lz)
         return outs
 

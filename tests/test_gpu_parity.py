@@ -1680,6 +1680,7 @@ def test_native_step_replays_the_recorded_pass_bit_for_bit(p, frozen_input, monk
     inputs every step (a replay must follow the step's own tensors, not the recorded addresses), with dropout (two
     forward passes around torch's dropout kernel), with an input that needs no gradient, and inside a captured HIP graph."""
     dev = need_gpu()
+    monkeypatch.setattr(ops, "PREP_RIDES", p == 0.5)          # one case also records rgcn_aggregate_prep (off by default)
     ei, et, n, r = synth.primekg_like(num_edges=120000, seed=13)
     eid, etd = ei.to(dev), et.to(dev)
     torch.manual_seed(13)

@@ -2,10 +2,13 @@
 # One measurement pass on the GPU box: headline bench line (with its fp32 / C4 secondary legs), rocprofv3 kernel stats of
 # the same command without the secondary legs (split and fp32 arithmetic, C3, C4 on one GPU, E = 1.68 M), PMC passes
 # (separate runs, --kernel-trace only beside --pmc), the N > 1 legs rehearsed with two gloo ranks on the one GPU.
-# usage: bash tools/measure.sh <tag>      -> gpurun_out/<tag>_*
+# usage: bash tools/measure.sh <tag> [1|2]     -> gpurun_out/<tag>_*   (part 1: bench lines + kernel stats; part 2: PMC
+#        passes, gloo rehearsals, host profile, stamps - each part fits one gpurun call of <= 20 minutes)
 tag=${1:-r03}
+part=${2:-1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out
+if [ "$part" = 1 ]; then
 python3 bench.py > $out/${tag}_c2_bench.json 2> $out/${tag}_c2_bench.err
 stats() {  # name, extra bench args ...: the line itself first (no profiler attached), then the same command under rocprofv3
   local name=$1; shift
@@ -21,6 +24,8 @@ stats c3 --workload c3
 stats c4_1gpu --workload c4 --steps 10 --warmup 3
 RGCN_TRAIN_FUSED=0 stats c4_1gpu_unfused --workload c4 --steps 10 --warmup 3
 stats c2_e1677772 --edges 1677772
+fi
+if [ "$part" = 2 ]; then
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TA_TA_BUSY_sum" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"; do
   d=$out/pmc_${tag}/$(echo $set | tr ' ' '_' | cut -c1-40)
@@ -34,8 +39,16 @@ python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29542 \
     bench.py --gpus 2 --steps 5 --warmup 2 --workload c4 2> $out/${tag}_gloo2_c4.err | grep '^{' > $out/${tag}_gloo2_c4_bench.json
 unset RGCN_BENCH_BACKEND
+python3 tools/host_profile.py 12 > $out/${tag}_host_profile.txt 2>&1
+tools/gemm_stamps > $out/${tag}_stamps.txt 2>&1
+python3 tools/epoch_time.py > $out/${tag}_epoch.txt 2>&1
+python3 tools/epoch_time.py --no_hip_graph >> $out/${tag}_epoch.txt 2>&1
+python3 tools/eval_time.py > $out/${tag}_eval.txt 2>&1
+fi
 python3 - <<PY
 import json
+import os, sys
+if not os.path.exists("$out/${tag}_c2_bench.json"): sys.exit(0)
 r = json.load(open("$out/${tag}_c2_bench.json"))
 print("C2", r["ms_per_step"], r["value"], r["config"]["launch"])
 print("roofline", {k: r["roofline"][k] for k in ("kernel", "bound", "avg_us", "achieved", "frac", "frac_compulsory")})
