@@ -341,6 +341,11 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
       }
       // split the lane's 8 k of A: v = a * 2^ea; hi = fp16(v); lo = fp16(v - hi)
       half8 ah, al;
+#ifdef RGCN_PROBE_NOSPLIT                         // tools/gemm_stamps: what the loop costs WITHOUT the split (results are garbage)
+      ah = __builtin_bit_cast(half8, fa[s][0]);
+      al = __builtin_bit_cast(half8, fa[s][1]);
+      (void)sa;
+#else
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -350,6 +355,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
           ah[4 * q + c] = h;
           if (LO) al[4 * q + c] = (_Float16)(v - (float)h);
         }
+#endif
 #pragma unroll
       for (int b = 0; b < TN; ++b) {             // small terms first
         const half8 bh = __builtin_bit_cast(half8, fh[s][b]);
@@ -1059,7 +1065,12 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
     if (half) RGCN_NT_LAUNCH(WM_, TN_, EPI_, false); \
     else RGCN_NT_LAUNCH(WM_, TN_, EPI_, true);       \
   } while (0)
-  if (N <= 64) {
+  // RGCN_NT_COLS=64: 64-column tiles for every width (A/B runs): three workgroups of 48 KB per CU instead of two of 72 KB
+  static const bool narrow = [] {
+    const char* e = getenv("RGCN_NT_COLS");
+    return e && atoi(e) == 64;
+  }();
+  if (N <= 64 || (narrow && !fin.ptr)) {
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
     if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 1, EPI_RELU);
     else if (epi == EPI_MASK) RGCN_NT_SPLIT(2, 1, EPI_MASK);
