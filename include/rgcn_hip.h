@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 19
+#define RGCN_ABI_VERSION 20
 
 enum {
   RGCN_OK = 0,
@@ -503,6 +503,16 @@ int rgcn_adam_clip_step(int num_tensors, float* const* params, const float* cons
 int distmult_rank_tails(const float* hr, const float* emb, const float* true_score,
                         const int64_t* tail, int64_t batch, int64_t num_entities, int64_t d,
                         int32_t* beaten_by, void* stream);
+
+/* The [B, num_entities] score matrix itself (LinkPredictor.score_all_tails rgcn.py:215-243: (h * r) @ E^T; the callers
+ * that want every candidate's score - predict_all_tails, the top-k consumers - rather than a rank):
+ * hr[b, :] = head[b, :] * rel[rel_idx[b], :] (rel_idx == NULL: rel holds one row per b), then
+ * scores[b, n] = <hr[b], emb[n]> on the fp32 MFMA - the ranking launch's GEMM with a store epilogue, so a score here
+ * and the score distmult_rank_tails compares are the same bits.  hr: caller's [B, d] buffer (the products, an output).
+ * d must be a multiple of 32; a relation id outside [0, num_relations) yields a NaN row. */
+int distmult_score_all_tails(const float* head, const float* rel, const int64_t* rel_idx, int64_t num_relations,
+                             const float* emb, int64_t batch, int64_t num_entities, int64_t d, float* hr, float* scores,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------
  * A recorded pass issued by ONE call.  The reference re-runs its encoder from Python for every 1,024-edge batch

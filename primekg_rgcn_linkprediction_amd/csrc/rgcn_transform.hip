@@ -903,6 +903,30 @@ bool bad_dims(int64_t n, int64_t r, int64_t di, int64_t dout) {
   return n < 0 || r <= 0 || di <= 0 || dout <= 0 || (di & 3) || (dout & 3);
 }
 
+// hr[b, :] = head[b, :] * rel[rel_idx ? rel_idx[b] : b, :] (LinkPredictor.score_all_tails rgcn.py:215-243: the A operand of
+// the [B, N] score GEMM); an out-of-range relation id gives a row of NaN, as loud as an index error can be from here
+__global__ __launch_bounds__(256) void k_head_times_relation(const float* __restrict__ head, const float* __restrict__ rel,
+                                                             const int64_t* __restrict__ rel_idx, int num_relations, int dq,
+                                                             int quads, float* __restrict__ hr) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  const int b = q / dq, c = q - b * dq;
+  const float4 h = reinterpret_cast<const float4*>(head)[q];
+  float4 r;
+  if (rel_idx) {
+    const int64_t id = rel_idx[b];
+    if (id < 0 || id >= num_relations) {
+      const float nan = __builtin_nanf("");
+      r = make_float4(nan, nan, nan, nan);
+    } else {
+      r = reinterpret_cast<const float4*>(rel)[(size_t)id * dq + c];
+    }
+  } else {
+    r = reinterpret_cast<const float4*>(rel)[q];
+  }
+  reinterpret_cast<float4*>(hr)[q] = make_float4(h.x * r.x, h.y * r.y, h.z * r.z, h.w * r.w);
+}
+
 }  // namespace
 
 extern "C" {
@@ -957,6 +981,27 @@ int distmult_rank_tails(const float* hr, const float* emb, const float* true_sco
   k_gemm_nt_dma<2, B_BLK, EPI_RANK><<<grid, kThreads, 0, stream>>>(hr, (int)d, hr, 0, emb, emb, (int)d, true_score,
                                                                     nullptr, reinterpret_cast<float*>(beaten_by),
                                                                     (int)batch, (int)num_entities, tail, nullptr, 0);
+  RGCN_HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
+int distmult_score_all_tails(const float* head, const float* rel, const int64_t* rel_idx, int64_t num_relations,
+                             const float* emb, int64_t batch, int64_t num_entities, int64_t d, float* hr, float* scores,
+                             void* stream_) {
+  if (batch < 0 || num_entities <= 0 || d <= 0 || (d % BK)) return (d > 0 && (d % BK)) ? RGCN_ERR_UNSUPPORTED : RGCN_ERR_ARG;
+  if (batch == 0) return RGCN_OK;
+  if (!head || !rel || !emb || !hr || !scores || (rel_idx && num_relations <= 0)) return RGCN_ERR_ARG;
+  if (batch > INT32_MAX / 2 || num_entities > INT32_MAX / 2 || batch * d > INT32_MAX) return RGCN_ERR_UNSUPPORTED;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t quads = batch * d / 4;
+  k_head_times_relation<<<(unsigned)ceil_div64(quads, 256), 256, 0, stream>>>(head, rel, rel_idx, (int)num_relations,
+                                                                              (int)(d / 4), (int)quads, hr);
+  RGCN_HIP_TRY(hipGetLastError());
+  // scores[b, n] = sum_k hr[b, k] * emb[n, k]: the ranking launch's operands, the plain store epilogue
+  dim3 grid((unsigned)ceil_div64(batch, 64), (unsigned)ceil_div64(num_entities, 128));
+  k_gemm_nt_dma<2, B_BLK, EPI_NONE><<<grid, kThreads, 0, stream>>>(hr, (int)d, hr, 0, emb, emb, (int)d, nullptr, nullptr,
+                                                                    scores, (int)batch, (int)num_entities, nullptr,
+                                                                    nullptr, 0);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

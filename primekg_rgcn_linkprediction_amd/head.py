@@ -120,6 +120,34 @@ class _DistMultBCEFunction(torch.autograd.Function):
         return gh, None, gt, None, gr, None, None
 
 
+class _ScoreAllTailsFunction(torch.autograd.Function):
+    """``(head * rel[rel_idx]) @ emb.T``; the gradients are three small dense products (the reference never asks for
+    them - ``score_all_tails`` runs under ``no_grad`` in ``evaluate.py`` - so they stay on the library GEMM)."""
+
+    @staticmethod
+    def forward(ctx, head: Tensor, rel: Tensor, rel_idx: Tensor, emb: Tensor) -> Tensor:
+        head, rel, emb = head.contiguous(), rel.contiguous(), emb.contiguous()
+        rel_idx = rel_idx.contiguous()
+        scores, hr = ops.distmult_score_all_tails(head, rel, rel_idx, emb)
+        ctx.save_for_backward(head, rel, rel_idx, emb, hr)
+        return scores
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        head, rel, rel_idx, emb, hr = ctx.saved_tensors
+        g = g.contiguous()
+        grad_head = grad_rel = grad_emb = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            grad_hr = g @ emb
+            if ctx.needs_input_grad[0]:
+                grad_head = grad_hr * rel[rel_idx]
+            if ctx.needs_input_grad[1]:
+                grad_rel = torch.zeros_like(rel).index_add_(0, rel_idx, grad_hr * head)
+        if ctx.needs_input_grad[3]:
+            grad_emb = g.t() @ hr
+        return grad_head, grad_rel, None, grad_emb
+
+
 def distmult(h, h_idx, t, t_idx, r, r_idx) -> Tensor:
     return _DistMultFunction.apply(h, h_idx, t, t_idx, r, r_idx)
 
@@ -180,7 +208,11 @@ class LinkPredictor(nn.Module):
 
     def score_all_tails(self, head_embeddings: Tensor, relation_types: Tensor,
                         all_tail_embeddings: Tensor) -> Tensor:
-        """``(h * r) @ E^T`` -> [B, num_entities] (rgcn.py:215-243).  A plain library GEMM
-        (SURVEY section 8f "next" row 2), kept on torch/rocBLAS for now."""
-        hr = head_embeddings * self.relation_embeddings(relation_types)
-        return hr @ all_tail_embeddings.t()
+        """``(h * r) @ E^T`` -> [B, num_entities] (rgcn.py:215-243): the ranking kernel's GEMM with a store
+        epilogue (``distmult_score_all_tails``), so ``score_all_tails(...)[b, n]`` and the score ``rank_tails``
+        compares are the same bits.  Differentiable like the reference's expression.  An embedding width that is not a
+        multiple of the kernel's 32-wide k step (the reference's is 128) takes the library GEMM on the GPU."""
+        if head_embeddings.size(1) % 32 and head_embeddings.is_cuda:
+            return (head_embeddings * self.relation_embeddings(relation_types)) @ all_tail_embeddings.t()
+        return _ScoreAllTailsFunction.apply(head_embeddings, self.relation_embeddings.weight, relation_types,
+                                            all_tail_embeddings)

@@ -1546,6 +1546,35 @@ def distmult_rank_tails(hr: torch.Tensor, emb: torch.Tensor, true_score: torch.T
     return beaten.to(torch.int64) + 1
 
 
+def distmult_score_all_tails(head: torch.Tensor, rel: torch.Tensor, rel_idx: Optional[torch.Tensor],
+                             emb: torch.Tensor):
+    """``((head * rel[rel_idx]) @ emb.T, head * rel[rel_idx])`` - the [B, N] score matrix of
+    ``LinkPredictor.score_all_tails`` (``rgcn.py:215-243``) from the ranking kernel's GEMM with a store epilogue, and
+    the products it multiplied (the backward's operand).  ``rel_idx is None``: ``rel`` holds one row per b."""
+    _need_gpu("head", head, torch.float32)
+    _need_gpu("rel", rel, torch.float32)
+    _need_gpu("emb", emb, torch.float32)
+    b, d = head.shape
+    if emb.dim() != 2 or emb.size(1) != d or rel.dim() != 2 or rel.size(1) != d:
+        raise ValueError("head [B, d], rel [R, d], emb [N, d] expected")
+    if rel_idx is not None:
+        _need_gpu("rel_idx", rel_idx, torch.int64)
+        if rel_idx.shape != (b,):
+            raise ValueError("rel_idx [B] expected")
+    elif rel.size(0) != b:
+        raise ValueError("rel must hold one row per head row when no relation ids are given")
+    if d % 32:
+        raise ValueError("embedding dim must be a multiple of 32 for the score kernel")
+    lib = _L()
+    with _on(head.device):
+        hr = _empty((b, d), dtype=torch.float32, device=head.device)
+        scores = _empty((b, emb.size(0)), dtype=torch.float32, device=head.device)
+        rc = lib.distmult_score_all_tails(_ptr(head), _ptr(rel), _ptr(rel_idx), rel.size(0), _ptr(emb), b, emb.size(0),
+                                          d, _ptr(hr), _ptr(scores), _stream())
+    _lib.check(rc, "distmult_score_all_tails")
+    return scores, hr
+
+
 # ----------------------------------------------------------------------------------
 # Region: a pass (a fixed list of this library's launches) recorded once, then issued by ONE native call
 # ----------------------------------------------------------------------------------

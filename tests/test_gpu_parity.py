@@ -533,6 +533,48 @@ def test_fused_bce_head_matches_reference_run_and_torch():
             assert_grad(a, b.cpu(), 1e-5)
 
 
+@pytest.mark.parametrize("batch,entities,d", [(1, 1, 32), (7, 129, 64), (200, 30926, 128), (1030, 500, 128)])
+def test_score_all_tails_kernel_vs_float64(batch, entities, d):
+    """``LinkPredictor.score_all_tails`` (rgcn.py:215-243) as a kernel: every score against the float64 product, the
+    gradients of all three operands against float64, ragged tiles in both directions, and the bits of the score the
+    ranking kernel compares (rank = 1 + #{scores > true score} recomputed from the matrix)."""
+    dev = need_gpu()
+    g = torch.Generator().manual_seed(batch + entities)
+    dec = LinkPredictor(5, d, dropout=0.0).to(dev)
+    head = torch.randn(batch, d, generator=g).to(dev).requires_grad_(True)
+    emb = torch.randn(entities, d, generator=g).to(dev).requires_grad_(True)
+    rel = torch.randint(0, 5, (batch,), generator=g).to(dev)
+    scores = dec.score_all_tails(head, rel, emb)
+    table = dec.relation_embeddings.weight
+    h64, e64, t64 = (x.detach().double().requires_grad_(True) for x in (head, emb, table))
+    want = (h64 * t64[rel]) @ e64.t()
+    bound = 4e-6 * float((h64.detach().abs() * t64.detach()[rel].abs()) .sum(1).max() * e64.detach().abs().max())
+    assert float((scores.detach().double() - want.detach()).abs().max()) <= bound
+    cot = torch.randn(batch, entities, generator=g).to(dev)
+    (scores * cot).sum().backward()
+    (want * cot.double()).sum().backward()
+    for got, ref in ((head.grad, h64.grad), (emb.grad, e64.grad), (table.grad, t64.grad)):
+        assert float((got.double() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    tails = torch.randint(0, entities, (batch,), generator=g).to(dev)
+    with torch.no_grad():
+        ranks = dec.rank_tails(head, rel, emb, tails)
+        hr = head * table[rel]
+        true = (hr * emb[tails]).sum(1, keepdim=True)
+        beaten = scores > true
+        beaten[torch.arange(batch, device=dev), tails] = False
+        assert torch.equal(ranks, beaten.sum(1) + 1)
+
+
+def test_score_all_tails_rejects_bad_relation_ids_loudly():
+    dev = need_gpu()
+    dec = LinkPredictor(3, 64, dropout=0.0).to(dev)
+    head, emb = torch.randn(4, 64, device=dev), torch.randn(10, 64, device=dev)
+    scores, _ = ops.distmult_score_all_tails(head, dec.relation_embeddings.weight.detach(),
+                                             torch.tensor([0, 1, 7, 2], device=dev), emb)
+    assert bool(torch.isnan(scores[2]).all()) and not bool(torch.isnan(scores[[0, 1, 3]]).any())
+
+
+
 def test_link_predictor_matches_reference_run():
     dev = need_gpu()
     z = load_golden("ref_link_predictor.npz")
@@ -1546,6 +1588,8 @@ def test_first_launch_riding_in_the_first_gather_changes_no_bit(dims, monkeypatc
     want_packs = ops.absmax_and_split(x, bufs[0], bufs[1:2], layers)
     want_agg, want_hubs = ops.aggregate_deferred(graph, x)
     bufs2 = torch.full((2, ops.AMAX_FLOATS), 3.0, device=dev)
+    assert ops.aggregate_with_prep(graph, x, bufs2[0], bufs2[1:2], layers) is None or ops.PREP_RIDES   # off by default
+    monkeypatch.setattr(ops, "PREP_RIDES", True)
     got = ops.aggregate_with_prep(graph, x, bufs2[0], bufs2[1:2], layers)
     assert got is not None
     agg, hubs, packs = got

@@ -172,8 +172,8 @@ def test_link_predictor_surface():
     a = (6.0 / (3 + 128)) ** 0.5
     assert d.relation_embeddings.weight.abs().max() <= a
     h = torch.randn(4, 128)
-    sc = d.score_all_tails(h, torch.tensor([0, 1, 2, 0]), torch.randn(10, 128))   # plain torch GEMM
-    assert sc.shape == (4, 10)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):          # the [B, N] score matrix is a kernel too
+        d.score_all_tails(h, torch.tensor([0, 1, 2, 0]), torch.randn(10, 128))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         d(h, h, torch.tensor([0, 1, 2, 0]))
 

@@ -79,7 +79,8 @@ int main() {
     };
     char name[128];
     snprintf(name, sizeof name, "NT forward  [%lld x %lld] x [%lld x %lld]", (long long)N, (long long)(K1 + d_in), (long long)(K1 + d_in), (long long)d_out);
-    timed([&] { rgcn_transform_fwd_split(agg, x, w, root, packed, bias, 1, nullptr, N, R, d_in, d_out, aa, 1.f, ax, 0, out, nullptr, ws1,
+    const int half = getenv("RGCN_STAMP_HALF") ? 1 : 0;           // one-pass fp16 arithmetic (configs[4]'s GEMMs)
+    timed([&] { rgcn_transform_fwd_split(agg, x, w, root, packed, bias, 1, nullptr, N, R, d_in, d_out, aa, 1.f, ax, half, out, nullptr, ws1,
                                          nt_ws, stream, nullptr, 0, nullptr); }, name, (int)((N + 63) / 64));
     rgcn_slab_job job;
     snprintf(name, sizeof name, "TN params   [%lld x %lld]^T x [%lld x %lld]", (long long)N, (long long)(K1 + d_in), (long long)N, (long long)d_out);
