@@ -25,7 +25,6 @@
 // operand is split once per call by k_pack_split into two k-contiguous fp16 images Bh / Bl [n][K].
 #include <algorithm>
 #include <cstdlib>
-#include <type_traits>
 
 #include <hip/hip_fp16.h>
 
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
                                                             const float* __restrict__ mask, float* __restrict__ C,
                                                             int M, int N, const uint32_t* __restrict__ tile_mask,
                                                             int kseg, unsigned* __restrict__ amax_out,
-                                                            const hub_fin fin, float out_scale, int pipe) {
+                                                            const hub_fin fin, float out_scale) {
 #ifdef RGCN_PROBE_DEPTH3                          // tools/gemm_stamps: one-pass (16 KB) slots in a ring of four - 2 workgroups per CU as before, 3 tiles in flight
   constexpr int BM = 32 * WM, BN = 64 * TN, NBUF = (WM == 2 && LO) ? 3 : 4, D = NBUF - 1;
 #else
@@ -374,153 +373,6 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
     }
   };
   RGCN_STAMP(1);
-  bool piped = false;
-  if constexpr (WM == 2) {
-  if (pipe) {
-    piped = true;
-    // Software-pipelined k loop (round 3).  The loop above runs its phases one after the other in every wave - wait
-    // for the tile, barrier, 12 fragment reads and their latency, 6 DMA issues, split, 12 MFMAs - and the waves of a CU
-    // move in lockstep, so a k-tile costs the SUM of the phases (the stamp probe: ~0.8 us per k-tile even with the split
-    // compiled out, 0.32 us of it MFMA).  Here the fragments of tile i + 1 are read into a SECOND register set while
-    // tile i is multiplied: iteration i = [own reads of tile i back, own DMAs of tile i + 1 landed] -> barrier (every
-    // wave's reads of tile i are in registers, so its ring slot is free; every wave's tile i + 1 has landed) -> issue
-    // the reads of tile i + 1 -> issue the DMAs of tile i + 3 into tile i's slot -> split + MFMAs of tile i.  Still one
-    // barrier per k-tile and two tiles in flight (the ring's third slot holds the tile being read).  Same operands
-    // into the same MFMAs in the same order: the same bits.
-    constexpr int PARTS_ = PARTS;
-    f32x4 qa[2][2][2], qh[2][2][TN], ql[2][2][TN];             // [register set][16-k step][...]
-    int cur = ktq[0], nxt = ktq[1];                            // (D == 2 tiles are staged: slots 0, 1)
-    int nx2 = nxt < K ? next_kt(nxt) : K;
-    if (nx2 < K) stage(nx2, 2);                                // the third slot: two tiles in flight behind the first
-    auto reads = [&](f32x4 (&ra)[2][2], f32x4 (&rh)[2][TN], f32x4 (&rl)[2][TN], unsigned buf) __attribute__((always_inline)) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        asm volatile("ds_read_b128 %0, %1" : "=v"(ra[s][0]) : "v"(a_addr[s][0] + buf));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(ra[s][1]) : "v"(a_addr[s][1] + buf));
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          asm volatile("ds_read_b128 %0, %1" : "=v"(rh[s][b]) : "v"(b_addr[b][s] + buf));
-          if constexpr (PARTS_ == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rl[s][b]) : "v"(b_addr[b][s] + buf), "n"(B_BYTES));
-        }
-      }
-    };
-    // one iteration on register set SET; returns false when the last tile has been multiplied
-    auto iter = [&](f32x4 (&ca)[2][2], f32x4 (&ch)[2][TN], f32x4 (&cl)[2][TN], f32x4 (&na)[2][2], f32x4 (&nh)[2][TN],
-                    f32x4 (&nl)[2][TN]) __attribute__((always_inline)) {
-      // own reads of the current tile are back (tied to the registers they fill: their uses stay below);
-      // own DMAs of the next tile have landed (those of the tile after it may still fly)
-      if constexpr (TN > 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0][0]), "+v"(ca[0][1]), "+v"(ca[1][0]), "+v"(ca[1][1]),
-                                              "+v"(ch[0][0]), "+v"(ch[0][1]), "+v"(ch[1][0]), "+v"(ch[1][1]));
-        if constexpr (LO) asm volatile("" : "+v"(cl[0][0]), "+v"(cl[0][1]), "+v"(cl[1][0]), "+v"(cl[1][1]));
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ca[0][0]), "+v"(ca[0][1]), "+v"(ca[1][0]), "+v"(ca[1][1]),
-                                              "+v"(ch[0][0]), "+v"(ch[1][0]));
-        if constexpr (LO) asm volatile("" : "+v"(cl[0][0]), "+v"(cl[1][0]));
-      }
-      if (nxt < K) {
-        if (nx2 < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        reads(na, nh, nl, (unsigned)(((t + 1) % NBUF) * BUF_BYTES));
-        const int nx3 = nx2 < K ? next_kt(nx2) : K;
-        if (nx3 < K) stage(nx3, t % NBUF);                     // into the slot of the tile whose fragments are in registers
-        // the multiply below stays BELOW the reads and DMAs just issued (the compiler would otherwise hoist it above
-        // the barrier and read the next tile into the same registers: the serial loop again)
-        if constexpr (TN > 1)
-          asm volatile("" : "+v"(ca[0][0]), "+v"(ca[0][1]), "+v"(ca[1][0]), "+v"(ca[1][1]), "+v"(ch[0][0]), "+v"(ch[0][1]),
-                            "+v"(ch[1][0]), "+v"(ch[1][1]));
-        else
-          asm volatile("" : "+v"(ca[0][0]), "+v"(ca[0][1]), "+v"(ca[1][0]), "+v"(ca[1][1]), "+v"(ch[0][0]), "+v"(ch[1][0]));
-        const float sa = cur < K1 ? sa1 : sa2;
-        const bool last_a1 = K2 > 0 && cur < K1 && nxt >= K1;  // wave-uniform
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          half8 ah, al;
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const float v = ca[s][q][c] * sa;
-              const _Float16 h = (_Float16)v;
-              ah[4 * q + c] = h;
-              if constexpr (LO) al[4 * q + c] = (_Float16)(v - (float)h);
-            }
-#pragma unroll
-          for (int b = 0; b < TN; ++b) {                       // small terms first
-            const half8 bh = __builtin_bit_cast(half8, ch[s][b]);
-            if constexpr (LO) {
-              const half8 bl = __builtin_bit_cast(half8, cl[s][b]);
-              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
-              acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
-            }
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
-          }
-        }
-        if (__builtin_amdgcn_readfirstlane((int)last_a1)) {    // sums so far -> A2's scale, ONCE (a real branch: the asm pins it)
-          asm volatile("" ::: "memory");
-          const float down = pow2f(-ea1);
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[b][r] = acc[b][r] * down * sa2;
-        }
-        cur = nxt;
-        nxt = nx2;
-        nx2 = nx3;
-        ++t;
-        return true;
-      }
-      // the last tile: nothing to read, nothing to stage
-      const float sa = cur < K1 ? sa1 : sa2;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        half8 ah, al;
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float v = ca[s][q][c] * sa;
-            const _Float16 h = (_Float16)v;
-            ah[4 * q + c] = h;
-            if constexpr (LO) al[4 * q + c] = (_Float16)(v - (float)h);
-          }
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          const half8 bh = __builtin_bit_cast(half8, ch[s][b]);
-          if constexpr (LO) {
-            const half8 bl = __builtin_bit_cast(half8, cl[s][b]);
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
-          }
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
-        }
-      }
-      if (K2 > 0 && cur < K1) {                                // (a call whose last tile lies in A1: no A2 tile was left)
-        const float down = pow2f(-ea1);
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[b][r] = acc[b][r] * down * sa2;
-      }
-      cur = K;
-      return false;
-    };
-    if (cur < K) {
-      // tile 0 has landed for this wave, then for every wave; its fragments into set 0
-      if (nx2 < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-      else if (nxt < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      reads(qa[0], qh[0], ql[0], 0u);
-      while (iter(qa[0], qh[0], ql[0], qa[1], qh[1], ql[1]) && iter(qa[1], qh[1], ql[1], qa[0], qh[0], ql[0])) {}
-      // nothing is outstanding here (the last iteration issues no reads); the wait costs nothing and lets the static
-      // checker (tools/check_waitcnt.py), which follows every edge of the compiled loop, see that too
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-  }
-  }
-  if (!piped) {
   while (ktq[0] < K1) k_tile(sa1);
   if (K2 > 0) {                                  // sums so far -> A2's scale (two exact power-of-two factors)
     const float down = pow2f(-ea1);
@@ -529,7 +381,6 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][r] = acc[b][r] * down * sa2;
     while (ktq[0] < K) k_tile(sa2);
-  }
   }
 
   RGCN_STAMP(2);
@@ -1209,26 +1060,16 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
   if (!r1.slots) { r1 = r2; r2 = amax_ref{nullptr, 0}; a1_mul = 1.f; }   // the kernels read r1 unconditionally
   if (kseg <= 0 || kseg % BK != 0) tile_mask = nullptr;
   unsigned* amax_out = reinterpret_cast<unsigned*>(c_amax);
-  // RGCN_NT_PIPE=1: the software-pipelined k loop (measured SLOWER: 0.293 against 0.287 ms per step); same bits either way
-  static const int pipe = [] {
-    const char* e = getenv("RGCN_NT_PIPE");
-    return (e && e[0] == '1') ? 1 : 0;
-  }();
 #define RGCN_NT_LAUNCH(WM_, TN_, EPI_, LO_)                                                                          \
   k_gemm_nt_split<WM_, TN_, EPI_, LO_><<<grid, 128 * WM_, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, \
                                                                         bias, mask, C, M, N, tile_mask, kseg, amax_out, \
-                                                                        fin, out_scale, pipe)
+                                                                        fin, out_scale)
 #define RGCN_NT_SPLIT(WM_, TN_, EPI_)        \
   do {                                       \
     if (half) RGCN_NT_LAUNCH(WM_, TN_, EPI_, false); \
     else RGCN_NT_LAUNCH(WM_, TN_, EPI_, true);       \
   } while (0)
-  // RGCN_NT_COLS=64: 64-column tiles for every width (A/B runs): three workgroups of 48 KB per CU instead of two of 72 KB
-  static const bool narrow = [] {
-    const char* e = getenv("RGCN_NT_COLS");
-    return e && atoi(e) == 64;
-  }();
-  if (N <= 64 || (narrow && !fin.ptr)) {
+  if (N <= 64) {
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
     if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 1, EPI_RELU);
     else if (epi == EPI_MASK) RGCN_NT_SPLIT(2, 1, EPI_MASK);
