@@ -14,7 +14,9 @@ steps = (tr["edge_index"].size(1) + args.batch_size - 1) // args.batch_size
 trainer.train_epoch(max_steps=20)                 # warm-up (bucketing, allocator)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-loss, acc = trainer.train_epoch()
+limit = int(os.environ.get("RGCN_EPOCH_STEPS", "0")) or None          # a shorter run for the profiler
+loss, acc = trainer.train_epoch(max_steps=limit)
+steps = min(steps, limit) if limit else steps
 torch.cuda.synchronize()
 t = time.perf_counter() - t0
 print(f"train columns {tr['edge_index'].size(1):,}  steps/epoch {steps}  epoch {t:.2f} s  "
@@ -23,3 +25,14 @@ t0 = time.perf_counter()
 vl, va_acc = trainer.validate()
 torch.cuda.synchronize()
 print(f"validate {time.perf_counter() - t0:.2f} s  val loss {vl:.4f} acc {va_acc:.4f}")
+if args.no_hip_graph:                             # which passes of the eager step are issued natively (ops.Region)
+    import gc
+    import warnings
+    from primekg_rgcn_linkprediction_amd import ops
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")           # (isinstance on every live object wakes deprecated module attributes)
+        graphs = [o for o in gc.get_objects() if isinstance(o, ops.BucketedGraph)]
+    for g in graphs:
+        for (name, *_), state in getattr(g, "_regions", {}).items():
+            what = "native" if isinstance(state, ops._Plan) else (state if isinstance(state, str) else state[0])
+            print(f"  region {name}: {what}")
