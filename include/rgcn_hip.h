@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 20
+#define RGCN_ABI_VERSION 21
 
 enum {
   RGCN_OK = 0,
@@ -455,6 +455,15 @@ int distmult_bce_bwd(const float* grad_mean_loss, const float* scores, const flo
                      const int64_t* h_idx, int64_t h_rows, const float* t, const int64_t* t_idx, int64_t t_rows,
                      const float* r, const int64_t* r_idx, int64_t r_rows, int64_t batch, int64_t d, float* grad_h,
                      float* grad_t, float* grad_r, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The step's bookkeeping around that loss in ONE launch (src/train.py:300, 321-326: the mean of BCEWithLogitsLoss,
+ * `predictions = sigmoid(scores) > 0.5`, `correct += (predictions == labels).sum()`, `total_loss += loss.item() * n` -
+ * nine elementwise / reduce launches when written in torch): mean_loss[0] = mean(loss[0..batch)) in a fixed order (two
+ * runs give the same bits); loss_sum[0] += (double)mean * batch and correct[0] += #{b : (scores[b] > 0) == (labels[b] >
+ * 0.5)} - the epoch's running sums, device-resident, either may be NULL; cursor[0] += cursor_add - the position of the
+ * next batch in the epoch's permutation (rgcn_sample_batch reads it), NULL to leave it alone. */
+int distmult_bce_reduce(const float* loss, const float* scores, const float* labels, int64_t batch, float* mean_loss,
+                        double* loss_sum, int64_t* correct, int64_t* cursor, int64_t cursor_add, void* stream);
 
 /* out[num_rows, d] = sum over b of rows[b, :] into row idx[b], deterministic (the two-level tree above by
  * itself): autograd of `table[idx]` for a table of few rows - LinkPredictor's relation embeddings when their

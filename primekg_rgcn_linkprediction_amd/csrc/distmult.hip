@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void k_distmult_fwd(const float* __restri
 //      flight, and writes the row once.  Head and tail slots of one table (grad_h == grad_t) are one key
 //      space.  The caller zeroes the rows nobody touches.
 //   3. k_segment_partials / k_segment_combine: the relation table (few rows, hundreds of occurrences
-//      each) as a fixed two-level tree: one wave per (row, 256-sample segment) adds its occurrences in
+//      each) as a fixed two-level tree: one wave per (row, segment of >= 64 samples) adds its occurrences in
 //      order, one wave per row adds the segments in order.
 // Every sum has a fixed order: two runs give the same bits.
 // ---------------------------------------------------------------------------------------
@@ -158,21 +158,27 @@ __device__ inline float4 ordered_row_sum(MatchIter& it, const float* __restrict_
   return acc;
 }
 
-constexpr int kScatterWaves = 4;                 // waves (slots) per workgroup
+constexpr int kScatterWaves = 16;                // waves (slots) per workgroup: one staging of the keys serves sixteen slots
 constexpr int kKeysInLds = 16384;                // key count up to which the keys are staged in LDS
 
-// rows[S, d] (workspace), keys[S] -> out[key] = sum of the rows with that key, in slot order; one wave per slot
+// rows[S, d] (workspace), keys[S] -> out[key] = sum of the rows with that key, in slot order; one wave per slot, sixteen
+// slots per workgroup (one staging of the keys serves them all).  A slot that finds an equal key BEFORE itself
+// retires; the first occurrence of a row adds the rows of all its occurrences in slot order.  A template on where the
+// keys are: the scans then read LDS with ds_read_b32, not through a flat pointer.
+// (Round 3 tried a chunked two-pass form - every 16th occurrence adds its chunk, a second launch adds the chunk sums
+// of the rows with more than 16 occurrences - to shorten the chain of a hub with 100+ occurrences: 15 + 18 us against
+// this kernel's 27 us.  The launch is bound by the scans over the keys, not by the hub's additions.)
+template <bool IN_LDS>
 __global__ __launch_bounds__(64 * kScatterWaves) void k_scatter_rows(const int32_t* __restrict__ keys, int S,
-                                                                       const float* __restrict__ rows, int d,
-                                                                       float* __restrict__ out) {
-  __shared__ int32_t skeys[kKeysInLds];
+                                                                              const float* __restrict__ rows, int d,
+                                                                              float* __restrict__ out) {
+  __shared__ int32_t skeys[IN_LDS ? kKeysInLds : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool in_lds = S <= kKeysInLds;
-  if (in_lds) {
+  if (IN_LDS) {
     for (int i = threadIdx.x; i < S; i += 64 * kScatterWaves) skeys[i] = keys[i];
     __syncthreads();
   }
-  const int32_t* k = in_lds ? skeys : keys;
+  const int32_t* k = IN_LDS ? skeys : keys;
   const int s = blockIdx.x * kScatterWaves + wave;
   if (s >= S) return;
   const int my = k[s];
@@ -180,23 +186,26 @@ __global__ __launch_bounds__(64 * kScatterWaves) void k_scatter_rows(const int32
     const int p = c + lane;
     if (__ballot(p < s && k[p] == my)) return;
   }
-  for (int c0 = lane * 4; c0 < ((d + 255) & ~255); c0 += 256) {   // (d <= 256: one pass; wider rows rescan the matches)
+  for (int c0 = lane * 4; c0 < ((d + 255) & ~255); c0 += 256) {
     MatchIter it;
     it.start(k, my, s, S, lane);
-    const int cc = min(c0, d - 4);               // lanes past the row end follow the (wave-uniform) iteration
+    const int cc = min(c0, d - 4);
     const float4 acc = ordered_row_sum(it, rows, d, cc, lane);
     if (c0 < d) *reinterpret_cast<float4*>(out + (size_t)my * d + c0) = acc;
   }
 }
 
-constexpr int kSegment = 256;                    // samples per segment of the relation-table tree
+// samples per segment of the relation-table tree: 64 for the training batch (a wave then adds ~20 rows in order instead
+// of ~85 - the launch is one latency chain per wave, 19 us at 256), growing with the batch so that the combine pass
+// never walks more than 64 segments
+inline int64_t segment_len(int64_t batch) { return std::max<int64_t>(64, (ceil_div64(batch, 64) + 63) / 64 * 64); }
 
 // partial[(seg * R + row), :] = sum of rows[b] over b in segment seg with keys[b] == row, in order
 __global__ __launch_bounds__(64) void k_segment_partials(const int32_t* __restrict__ keys, int B,
-                                                         const float* __restrict__ rows, int d, int R,
+                                                         const float* __restrict__ rows, int d, int R, int seg_len,
                                                          float* __restrict__ partial) {
   const int lane = threadIdx.x, row = blockIdx.x, seg = blockIdx.y;
-  const int lo = seg * kSegment, hi = min(B, lo + kSegment);
+  const int lo = seg * seg_len, hi = min(B, lo + seg_len);
   for (int c0 = lane * 4; c0 < ((d + 255) & ~255); c0 += 256) {
     MatchIter it;
     it.start(keys, row, lo, hi, lane);
@@ -212,11 +221,52 @@ __global__ __launch_bounds__(64) void k_segment_combine(const float* __restrict_
   const int lane = threadIdx.x, row = blockIdx.x;
   for (int c0 = lane * 4; c0 < d; c0 += 256) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nseg; ++s) {
-      const float4 v = ld4(partial + ((size_t)s * R + row) * d + c0);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    for (int s0 = 0; s0 < nseg; s0 += 16) {      // sixteen loads in flight, added in segment order
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        v[u] = s0 + u < nseg ? ld4(partial + ((size_t)(s0 + u) * R + row) * d + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+      }
     }
     *reinterpret_cast<float4*>(out + (size_t)row * d + c0) = acc;
+  }
+}
+
+// The step's bookkeeping in ONE launch (one 1,024-thread workgroup): mean of the per-sample losses (fixed order: thread i
+// adds elements i, i + 1024, ... , then a fixed tree - two runs give the same bits), the epoch's running sums
+// (src/train.py:321-326: `predictions = sigmoid(scores) > 0.5`, `correct += (predictions == labels).sum()`,
+// `total_loss += loss.item() * labels.size(0)`) kept on the device, and the batch cursor moved on.
+__global__ __launch_bounds__(1024) void k_bce_reduce(const float* __restrict__ loss, const float* __restrict__ scores,
+                                                     const float* __restrict__ labels, int B, float* __restrict__ mean_loss,
+                                                     double* __restrict__ loss_sum, long long* __restrict__ correct,
+                                                     long long* __restrict__ cursor, long long cursor_add) {
+  __shared__ float red[1024];
+  __shared__ int hits[1024];
+  float s = 0.f;
+  int c = 0;
+  for (int b = threadIdx.x; b < B; b += 1024) {
+    s += loss[b];
+    if (correct) c += ((scores[b] > 0.f) == (labels[b] > 0.5f)) ? 1 : 0;
+  }
+  red[threadIdx.x] = s;
+  hits[threadIdx.x] = c;
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[threadIdx.x] += red[threadIdx.x + w];
+      hits[threadIdx.x] += hits[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float mean = red[0] / (float)B;
+    mean_loss[0] = mean;
+    if (loss_sum) loss_sum[0] += (double)mean * (double)B;
+    if (correct) correct[0] += hits[0];
+    if (cursor) cursor[0] += cursor_add;
   }
 }
 
@@ -281,9 +331,20 @@ int distmult_bce_fwd(const float* h, const int64_t* h_idx, int64_t h_rows, const
   return RGCN_OK;
 }
 
+int distmult_bce_reduce(const float* loss, const float* scores, const float* labels, int64_t batch, float* mean_loss,
+                        double* loss_sum, int64_t* correct, int64_t* cursor, int64_t cursor_add, void* stream_) {
+  if (batch <= 0 || !loss || !mean_loss || (correct && (!scores || !labels))) return RGCN_ERR_ARG;
+  if (batch > INT32_MAX / 2) return RGCN_ERR_UNSUPPORTED;
+  k_bce_reduce<<<1, 1024, 0, (hipStream_t)stream_>>>(loss, scores, labels, (int)batch, mean_loss, loss_sum,
+                                                     reinterpret_cast<long long*>(correct), reinterpret_cast<long long*>(cursor),
+                                                     (long long)cursor_add);
+  RGCN_HIP_TRY(hipGetLastError());
+  return RGCN_OK;
+}
+
 size_t distmult_bwd_workspace_bytes(int64_t batch, int64_t d, int64_t r_rows) {
   if (batch <= 0 || d <= 0) return 0;
-  const int64_t nseg = ceil_div64(batch, kSegment);
+  const int64_t nseg = ceil_div64(batch, segment_len(batch));
   return ((size_t)3 * batch * d + (size_t)nseg * (r_rows > 0 ? r_rows : 0) * d) * sizeof(float) +
          (size_t)3 * batch * sizeof(int32_t) + 256;
 }
@@ -306,7 +367,7 @@ int bwd_impl(const float* gs, const float* scores, const float* labels, const fl
   float* ws = (float*)workspace;
   const size_t bd = (size_t)batch * d;
   float *ch = ws, *ct = ws + bd, *cr = ws + 2 * bd;
-  const int64_t nseg = ceil_div64(batch, kSegment);
+  const int64_t nseg = ceil_div64(batch, segment_len(batch));
   float* partial = ws + 3 * bd;
   int32_t* keys = (int32_t*)(partial + (size_t)nseg * (r_idx ? r_rows : 0) * d);
   int32_t *kh = keys, *kt = keys + batch, *kr = keys + 2 * batch;
@@ -321,18 +382,20 @@ int bwd_impl(const float* gs, const float* scores, const float* labels, const fl
                     (grad_h && h_idx) ? kh : nullptr, (grad_t && t_idx) ? kt : nullptr, (grad_r && r_idx) ? kr : nullptr,
                     scores, labels)));
   const bool sh = grad_h && h_idx, st = grad_t && t_idx;
-  if (sh && st && grad_h == grad_t) {            // one table, one key space: head slots then tail slots
-    const int S = (int)(2 * batch);
-    k_scatter_rows<<<(unsigned)ceil_div64(S, kScatterWaves), 64 * kScatterWaves, 0, stream>>>(kh, S, ch, (int)d, grad_h);
-  } else {
-    const int S = (int)batch;
+  auto scatter = [&](const int32_t* k, int S, const float* rows, float* out) {
     const unsigned sg = (unsigned)ceil_div64(S, kScatterWaves);
-    if (sh) k_scatter_rows<<<sg, 64 * kScatterWaves, 0, stream>>>(kh, S, ch, (int)d, grad_h);
-    if (st) k_scatter_rows<<<sg, 64 * kScatterWaves, 0, stream>>>(kt, S, ct, (int)d, grad_t);
+    if (S <= kKeysInLds) k_scatter_rows<true><<<sg, 64 * kScatterWaves, 0, stream>>>(k, S, rows, (int)d, out);
+    else k_scatter_rows<false><<<sg, 64 * kScatterWaves, 0, stream>>>(k, S, rows, (int)d, out);
+  };
+  if (sh && st && grad_h == grad_t) {            // one table, one key space: head slots then tail slots
+    scatter(kh, (int)(2 * batch), ch, grad_h);
+  } else {
+    if (sh) scatter(kh, (int)batch, ch, grad_h);
+    if (st) scatter(kt, (int)batch, ct, grad_t);
   }
   if (grad_r && r_idx && r_rows > 0) {
     dim3 pg((unsigned)r_rows, (unsigned)nseg);
-    k_segment_partials<<<pg, 64, 0, stream>>>(kr, (int)batch, cr, (int)d, (int)r_rows, partial);
+    k_segment_partials<<<pg, 64, 0, stream>>>(kr, (int)batch, cr, (int)d, (int)r_rows, (int)segment_len(batch), partial);
     k_segment_combine<<<(unsigned)r_rows, 64, 0, stream>>>(partial, (int)nseg, (int)r_rows, (int)d, grad_r);
   }
   RGCN_HIP_TRY(hipGetLastError());
@@ -367,7 +430,7 @@ int distmult_bce_bwd(const float* grad_mean_loss, const float* scores, const flo
 
 size_t rgcn_segment_sum_workspace_bytes(int64_t batch, int64_t d, int64_t num_rows) {
   if (batch <= 0 || d <= 0 || num_rows <= 0) return 0;
-  return (size_t)ceil_div64(batch, kSegment) * num_rows * d * sizeof(float) + (size_t)batch * sizeof(int32_t) + 256;
+  return (size_t)ceil_div64(batch, segment_len(batch)) * num_rows * d * sizeof(float) + (size_t)batch * sizeof(int32_t) + 256;
 }
 
 int rgcn_segment_sum(const float* rows, const int64_t* idx, int64_t batch, int64_t d, int64_t num_rows, float* out,
@@ -381,12 +444,12 @@ int rgcn_segment_sum(const float* rows, const int64_t* idx, int64_t batch, int64
   if (!rows || !idx) return RGCN_ERR_ARG;
   if (batch > INT32_MAX / 4 || num_rows > INT32_MAX) return RGCN_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < rgcn_segment_sum_workspace_bytes(batch, d, num_rows)) return RGCN_ERR_WORKSPACE;
-  const int64_t nseg = ceil_div64(batch, kSegment);
+  const int64_t nseg = ceil_div64(batch, segment_len(batch));
   float* partial = (float*)workspace;
   int32_t* keys = (int32_t*)(partial + (size_t)nseg * num_rows * d);
   k_keys32<<<(unsigned)ceil_div64(batch, 256), 256, 0, stream>>>(idx, batch, num_rows, keys);
   dim3 pg((unsigned)num_rows, (unsigned)nseg);
-  k_segment_partials<<<pg, 64, 0, stream>>>(keys, (int)batch, rows, (int)d, (int)num_rows, partial);
+  k_segment_partials<<<pg, 64, 0, stream>>>(keys, (int)batch, rows, (int)d, (int)num_rows, (int)segment_len(batch), partial);
   k_segment_combine<<<(unsigned)num_rows, 64, 0, stream>>>(partial, (int)nseg, (int)num_rows, (int)d, out);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;

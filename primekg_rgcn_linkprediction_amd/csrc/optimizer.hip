@@ -7,9 +7,9 @@
 // multi_tensor_apply runs 2.1M parameters on 32 workgroups: 84 us measured for both).  Here the
 // parameter tensors (<= 32) travel to the kernels BY VALUE in the launch arguments - no device-side
 // table, so the launch can sit in a captured HIP graph with the addresses it was captured with -
-// and the work is one streaming pass in 8,192-element slices:
+// and the work is one streaming pass in 2,048-element slices:
 //   k_sumsq      : sum of g^2 per slice (fixed order: deterministic); bumps every step counter
-//   k_adam_update: each workgroup re-reduces the few hundred slice sums -> clip coefficient, then
+//   k_adam_update: each workgroup re-reduces the ~1,000 slice sums -> clip coefficient, then
 //                  updates its slice of p / m / v exactly as torch.optim.Adam(W) does (fp32).
 #include "rgcn_common.h"
 
@@ -17,7 +17,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxTensors = 32;
-constexpr int kSlice = 8192;                     // elements per workgroup
+constexpr int kSlice = 2048;                     // elements per workgroup (2.1 M parameters: ~1,040 workgroups, 4 per CU)
 
 struct AdamList {
   float* p[kMaxTensors];
@@ -46,6 +46,14 @@ __device__ inline float block_sum(float s, float* red) {
   return red[0];
 }
 
+// A slice is 2,048 elements = 2 float4 per thread and operand, all requested before the first is used (round 2 read a
+// slice of 8,192 with 32 dependent round trips per thread, one workgroup per CU: 27.8 us for 59 MB, three times the
+// byte floor).  Slices start at multiples of 2,048 elements, so a tensor whose base is 16-byte aligned (every torch
+// allocation) is read as float4; anything else, and the ragged tail of a tensor, goes element by element.
+constexpr int kQuads = kSlice / (4 * kThreads);  // float4 per thread and operand: 2
+
+__device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 __global__ __launch_bounds__(kThreads) void k_sumsq(const AdamList L, float* __restrict__ partial) {
   __shared__ float red[kThreads];
   if (blockIdx.x == 0 && (int)threadIdx.x < L.count) L.step[threadIdx.x][0] += 1.f;   // `step += 1` per tensor
@@ -54,7 +62,16 @@ __global__ __launch_bounds__(kThreads) void k_sumsq(const AdamList L, float* __r
   const int64_t lo = (int64_t)(blockIdx.x - L.first_block[t]) * kSlice;
   const int64_t hi = lo + kSlice < L.n[t] ? lo + kSlice : L.n[t];
   float s = 0.f;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) s += g[i] * g[i];          // coalesced, any alignment
+  if (hi - lo == kSlice && aligned16(g)) {
+    const float4* g4 = reinterpret_cast<const float4*>(g + lo);
+    float4 v[kQuads];
+#pragma unroll
+    for (int q = 0; q < kQuads; ++q) v[q] = g4[q * kThreads + threadIdx.x];
+#pragma unroll
+    for (int q = 0; q < kQuads; ++q) s += v[q].x * v[q].x + v[q].y * v[q].y + v[q].z * v[q].z + v[q].w * v[q].w;
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) s += g[i] * g[i];        // coalesced, any alignment
+  }
   const float total = block_sum(s, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = total;
 }
@@ -82,14 +99,41 @@ __global__ __launch_bounds__(kThreads) void k_adam_update(const AdamList L, cons
   float* v = L.v[t];
   const int64_t lo = (int64_t)(blockIdx.x - L.first_block[t]) * kSlice;
   const int64_t hi = lo + kSlice < L.n[t] ? lo + kSlice : L.n[t];
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
-    float pp = p[i], mm = m[i], vv = v[i], gg = g[i] * coef;
+  auto update = [&](float& pp, float& mm, float& vv, float gg) {
+    gg *= coef;
     if (adamw) pp *= 1.f - lr * weight_decay;
     else if (weight_decay != 0.f) gg += weight_decay * pp;
     mm = mm + (gg - mm) * (1.f - beta1);                      // exp_avg.lerp_(grad, 1 - beta1)
     vv = beta2 * vv + (1.f - beta2) * gg * gg;                // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
     pp -= step_size * (mm / denom);
+  };
+  if (hi - lo == kSlice && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) {
+    // the same arithmetic per element, every load of the slice in flight before the first use
+    float4* p4 = reinterpret_cast<float4*>(p + lo);
+    const float4* g4 = reinterpret_cast<const float4*>(g + lo);
+    float4* m4 = reinterpret_cast<float4*>(m + lo);
+    float4* v4 = reinterpret_cast<float4*>(v + lo);
+    float4 pp[kQuads], gg[kQuads], mm[kQuads], vv[kQuads];
+#pragma unroll
+    for (int q = 0; q < kQuads; ++q) {
+      const int i = q * kThreads + threadIdx.x;
+      pp[q] = p4[i]; gg[q] = g4[i]; mm[q] = m4[i]; vv[q] = v4[i];
+    }
+#pragma unroll
+    for (int q = 0; q < kQuads; ++q) {
+      const int i = q * kThreads + threadIdx.x;
+      update(pp[q].x, mm[q].x, vv[q].x, gg[q].x);
+      update(pp[q].y, mm[q].y, vv[q].y, gg[q].y);
+      update(pp[q].z, mm[q].z, vv[q].z, gg[q].z);
+      update(pp[q].w, mm[q].w, vv[q].w, gg[q].w);
+      p4[i] = pp[q]; m4[i] = mm[q]; v4[i] = vv[q];
+    }
+    return;
+  }
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+    float pp = p[i], mm = m[i], vv = v[i];
+    update(pp, mm, vv, g[i]);
     p[i] = pp;
     m[i] = mm;
     v[i] = vv;

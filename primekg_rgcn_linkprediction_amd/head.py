@@ -87,7 +87,7 @@ class _DistMultBCEFunction(torch.autograd.Function):
     (``src/train.py:300``).  ``scores`` is returned for the accuracy bookkeeping only."""
 
     @staticmethod
-    def forward(ctx, h, h_idx, t, t_idx, r, r_idx, labels):
+    def forward(ctx, h, h_idx, t, t_idx, r, r_idx, labels, stats=None):
         h, t, r = h.contiguous(), t.contiguous(), r.contiguous()
         h_idx, t_idx, r_idx = (i.contiguous() if i is not None else None for i in (h_idx, t_idx, r_idx))
         labels = labels.contiguous()
@@ -97,12 +97,19 @@ class _DistMultBCEFunction(torch.autograd.Function):
         ctx.same_ht = h.data_ptr() == t.data_ptr() and h.shape == t.shape
         ctx.save_for_backward(h, h_idx, t, t_idx, r, r_idx, labels, scores)
         ctx.mark_non_differentiable(scores)
-        return per_sample.mean(), scores
+        ctx.set_materialize_grads(False)             # (no zero-filled stand-in for the gradient of `scores` per step)
+        # the mean in a fixed order and, when the caller keeps running sums on the device (``stats`` = (loss_sum,
+        # correct, cursor, cursor_add), any of the first three None), the step's bookkeeping in the same launch
+        loss_sum, correct, cursor, cursor_add = stats if stats is not None else (None, None, None, 0)
+        mean = ops.distmult_bce_reduce(per_sample, scores, labels, loss_sum, correct, cursor, cursor_add)
+        return mean.reshape(()), scores
 
     @staticmethod
     def backward(ctx, g_loss, _g_scores):
         h, h_idx, t, t_idx, r, r_idx, labels, scores = ctx.saved_tensors
-        need_h, _, need_t, _, need_r, _, _ = ctx.needs_input_grad
+        need_h, _, need_t, _, need_r, _, _, _ = ctx.needs_input_grad
+        if g_loss is None:                           # nothing downstream used the loss
+            return (None,) * 8
 
         def buf(src, idx, need):
             if not need:
@@ -116,8 +123,8 @@ class _DistMultBCEFunction(torch.autograd.Function):
         ops.distmult_bce_bwd(g_loss.reshape(1).contiguous(), scores, labels, h, h_idx, t, t_idx, r, r_idx,
                              ctx.batch, gh, gt, gr)
         if shared:
-            return gh, None, None, None, gr, None, None
-        return gh, None, gt, None, gr, None, None
+            return gh, None, None, None, gr, None, None, None
+        return gh, None, gt, None, gr, None, None, None
 
 
 class _ScoreAllTailsFunction(torch.autograd.Function):
@@ -188,11 +195,13 @@ class LinkPredictor(nn.Module):
         return distmult(node_embeddings, head_indices, node_embeddings, tail_indices, r, r_idx)
 
     def bce_loss(self, node_embeddings: Tensor, head_indices: Tensor, tail_indices: Tensor,
-                 relation_types: Tensor, labels: Tensor):
-        """``(BCEWithLogitsLoss()(score_triples(...), labels), scores)`` as one fused node."""
+                 relation_types: Tensor, labels: Tensor, stats=None):
+        """``(BCEWithLogitsLoss()(score_triples(...), labels), scores)`` as one fused node.  ``stats``: the caller's
+        device-resident running sums and batch cursor ``(loss_sum, correct, cursor, cursor_add)``, updated by the launch
+        that forms the mean (``Trainer``: ``src/train.py:321-326`` without nine elementwise launches per step)."""
         r, r_idx = self._relation_operand(relation_types)
         return _DistMultBCEFunction.apply(node_embeddings, head_indices, node_embeddings, tail_indices,
-                                          r, r_idx, labels)
+                                          r, r_idx, labels, stats)
 
     @torch.no_grad()
     def rank_tails(self, head_embeddings: Tensor, relation_types: Tensor, all_tail_embeddings: Tensor,

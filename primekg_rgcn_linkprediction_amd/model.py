@@ -87,11 +87,12 @@ class DrugDiseaseModel(nn.Module):
         return self.decoder.score_triples(node_embeddings, head_indices, tail_indices, relation_types)
 
     def bce_loss(self, edge_index: Tensor, edge_type: Tensor, head_indices: Tensor, tail_indices: Tensor,
-                 relation_types: Tensor, labels: Tensor):
+                 relation_types: Tensor, labels: Tensor, stats=None):
         """``(nn.BCEWithLogitsLoss()(self(...), labels), scores)`` - what ``Trainer`` needs per
-        step (``train.py:291-300``) with the loss fused into the head kernels."""
+        step (``train.py:291-300``) with the loss fused into the head kernels; ``stats``: see
+        ``LinkPredictor.bce_loss``."""
         node_embeddings = self.encoder(edge_index, edge_type)
-        return self.decoder.bce_loss(node_embeddings, head_indices, tail_indices, relation_types, labels)
+        return self.decoder.bce_loss(node_embeddings, head_indices, tail_indices, relation_types, labels, stats)
 
     def predict(self, edge_index: Tensor, edge_type: Tensor, head_indices: Tensor,
                 tail_indices: Tensor, relation_types: Tensor) -> Tensor:

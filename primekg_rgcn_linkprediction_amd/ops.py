@@ -1486,6 +1486,33 @@ def distmult_bce_fwd(h, h_idx, t, t_idx, r, r_idx, labels, batch: int):
     return scores, loss
 
 
+def distmult_bce_reduce(loss: torch.Tensor, scores: torch.Tensor, labels: torch.Tensor, loss_sum=None, correct=None,
+                        cursor=None, cursor_add: int = 0) -> torch.Tensor:
+    """-> ``mean(loss)`` as a one-element tensor, in ONE launch together with the epoch's device-resident running sums
+    (``loss_sum`` float64 [] += mean * B, ``correct`` int64 [] += #{(scores > 0) == (labels > 0.5)}) and the batch cursor
+    (``cursor`` int64 [1] += cursor_add) - ``src/train.py:300, 321-326``; any of the three may be None."""
+    _need_gpu("loss", loss, torch.float32)
+    b = loss.numel()
+    if correct is not None:
+        _need_gpu("scores", scores, torch.float32)
+        _need_gpu("labels", labels, torch.float32)
+        _need_gpu("correct", correct, torch.int64)
+        if scores.numel() != b or labels.numel() != b:
+            raise ValueError("loss, scores and labels must have one element per sample")
+    if loss_sum is not None:
+        _need_gpu("loss_sum", loss_sum, torch.float64)
+    if cursor is not None:
+        _need_gpu("cursor", cursor, torch.int64)
+    lib = _L()
+    with _on(loss.device):
+        mean = _empty(1, dtype=torch.float32, device=loss.device)
+        rc = lib.distmult_bce_reduce(_ptr(loss), _ptr(scores) if correct is not None else None,
+                                     _ptr(labels) if correct is not None else None, b, _ptr(mean), _ptr(loss_sum),
+                                     _ptr(correct), _ptr(cursor), int(cursor_add), _stream())
+    _lib.check(rc, "distmult_bce_reduce")
+    return mean
+
+
 def _bwd_workspace(lib, batch: int, d: int, r, r_idx, device):
     nbytes = lib.distmult_bwd_workspace_bytes(batch, d, r.size(0) if r_idx is not None else 0)
     return _workspace(nbytes, device), nbytes

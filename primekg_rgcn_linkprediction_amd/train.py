@@ -99,6 +99,7 @@ class Trainer:
         extra = {"fused": True, "capturable": self.use_hip_graph} if device.type == "cuda" else {}
         self.optimizer = opt(self.model.parameters(), lr=args.lr, weight_decay=args.weight_decay, **extra)
         self._graph = self._loss_sum = None
+        self._grad_seed = {}
         # clip + Adam(W) as two launches of this package instead of ~14 of torch's
         self.fused_update = (device.type == "cuda" and not getattr(args, "torch_optimizer", False)
                              and not group_has_extras(self.optimizer))
@@ -113,6 +114,12 @@ class Trainer:
         self.checkpoint_dir, self.model_dir = self.output_dir / "checkpoints", self.output_dir / "models"
         self.checkpoint_dir.mkdir(parents=True, exist_ok=True)
         self.model_dir.mkdir(parents=True, exist_ok=True)
+
+    @property
+    def _fused_bookkeeping(self) -> bool:
+        """the criterion, the running loss / hit sums and the batch cursor inside the head's launches"""
+        return (self.device.type == "cuda" and isinstance(self.criterion, nn.BCEWithLogitsLoss)
+                and hasattr(self.model, "bce_loss"))
 
     # -- batches ------------------------------------------------------------------------
     def _batches(self, edge_index, edge_type, shuffle: bool):
@@ -149,18 +156,27 @@ class Trainer:
         ``update``) clip + optimizer step; running loss / hits stay on the device.  ``lo`` is
         only documentation here - the position is whatever ``self._cursor`` holds."""
         heads, tails, rels, labels = self._make_batch(lo, size)
-        if isinstance(self.criterion, nn.BCEWithLogitsLoss) and hasattr(self.model, "bce_loss"):
-            loss, scores = self.model.bce_loss(self.train_edge_index, self.train_edge_type, heads, tails, rels,
-                                               labels)                  # the criterion fused into the head
+        fused = self._fused_bookkeeping
+        if fused:
+            # the criterion fused into the head; the launch that forms the mean also keeps the epoch's running sums
+            # and moves the batch cursor on (device-side bookkeeping, no host sync, no elementwise launches)
+            loss, scores = self.model.bce_loss(self.train_edge_index, self.train_edge_type, heads, tails, rels, labels,
+                                               stats=(self._loss_sum, self._correct, self._cursor, size))
         else:
             scores = self.model(self.train_edge_index, self.train_edge_type, heads, tails, rels)
             loss = self.criterion(scores, labels)
-        (loss / accum if accum > 1 else loss).backward()
+        # d(loss / accum) / d loss as a kept device scalar: `.backward()` would launch a fill for its implicit ones
+        # tensor (and a division for the accumulation) in every step
+        seed = self._grad_seed.get(accum)
+        if seed is None:
+            seed = self._grad_seed[accum] = torch.full((), 1.0 / accum, device=self.device)
+        loss.backward(seed)
         if update:
             self._clip_and_update()
-        with torch.no_grad():                       # device-side bookkeeping, no host sync
-            self._loss_sum += loss.detach().double() * labels.numel()
-            self._correct += ((scores.detach() > 0) == (labels > 0.5)).sum()
+        if not fused:
+            with torch.no_grad():
+                self._loss_sum += loss.detach().double() * labels.numel()
+                self._correct += ((scores.detach() > 0) == (labels > 0.5)).sum()
         return heads, tails, rels, labels, loss.detach()
 
     def _clip_and_update(self) -> None:
@@ -215,6 +231,7 @@ class Trainer:
             self._rng = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64).to(self.device)
         self._loss_sum.zero_()
         self._correct.zero_()
+        self._cursor.zero_()
         self._rng[1] += 1
         # the permutation is drawn on the host like the reference's torch.randperm(num_edges)
         self._order.copy_(torch.randperm(e))
@@ -225,7 +242,8 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=True)
         for step in range(steps):
             lo, hi = step * bsz, min((step + 1) * bsz, e)
-            self._cursor.fill_(lo)
+            if not self._fused_bookkeeping:
+                self._cursor.fill_(lo)               # (the fused bookkeeping launch moves the cursor itself)
             replayable = self.use_hip_graph and hi - lo == bsz
             if replayable and step >= 1 and (self._graph is None or self._graph_batch != bsz):
                 self._capture_step(bsz)

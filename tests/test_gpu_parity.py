@@ -620,6 +620,37 @@ def test_distmult_duplicate_rows_and_dropout_path():
     assert distmult(e2[:0], None, e2[:0], None, e2[:0], None).shape == (0,)
 
 
+@pytest.mark.parametrize("shared", [True, False])
+def test_distmult_backward_counts_every_occurrence_once(shared):
+    """the head's backward adds a row's occurrences eight loads at a time, 64 keys per scan step: rows with exactly 1,
+    15, 16, 17, 31, 32, 33, 48, 100 and 700 occurrences, integer-valued contributions (every order gives the same
+    float) - the sums are exact, nothing is dropped or counted twice; head and tail slots of one table form one key
+    space"""
+    dev = need_gpu()
+    counts = [1, 15, 16, 17, 31, 32, 33, 48, 100, 700]
+    d = 128
+    ids = torch.cat([torch.full((c,), i, dtype=torch.int64) for i, c in enumerate(counts)])
+    gen = torch.Generator().manual_seed(3)
+    ids = ids[torch.randperm(ids.numel(), generator=gen)]
+    b = ids.numel()
+    other = torch.randint(len(counts), len(counts) + 50, (b,), generator=gen)          # rows the heads never use
+    rows = len(counts) + 50
+    emb = torch.ones(rows, d, device=dev, requires_grad=True)
+    tail_table = emb if shared else torch.ones(rows, d, device=dev, requires_grad=True)
+    rel = torch.ones(1, d, device=dev, requires_grad=True)
+    cot = torch.randint(-8, 9, (b,), generator=gen).float()
+    sc = distmult(emb, ids.to(dev), tail_table, other.to(dev), rel, torch.zeros(b, dtype=torch.int64, device=dev))
+    (sc * cot.to(dev)).sum().backward()
+    want_h = torch.zeros(rows).index_add_(0, ids, cot)                                   # per row: the sum of its cotangents
+    want_t = torch.zeros(rows).index_add_(0, other, cot)
+    if shared:
+        assert torch.equal(emb.grad.cpu(), (want_h + want_t).view(-1, 1).expand(-1, d))
+    else:
+        assert torch.equal(emb.grad.cpu(), want_h.view(-1, 1).expand(-1, d))
+        assert torch.equal(tail_table.grad.cpu(), want_t.view(-1, 1).expand(-1, d))
+    assert torch.equal(rel.grad.cpu(), cot.sum().view(1, 1).expand(1, d))
+
+
 def test_distmult_backward_is_deterministic_with_heavy_duplicates():
     """no float atomics in the head's backward: hub rows (one row the head of a third of the batch), head and tail
     from ONE table (one key space) or from two, relation table rows taking every sample - two runs give the

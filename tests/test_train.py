@@ -238,6 +238,57 @@ def test_gradient_accumulation_takes_one_update_per_group(tmp_path):
 
 
 @pytest.mark.gpu
+def test_fused_clip_adam_on_views_that_are_not_16_byte_aligned():
+    """the vector path of the update needs 16-byte aligned bases; a contiguous view one element into its storage takes
+    the element-wise path - same rule, same result as torch's"""
+    dev = need_gpu()
+    from primekg_rgcn_linkprediction_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    n = 3 * 8192 + 5
+    store = [torch.randn(n + 1, generator=gen).to(dev) for _ in range(4)]
+    p, g, m, v = (t[1:] for t in store)
+    m.zero_()
+    v.zero_()
+    before = [float(t[0]) for t in store]
+    assert p.data_ptr() % 16 == 4 and p.is_contiguous()
+    ref = p.detach().clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-2)
+    step = torch.zeros((), device=dev)
+    for _ in range(3):
+        ref.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        ops.adam_clip_step([p], [g], [m], [v], [step], 1e-2, 0.9, 0.999, 1e-8, 0.0, adamw=False, max_norm=1.0)
+        assert (p - ref.detach()).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    assert [float(t[0]) for t in store] == before                                 # the element before each view: untouched
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 1000, 2048, 5000])
+def test_bce_reduce_keeps_the_epoch_sums_on_the_device(batch):
+    """``distmult_bce_reduce``: the mean of the per-sample losses in a fixed order (same bits every run, float64 sum
+    within 1e-6), the running loss / hit sums of ``src/train.py:321-326`` and the batch cursor in the same launch"""
+    dev = need_gpu()
+    from primekg_rgcn_linkprediction_amd import ops
+    gen = torch.Generator().manual_seed(batch)
+    loss = torch.rand(batch, generator=gen).to(dev) * 3
+    scores = torch.randn(batch, generator=gen).to(dev)
+    labels = (torch.rand(batch, generator=gen) > 0.7).float().to(dev)
+    loss_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    correct = torch.zeros((), dtype=torch.int64, device=dev)
+    cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+    means = [ops.distmult_bce_reduce(loss, scores, labels, loss_sum, correct, cursor, 7) for _ in range(3)]
+    assert torch.equal(means[0], means[1]) and torch.equal(means[1], means[2])
+    want = loss.double().mean().item()
+    assert abs(means[0].item() - want) <= 1e-6 * max(1.0, want)
+    hits = int(((torch.sigmoid(scores) > 0.5).float() == labels).sum())          # the reference's expression
+    assert correct.item() == 3 * hits and cursor.item() == 21
+    assert abs(loss_sum.item() - 3 * float(means[0].double()) * batch) <= 1e-9 * max(1.0, loss_sum.item())
+    only_mean = ops.distmult_bce_reduce(loss, scores, labels)
+    assert torch.equal(only_mean, means[0]) and correct.item() == 3 * hits and cursor.item() == 21
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("adamw,wd,clip", [(False, 0.0, 1.0), (False, 0.01, 0.0), (True, 0.05, 0.5), (False, 0.0, 1e6)])
 def test_fused_clip_adam_equals_torch(adamw, wd, clip):
     """rgcn_adam_clip_step vs clip_grad_norm_ + torch.optim.Adam / AdamW over six steps: tensors of odd
