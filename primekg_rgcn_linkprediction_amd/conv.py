@@ -172,6 +172,7 @@ def _defer_hubs(half: bool, packed, amax, k: int, n_out: int) -> bool:
 
 
 _DEFER_HUBS = _os.environ.get("RGCN_DEFER_HUBS", "1") == "1"
+_SLAB_RIDES = _os.environ.get("RGCN_SLAB_RIDES", "1") == "1"      # 0: the slab reductions as launches of their own (A/B)
 
 
 def _train_fused(graph, n, r, d_in, d_out, half) -> bool:
@@ -300,6 +301,8 @@ def _enc2_backward(x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax, pk1bu
     # the slab reductions of the parameter gradients ride in the transposed gathers that follow them
     red2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2, graph=graph,
                                     defer=True, amax=(h_amax, h_amax, g_amax), precision=prec)
+    if not _SLAB_RIDES:
+        red2.finish()
     # dropout backward: the factor 1 / (1 - p) goes into the input-gradient epilogue as a scalar (the mask is h itself,
     # positive exactly where a unit is active and kept) - the weights keep their split images and the hub deferral
     scale = 1.0 / (1.0 - p) if p > 0 else 1.0
@@ -316,6 +319,8 @@ def _enc2_backward(x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax, pk1bu
                                      out_scale=scale)   # d loss / d (pre-ReLU of conv1)
     red1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1, graph=graph,
                                     defer=True, amax=(x_amax, x_amax, gz_amax), precision=prec)
+    if not _SLAB_RIDES:
+        red1.finish()
     gx = None
     if need_x:
         gx = _input_grad(graph, gz, w1, root1, tail=red1, g_amax=gz_amax, scales=scales, packed=pk1, precision=prec)
