@@ -27,6 +27,25 @@ t_fused = time.perf_counter() - t0
 m = ev2.compute_ranking_metrics()
 print(f"fused: {test['edge_index'].size(1)} test edges ranked in {t_fused * 1e3:.1f} ms (encoder once + one MFMA pass); "
       f"MRR {m['mrr']:.4f}")
+# the two device passes by themselves (events): the no-grad encoder and the fused ranking launch
+with torch.no_grad():
+    emb = ev2.embeddings()
+    head, tail, rel = ev2.test_edge_index[0], ev2.test_edge_index[1], ev2.test_edge_type
+    hemb = emb[head]
+    beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, fn in (("no-grad encoder", lambda: model.encoder(ev2.full_edge_index, ev2.full_edge_type)),
+                     ("rank_tails (products, true scores, MFMA pass with the counting epilogue)",
+                      lambda: model.decoder.rank_tails(hemb, rel, emb, tail)),
+                     ("score_all_tails, first 1,024 edges ([1024, 30926] matrix)",
+                      lambda: model.decoder.score_all_tails(hemb[:1024], rel[:1024], emb))):
+        for _ in range(3):
+            fn()
+        beg.record()
+        for _ in range(10):
+            fn()
+        end.record()
+        torch.cuda.synchronize()
+        print(f"    {name}: {beg.elapsed_time(end) / 10:.3f} ms")
 # the reference's loop, first 2 batches of 1,024
 eid, etd = ei.to(dev), et.to(dev)
 heads, tails, rels = (t.to(dev) for t in (test["edge_index"][0], test["edge_index"][1], test["edge_type"]))
