@@ -148,8 +148,8 @@ struct hub_fin {
   int d, tiles;
 };
 
-template <int WM, int TN, int EPI, bool LO>
-__global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restrict__ A1, int K1,
+template <int WM, int WN, int TN, int EPI, bool LO>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __restrict__ A1, int K1,
                                                             const float* __restrict__ A2, int K2,
                                                             const __half* __restrict__ Bh,
                                                             const __half* __restrict__ Bl,
@@ -160,24 +160,25 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
                                                             int M, int N, const uint32_t* __restrict__ tile_mask,
                                                             int kseg, unsigned* __restrict__ amax_out,
                                                             const hub_fin fin, float out_scale) {
+  constexpr int WAVES = WM * WN;                 // WM wave rows (32 output rows each) x WN wave columns (32 TN columns each)
 #ifdef RGCN_PROBE_DEPTH3                          // tools/gemm_stamps: one-pass (16 KB) slots in a ring of four - 2 workgroups per CU as before, 3 tiles in flight
-  constexpr int BM = 32 * WM, BN = 64 * TN, NBUF = (WM == 2 && LO) ? 3 : 4, D = NBUF - 1;
+  constexpr int BM = 32 * WM, BN = 32 * TN * WN, NBUF = (WM == 2 && LO) ? 3 : 4, D = NBUF - 1;
 #else
-  constexpr int BM = 32 * WM, BN = 64 * TN, NBUF = WM == 2 ? 3 : 4, D = NBUF - 1;   // D k-tiles in flight
+  constexpr int BM = 32 * WM, BN = 32 * TN * WN, NBUF = WM == 2 ? 3 : 4, D = NBUF - 1;   // D k-tiles in flight
 #endif
   constexpr int PARTS = LO ? 2 : 1;              // B images staged: hi (and lo)
   constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + PARTS * B_BYTES;
-  constexpr int A_PW = 2;                        // A DMA instructions per wave and k-tile (8 rows of 128 B each)
-  constexpr int B_PW = BN / (32 * WM);           // B DMA instructions per wave, k-tile and part (16 rows of 64 B each)
+  constexpr int A_PW = BM / (8 * WAVES);         // A DMA instructions per wave and k-tile (8 rows of 128 B each)
+  constexpr int B_PW = BN / (16 * WAVES);        // B DMA instructions per wave, k-tile and part (16 rows of 64 B each)
   constexpr int P = A_PW + PARTS * B_PW;
-  static_assert(B_PW >= 1 && A_PW * 8 * 2 * WM == BM, "tile / wave layout");
+  static_assert(A_PW >= 1 && B_PW >= 1 && A_PW * 8 * WAVES == BM && B_PW * 16 * WAVES == BN, "tile / wave layout");
   __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF_BYTES];   // the ONLY LDS object
 
   const int K = K1 + K2;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
   RGCN_STAMP(0);
   // Every workgroup of the launch starts at once and its first loads meet a cold memory system (2 us and more): the
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
   // Hub rows of this workgroup's row tiles whose partial rows the gather left unsummed: summed here, by the whole
   // workgroup, exactly as k_reduce_partials would (same function), written to A1 and only then read back by the
   // DMAs below.  Workgroups of other column blocks of the same rows write the same values.
-  if (WM == 2 && fin.ptr) {
+  if (WAVES == 4 && fin.ptr) {                   // (rgcn_reduce_item is written for 256 threads)
     const int t32 = m0 >> 5;
     const int jb = __builtin_amdgcn_readfirstlane(fin.ptr[min(t32, fin.tiles)]);
     const int je = __builtin_amdgcn_readfirstlane(fin.ptr[min(t32 + WM, fin.tiles)]);
@@ -334,7 +335,12 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
       // (one operand per DISTINCT register: naming fh[s][0] twice at TN == 1 makes the compiler copy it into a
       // second register ABOVE the wait - a read of a register whose ds_read has not landed: the one-pass
       // 64-column kernel returned different bits in one run of five)
-      if constexpr (TN > 1) {
+      if constexpr (TN == 4) {
+        if (s == 0) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fh[0][0]), "+v"(fh[0][1]), "+v"(fh[0][2]), "+v"(fh[0][3]) : "n"(kStepReads));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fh[1][0]), "+v"(fh[1][1]), "+v"(fh[1][2]), "+v"(fh[1][3]));
+        if (LO) asm volatile("" : "+v"(fl[s][0]), "+v"(fl[s][1]), "+v"(fl[s][2]), "+v"(fl[s][3]));
+      } else if constexpr (TN > 1) {
+        static_assert(TN <= 2 || TN == 4, "every fragment register must be tied to its wait");
         if (s == 0) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fh[0][0]), "+v"(fh[0][TN - 1]) : "n"(kStepReads));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fh[1][0]), "+v"(fh[1][TN - 1]));
         if (LO) asm volatile("" : "+v"(fl[s][0]), "+v"(fl[s][TN - 1]));
@@ -360,16 +366,19 @@ __global__ __launch_bounds__(128 * WM) void k_gemm_nt_split(const float* __restr
           if (LO) al[4 * q + c] = (_Float16)(v - (float)h);
         }
 #endif
+      // small terms first - per accumulator al*bh, ah*bl, ah*bh, as ever (the same bits) - issued pass by pass, so that
+      // consecutive MFMAs write different accumulators and none waits for its predecessor's result
+      if (LO) {
 #pragma unroll
-      for (int b = 0; b < TN; ++b) {             // small terms first
-        const half8 bh = __builtin_bit_cast(half8, fh[s][b]);
-        if (LO) {
-          const half8 bl = __builtin_bit_cast(half8, fl[s][b]);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
-        }
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+        for (int b = 0; b < TN; ++b)
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(half8, fh[s][b]), acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, fl[s][b]), acc[b], 0, 0, 0);
       }
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, fh[s][b]), acc[b], 0, 0, 0);
     }
   };
   RGCN_STAMP(1);
@@ -1060,15 +1069,19 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
   if (!r1.slots) { r1 = r2; r2 = amax_ref{nullptr, 0}; a1_mul = 1.f; }   // the kernels read r1 unconditionally
   if (kseg <= 0 || kseg % BK != 0) tile_mask = nullptr;
   unsigned* amax_out = reinterpret_cast<unsigned*>(c_amax);
-#define RGCN_NT_LAUNCH(WM_, TN_, EPI_, LO_)                                                                          \
-  k_gemm_nt_split<WM_, TN_, EPI_, LO_><<<grid, 128 * WM_, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, \
-                                                                        bias, mask, C, M, N, tile_mask, kseg, amax_out, \
-                                                                        fin, out_scale)
-#define RGCN_NT_SPLIT(WM_, TN_, EPI_)        \
-  do {                                       \
-    if (half) RGCN_NT_LAUNCH(WM_, TN_, EPI_, false); \
-    else RGCN_NT_LAUNCH(WM_, TN_, EPI_, true);       \
+#define RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, LO_)                                                                     \
+  k_gemm_nt_split<WM_, WN_, TN_, EPI_, LO_><<<grid, 64 * WM_ * WN_, 0, stream>>>(                                     \
+      A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, C, M, N, tile_mask, kseg, amax_out, fin, out_scale)
+#define RGCN_NT_SPLIT_W(WM_, WN_, TN_, EPI_)             \
+  do {                                                   \
+    if (half) RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, false); \
+    else RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, true);       \
   } while (0)
+#define RGCN_NT_SPLIT(WM_, TN_, EPI_) RGCN_NT_SPLIT_W(WM_, 2, TN_, EPI_)   /* two wave columns: see the note below */
+  // (Round 3 also built WM x WN = 4 x 1 with TN = 4 - four waves of 32 rows x 128 columns, a 128 x 128 tile, one
+  // workgroup per CU: A read and split once per row, 112 KB of LDS traffic per k-tile round instead of 144 - and
+  // measured it 16 % SLOWER per k-tile (1.08 against 0.94 us, step 0.312 against 0.285 ms): at one wave per SIMD nothing
+  // hides the fragment reads and the MFMA latency.  profiles/r03_nt_loop_experiments.txt.)
   if (N <= 64) {
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
     if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 1, EPI_RELU);
@@ -1087,6 +1100,7 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
   }
 #undef RGCN_NT_LAUNCH
 #undef RGCN_NT_SPLIT
+#undef RGCN_NT_SPLIT_W
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
