@@ -148,7 +148,7 @@ struct hub_fin {
   int d, tiles;
 };
 
-template <int WM, int WN, int TN, int EPI, bool LO, bool PP = false>
+template <int WM, int WN, int TN, int EPI, bool LO>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __restrict__ A1, int K1,
                                                             const float* __restrict__ A2, int K2,
                                                             const __half* __restrict__ Bh,
@@ -382,115 +382,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
     }
   };
   RGCN_STAMP(1);
-  if constexpr (PP) {
-    // Ping-pong k loop (round 3).  In the loop above a k-tile round costs its wait / barrier / fragment-read / split /
-    // DMA-issue time PLUS its MFMA time (0.45 + 0.49 us: tools/mfma_f16_peak) - all waves of a CU reach each phase
-    // together and stay together, two workgroups per CU as well.  Here the eight waves of a 128-row workgroup are two
-    // groups of four (one wave per SIMD each) that are made to run HALF A ROUND APART: in every barrier interval one
-    // group multiplies the fragments it holds while the other reads, splits and stages - the matrix pipe of a SIMD
-    // works for one wave while its vector / LDS / address pipes work for the other.  Interval i: group 0 runs A(i / 2)
-    // for even i and B((i - 1) / 2) for odd i, group 1 runs A((i - 1) / 2) for odd i and B(i / 2 - 1) for even i
-    // (A = reads + split + DMA issue of a tile, B = its MFMAs).  Tile t is read in intervals 2t (group 0) and 2t + 1
-    // (group 1): every wave's share of it has landed before the barrier that opens interval 2t (each wave waits for
-    // its own DMAs in the interval before), and its ring slot is refilled (by tile t + 4 of the ring of four) only from
-    // interval 2t + 2 on.  Same operands into the same MFMAs in the same order: the same bits.
-    static_assert(WM == 4 && WN == 2 && D == 3, "ping-pong: 128-row workgroups, ring of four");
-    const int grp = __builtin_amdgcn_readfirstlane(wm >> 1);
-    f32x4 ph[2][TN], pl[2][TN];
-    half8 ah[2], al[2];
-    bool frag_first = true, in_a2 = false;       // the held fragments lie in A1 | the sums are already in A2's scale
-    auto wait_landed = [&]() {                   // own DMAs of tile ktq[0] are done (those of the tiles behind it may fly)
-      const int n = (ktq[1] < K ? 1 : 0) + (ktq[2] < K ? 1 : 0);
-      if (n == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-      else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    auto phase_a = [&]() {
-      frag_first = ktq[0] < K1;
-      const float sa = frag_first ? sa1 : sa2;
-      const unsigned buf = (unsigned)((t % NBUF) * BUF_BYTES);
-      f32x4 fa[2][2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s][0]) : "v"(a_addr[s][0] + buf));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s][1]) : "v"(a_addr[s][1] + buf));
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          asm volatile("ds_read_b128 %0, %1" : "=v"(ph[s][b]) : "v"(b_addr[b][s] + buf));
-          if (LO) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(pl[s][b]) : "v"(b_addr[b][s] + buf), "n"(B_BYTES));
-        }
-      }
-      const int kt_new = ktq[D - 1] < K ? next_kt(ktq[D - 1]) : K;
-      if (kt_new < K) stage(kt_new, (t + D) % NBUF);
-#pragma unroll
-      for (int j = 0; j + 1 < D; ++j) ktq[j] = ktq[j + 1];
-      ktq[D - 1] = kt_new;
-      ++t;
-      static_assert(TN == 2, "every fragment register is tied to the wait below");
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]),
-                                            "+v"(ph[0][0]), "+v"(ph[0][1]), "+v"(ph[1][0]), "+v"(ph[1][1]));
-      if (LO) asm volatile("" : "+v"(pl[0][0]), "+v"(pl[0][1]), "+v"(pl[1][0]), "+v"(pl[1][1]));
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float v = fa[s][q][c] * sa;
-            const _Float16 h = (_Float16)v;
-            ah[s][4 * q + c] = h;
-            if (LO) al[s][4 * q + c] = (_Float16)(v - (float)h);
-          }
-    };
-    auto phase_b = [&]() {
-      if (__builtin_amdgcn_readfirstlane((int)(K2 > 0 && !frag_first && !in_a2))) {   // sums so far -> A2's scale, once
-        asm volatile("" ::: "memory");             // (a real branch, not a select over every accumulator)
-        const float down = pow2f(-ea1);
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[b][r] = acc[b][r] * down * sa2;
-      }
-      in_a2 = in_a2 || !frag_first;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (LO) {
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s], __builtin_bit_cast(half8, ph[s][b]), acc[b], 0, 0, 0);
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], __builtin_bit_cast(half8, pl[s][b]), acc[b], 0, 0, 0);
-        }
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s], __builtin_bit_cast(half8, ph[s][b]), acc[b], 0, 0, 0);
-      }
-    };
-    auto barrier = [&]() {                       // nothing is scheduled across an interval boundary
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    wait_landed();
-    barrier();
-    if (grp == 0) phase_a();                     // interval 0
-    barrier();
-    while (true) {
-      if (grp == 0) phase_b();                   // odd interval
-      else phase_a();
-      wait_landed();                             // the next tile's own DMAs, before the barrier that lets group 0 read it
-      const bool more = ktq[0] < K;              // (the same in both groups here)
-      barrier();
-      if (grp == 0) {                            // even interval
-        if (more) phase_a();
-      } else {
-        phase_b();
-      }
-      barrier();
-      if (!more) break;
-    }
-  } else {
   while (ktq[0] < K1) k_tile(sa1);
   if (K2 > 0) {                                  // sums so far -> A2's scale (two exact power-of-two factors)
     const float down = pow2f(-ea1);
@@ -499,7 +390,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][r] = acc[b][r] * down * sa2;
     while (ktq[0] < K) k_tile(sa2);
-  }
   }
 
   RGCN_STAMP(2);
@@ -1192,23 +1082,11 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
   // workgroup per CU: A read and split once per row, 112 KB of LDS traffic per k-tile round instead of 144 - and
   // measured it 16 % SLOWER per k-tile (1.08 against 0.94 us, step 0.312 against 0.285 ms): at one wave per SIMD nothing
   // hides the fragment reads and the MFMA latency.  profiles/r03_nt_loop_experiments.txt.)
-  // RGCN_NT_PP=1: the ping-pong k loop (128-row workgroups in two wave groups half a round apart) where no hub rows
-  // are left to this launch
-  static const bool pingpong = [] {
-    const char* e = getenv("RGCN_NT_PP");
-    return e && e[0] == '1';
-  }();
-  if (pingpong && N > 64 && !fin.ptr) {
-    dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)ceil_div64(N, 128));
-#define RGCN_NT_PP_LAUNCH(EPI_, LO_)                                                                                  \
-  k_gemm_nt_split<4, 2, 2, EPI_, LO_, true><<<grid, 512, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2,  \
-                                                                        bias, mask, C, M, N, tile_mask, kseg,          \
-                                                                        amax_out, fin, out_scale)
-    if (epi == EPI_RELU) { if (half) RGCN_NT_PP_LAUNCH(EPI_RELU, false); else RGCN_NT_PP_LAUNCH(EPI_RELU, true); }
-    else if (epi == EPI_MASK) { if (half) RGCN_NT_PP_LAUNCH(EPI_MASK, false); else RGCN_NT_PP_LAUNCH(EPI_MASK, true); }
-    else { if (half) RGCN_NT_PP_LAUNCH(EPI_NONE, false); else RGCN_NT_PP_LAUNCH(EPI_NONE, true); }
-#undef RGCN_NT_PP_LAUNCH
-  } else if (N <= 64) {
+  // (Round 3 also built a ping-pong k loop for the 128-row workgroup - its eight waves as two groups half a round
+  // apart, one multiplying while the other reads, splits and stages; commit "NT: ping-pong k loop" - bit-identical and
+  // SLOWER, 1.26 us per k-tile against 0.99 in lockstep and 0.94 for two 64-row workgroups: the read / split / stage
+  // phase of four waves alone takes ~0.6 us, longer than the 0.25 us of MFMAs it was meant to hide behind.)
+  if (N <= 64) {
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
     if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 1, EPI_RELU);
     else if (epi == EPI_MASK) RGCN_NT_SPLIT(2, 1, EPI_MASK);
