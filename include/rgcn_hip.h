@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 21
+#define RGCN_ABI_VERSION 22
 
 enum {
   RGCN_OK = 0,
@@ -431,15 +431,17 @@ int rgcn_index_error_fetch(int* host_flag, void* stream);
 /* Backward, DETERMINISTIC: grad_h[hi(b), :] = sum over the samples b' with hi(b') == hi(b) of gs[b'] * r * t,
  * etc.  Duplicates in head / tail / relation ids are legal and frequent; no float atomics are used - every row
  * is summed by one wave in sample order (embedding rows: the row's first occurrence adds all of them; the
- * relation table: a fixed two-level tree over 256-sample segments), so two runs give the same bits.
- * Rows reached through an index vector are WRITTEN (the caller zeroes the rows nobody touches); a NULL index
- * writes row b directly.  grad_h == grad_t (head and tail gathered from one table) is one key space.  Any
- * grad pointer may be NULL.  workspace: distmult_bwd_workspace_bytes(batch, d, r_idx ? r_rows : 0). */
+ * relation table: a fixed two-level tree over segments of >= 64 samples), so two runs give the same bits.
+ * Rows reached through an index vector are WRITTEN; the rows nobody touches must read zero afterwards:
+ * zero_tables != 0 - the first launch clears the indexed head / tail tables itself (all h_rows x d, t_rows x d
+ * floats; extra workgroups of that launch, no fill launch of the caller's), zero_tables == 0 - the caller has
+ * zeroed them.  A NULL index writes row b directly.  grad_h == grad_t (head and tail gathered from one table) is
+ * one key space.  Any grad pointer may be NULL.  workspace: distmult_bwd_workspace_bytes(batch, d, r_idx ? r_rows : 0). */
 size_t distmult_bwd_workspace_bytes(int64_t batch, int64_t d, int64_t r_rows);
 int distmult_bwd(const float* grad_scores, const float* h, const int64_t* h_idx, int64_t h_rows, const float* t,
                  const int64_t* t_idx, int64_t t_rows, const float* r, const int64_t* r_idx, int64_t r_rows,
                  int64_t batch, int64_t d, float* grad_h, float* grad_t, float* grad_r, void* workspace,
-                 size_t workspace_bytes, void* stream);
+                 size_t workspace_bytes, int zero_tables, void* stream);
 
 /* The head fused with the training loss (SURVEY section 8f "next" row 1; reference
  * `self.criterion = nn.BCEWithLogitsLoss()` src/train.py:139 applied to the scores at
@@ -454,7 +456,8 @@ int distmult_bce_fwd(const float* h, const int64_t* h_idx, int64_t h_rows, const
 int distmult_bce_bwd(const float* grad_mean_loss, const float* scores, const float* labels, const float* h,
                      const int64_t* h_idx, int64_t h_rows, const float* t, const int64_t* t_idx, int64_t t_rows,
                      const float* r, const int64_t* r_idx, int64_t r_rows, int64_t batch, int64_t d, float* grad_h,
-                     float* grad_t, float* grad_r, void* workspace, size_t workspace_bytes, void* stream);
+                     float* grad_t, float* grad_r, void* workspace, size_t workspace_bytes, int zero_tables,
+                     void* stream);
 
 /* The step's bookkeeping around that loss in ONE launch (src/train.py:300, 321-326: the mean of BCEWithLogitsLoss,
  * `predictions = sigmoid(scores) > 0.5`, `correct += (predictions == labels).sum()`, `total_loss += loss.item() * n` -

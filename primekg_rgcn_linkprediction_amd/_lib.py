@@ -13,7 +13,7 @@ from ctypes import c_float, POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -129,14 +129,14 @@ PROTOTYPES = {
     "distmult_rank_tails": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P]),
     "distmult_bce_reduce": (c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _I64, _P]),
     "distmult_score_all_tails": (c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _I64, _P, _P, _P]),
-    "distmult_bwd": (c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, c_size_t, _P]),
+    "distmult_bwd": (c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, c_size_t, c_int, _P]),
     "rgcn_adam_workspace_bytes": (c_size_t, [c_int, _P]),
     "rgcn_adam_clip_step": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int,
                                     c_float, _P, _P, c_size_t, _P]),
     "rgcn_sample_batch": (c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "distmult_bce_fwd": (c_int, [_P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _P, _P, _P]),
     "distmult_bce_bwd": (c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P,
-                                 c_size_t, _P]),
+                                 c_size_t, c_int, _P]),
 }
 
 _lib = None

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void k_distmult_fwd(const float* __restri
 //      64 per step, one ballot each); a slot that finds an equal key BEFORE itself retires; the first
 //      occurrence of a row adds the workspace rows of all its occurrences in slot order, eight loads in
 //      flight, and writes the row once.  Head and tail slots of one table (grad_h == grad_t) are one key
-//      space.  The caller zeroes the rows nobody touches.
+//      space.  The rows nobody touches: cleared by riders of launch 1 (zero_tables) or by the caller.
 //   3. k_segment_partials / k_segment_combine: the relation table (few rows, hundreds of occurrences
 //      each) as a fixed two-level tree: one wave per (row, segment of >= 64 samples) adds its occurrences in
 //      order, one wave per row adds the segments in order.
@@ -89,7 +89,17 @@ __global__ __launch_bounds__(kThreads) void k_distmult_contrib(
     const float* __restrict__ t, const int64_t* __restrict__ ti, int64_t t_rows, const float* __restrict__ r,
     const int64_t* __restrict__ ri, int64_t r_rows, int64_t B, int d, float* __restrict__ out_h,
     float* __restrict__ out_t, float* __restrict__ out_r, int32_t* __restrict__ key_h, int32_t* __restrict__ key_t,
-    int32_t* __restrict__ key_r, const float* __restrict__ scores = nullptr, const float* __restrict__ labels = nullptr) {
+    int32_t* __restrict__ key_r, const float* __restrict__ scores, const float* __restrict__ labels, int work_blocks,
+    float* __restrict__ zero_a, int64_t zero_a_quads, float* __restrict__ zero_b, int64_t zero_b_quads) {
+  if ((int)blockIdx.x >= work_blocks) {          // riders: zero the gradient tables the scatter launch writes rows into
+    const int64_t stride = (int64_t)(gridDim.x - work_blocks) * kThreads;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t q = (int64_t)((int)blockIdx.x - work_blocks) * kThreads + threadIdx.x; q < zero_a_quads + zero_b_quads; q += stride) {
+      if (q < zero_a_quads) reinterpret_cast<float4*>(zero_a)[q] = z;
+      else reinterpret_cast<float4*>(zero_b)[q - zero_a_quads] = z;
+    }
+    return;
+  }
   const int64_t b = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G;
   const int gl = threadIdx.x % G;
   if (b >= B) return;
@@ -358,7 +368,7 @@ template <bool BCE>
 int bwd_impl(const float* gs, const float* scores, const float* labels, const float* h, const int64_t* h_idx,
              int64_t h_rows, const float* t, const int64_t* t_idx, int64_t t_rows, const float* r, const int64_t* r_idx,
              int64_t r_rows, int64_t batch, int64_t d, float* grad_h, float* grad_t, float* grad_r, void* workspace,
-             size_t workspace_bytes, hipStream_t stream) {
+             size_t workspace_bytes, int zero_tables, hipStream_t stream) {
   if (batch < 0 || d <= 0 || (d & 3) || h_rows < 0 || t_rows < 0 || r_rows < 0) return RGCN_ERR_ARG;
   if (batch == 0) return RGCN_OK;
   if (!gs || !h || !t || !r) return RGCN_ERR_ARG;
@@ -377,11 +387,20 @@ int bwd_impl(const float* gs, const float* scores, const float* labels, const fl
   float* out_r = grad_r ? (r_idx ? cr : grad_r) : nullptr;
   const int g = pick_group(d);
   const unsigned grid = (unsigned)ceil_div64(batch, kThreads / g);
-  DISPATCH_G(g, (k_distmult_contrib<G, BCE><<<grid, kThreads, 0, stream>>>(
+  const bool sh = grad_h && h_idx, st = grad_t && t_idx;
+  // zero_tables: the tables the scatter below writes rows into are cleared by riders of this launch (the relation
+  // table is written whole by its tree)
+  float *za = nullptr, *zb = nullptr;
+  int64_t zaq = 0, zbq = 0;
+  if (zero_tables) {
+    if (sh) { za = grad_h; zaq = h_rows * d / 4; }
+    if (st && !(sh && grad_h == grad_t)) { zb = grad_t; zbq = t_rows * d / 4; }
+  }
+  const unsigned riders = (zaq + zbq) > 0 ? (unsigned)std::min<int64_t>(1024, ceil_div64(zaq + zbq, 4 * kThreads)) : 0u;
+  DISPATCH_G(g, (k_distmult_contrib<G, BCE><<<grid + riders, kThreads, 0, stream>>>(
                     gs, h, h_idx, h_rows, t, t_idx, t_rows, r, r_idx, r_rows, batch, (int)d, out_h, out_t, out_r,
                     (grad_h && h_idx) ? kh : nullptr, (grad_t && t_idx) ? kt : nullptr, (grad_r && r_idx) ? kr : nullptr,
-                    scores, labels)));
-  const bool sh = grad_h && h_idx, st = grad_t && t_idx;
+                    scores, labels, (int)grid, za, zaq, zb, zbq)));
   auto scatter = [&](const int32_t* k, int S, const float* rows, float* out) {
     const unsigned sg = (unsigned)ceil_div64(S, kScatterWaves);
     if (S <= kKeysInLds) k_scatter_rows<true><<<sg, 64 * kScatterWaves, 0, stream>>>(k, S, rows, (int)d, out);
@@ -414,18 +433,19 @@ extern "C" {
 int distmult_bwd(const float* grad_scores, const float* h, const int64_t* h_idx, int64_t h_rows, const float* t,
                  const int64_t* t_idx, int64_t t_rows, const float* r, const int64_t* r_idx, int64_t r_rows,
                  int64_t batch, int64_t d, float* grad_h, float* grad_t, float* grad_r, void* workspace,
-                 size_t workspace_bytes, void* stream_) {
+                 size_t workspace_bytes, int zero_tables, void* stream_) {
   return bwd_impl<false>(grad_scores, nullptr, nullptr, h, h_idx, h_rows, t, t_idx, t_rows, r, r_idx, r_rows, batch, d,
-                         grad_h, grad_t, grad_r, workspace, workspace_bytes, (hipStream_t)stream_);
+                         grad_h, grad_t, grad_r, workspace, workspace_bytes, zero_tables, (hipStream_t)stream_);
 }
 
 int distmult_bce_bwd(const float* grad_mean_loss, const float* scores, const float* labels, const float* h,
                      const int64_t* h_idx, int64_t h_rows, const float* t, const int64_t* t_idx, int64_t t_rows,
                      const float* r, const int64_t* r_idx, int64_t r_rows, int64_t batch, int64_t d, float* grad_h,
-                     float* grad_t, float* grad_r, void* workspace, size_t workspace_bytes, void* stream_) {
+                     float* grad_t, float* grad_r, void* workspace, size_t workspace_bytes, int zero_tables,
+                     void* stream_) {
   if (batch > 0 && (!scores || !labels)) return RGCN_ERR_ARG;
   return bwd_impl<true>(grad_mean_loss, scores, labels, h, h_idx, h_rows, t, t_idx, t_rows, r, r_idx, r_rows, batch, d,
-                        grad_h, grad_t, grad_r, workspace, workspace_bytes, (hipStream_t)stream_);
+                        grad_h, grad_t, grad_r, workspace, workspace_bytes, zero_tables, (hipStream_t)stream_);
 }
 
 size_t rgcn_segment_sum_workspace_bytes(int64_t batch, int64_t d, int64_t num_rows) {

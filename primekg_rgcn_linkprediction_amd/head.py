@@ -43,17 +43,15 @@ class _DistMultFunction(torch.autograd.Function):
         gs = gs.contiguous()
         need_h, _, need_t, _, need_r, _ = ctx.needs_input_grad
 
-        def buf(src, idx, need):
-            if not need:
-                return None
-            return torch.zeros_like(src) if idx is not None else torch.empty_like(src)
+        def buf(src, idx, need):                     # (an indexed table is cleared by the backward's first launch)
+            return torch.empty_like(src) if need else None
 
         gh = buf(h, h_idx, need_h)
         # head and tail gathered from one table: accumulate both into one buffer
         shared = ctx.same_ht and need_h and need_t and h_idx is not None and t_idx is not None
         gt = gh if shared else buf(t, t_idx, need_t)
         gr = buf(r, r_idx, need_r)
-        ops.distmult_bwd(gs, h, h_idx, t, t_idx, r, r_idx, ctx.batch, gh, gt, gr)
+        ops.distmult_bwd(gs, h, h_idx, t, t_idx, r, r_idx, ctx.batch, gh, gt, gr, zero_tables=True)
         if shared:
             # autograd sums the two returned grads of the same leaf: hand back the whole
             # accumulation once and an untouched None for the second slot
@@ -111,17 +109,15 @@ class _DistMultBCEFunction(torch.autograd.Function):
         if g_loss is None:                           # nothing downstream used the loss
             return (None,) * 8
 
-        def buf(src, idx, need):
-            if not need:
-                return None
-            return torch.zeros_like(src) if idx is not None else torch.empty_like(src)
+        def buf(src, idx, need):                     # (an indexed table is cleared by the backward's first launch)
+            return torch.empty_like(src) if need else None
 
         gh = buf(h, h_idx, need_h)
         shared = ctx.same_ht and need_h and need_t and h_idx is not None and t_idx is not None
         gt = gh if shared else buf(t, t_idx, need_t)
         gr = buf(r, r_idx, need_r)
         ops.distmult_bce_bwd(g_loss.reshape(1).contiguous(), scores, labels, h, h_idx, t, t_idx, r, r_idx,
-                             ctx.batch, gh, gt, gr)
+                             ctx.batch, gh, gt, gr, zero_tables=True)
         if shared:
             return gh, None, None, None, gr, None, None, None
         return gh, None, gt, None, gr, None, None, None

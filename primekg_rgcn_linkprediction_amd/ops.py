@@ -1519,9 +1519,9 @@ def _bwd_workspace(lib, batch: int, d: int, r, r_idx, device):
 
 
 def distmult_bce_bwd(grad_mean_loss, scores, labels, h, h_idx, t, t_idx, r, r_idx, batch: int,
-                     grad_h, grad_t, grad_r) -> None:
+                     grad_h, grad_t, grad_r, zero_tables: bool = False) -> None:
     """Backward of ``mean(bce_with_logits(distmult(...), labels))``; ``grad_mean_loss`` is a
-    one-element device tensor.  Writes like ``distmult_bwd``."""
+    one-element device tensor.  Writes like ``distmult_bwd`` (``zero_tables`` as there)."""
     _need_gpu("grad_mean_loss", grad_mean_loss, torch.float32)
     if grad_mean_loss.numel() != 1:
         raise ValueError("grad_mean_loss must hold one float")
@@ -1531,14 +1531,16 @@ def distmult_bce_bwd(grad_mean_loss, scores, labels, h, h_idx, t, t_idx, r, r_id
         ws, nbytes = _bwd_workspace(lib, batch, d, r, r_idx, h.device)
         rc = lib.distmult_bce_bwd(_ptr(grad_mean_loss), _ptr(scores), _ptr(labels), _ptr(h), _ptr(h_idx), h.size(0),
                                   _ptr(t), _ptr(t_idx), t.size(0), _ptr(r), _ptr(r_idx), r.size(0), batch, d,
-                                  _ptr(grad_h), _ptr(grad_t), _ptr(grad_r), _ptr(ws), nbytes, _stream())
+                                  _ptr(grad_h), _ptr(grad_t), _ptr(grad_r), _ptr(ws), nbytes, int(bool(zero_tables)),
+                                  _stream())
     _lib.check(rc, "distmult_bce_bwd")
 
 
-def distmult_bwd(gs, h, h_idx, t, t_idx, r, r_idx, batch: int, grad_h, grad_t, grad_r) -> None:
+def distmult_bwd(gs, h, h_idx, t, t_idx, r, r_idx, batch: int, grad_h, grad_t, grad_r, zero_tables: bool = False) -> None:
     """Deterministic backward (no float atomics; two runs give the same bits): rows reached through an
-    index vector are WRITTEN with the ordered sum of their samples' contributions - the caller provides
-    buffers that are zero in the rows nobody touches; ``grad_h is grad_t`` (one table) is one key space."""
+    index vector are WRITTEN with the ordered sum of their samples' contributions; the rows nobody touches are
+    cleared by the first launch itself (``zero_tables``: the buffers may then be ``torch.empty``) or must come
+    zeroed from the caller; ``grad_h is grad_t`` (one table) is one key space."""
     _need_gpu("grad_scores", gs, torch.float32)
     d = h.size(1)
     lib = _L()
@@ -1546,7 +1548,7 @@ def distmult_bwd(gs, h, h_idx, t, t_idx, r, r_idx, batch: int, grad_h, grad_t, g
         ws, nbytes = _bwd_workspace(lib, batch, d, r, r_idx, h.device)
         rc = lib.distmult_bwd(_ptr(gs), _ptr(h), _ptr(h_idx), h.size(0), _ptr(t), _ptr(t_idx), t.size(0), _ptr(r),
                               _ptr(r_idx), r.size(0), batch, d, _ptr(grad_h), _ptr(grad_t), _ptr(grad_r), _ptr(ws),
-                              nbytes, _stream())
+                              nbytes, int(bool(zero_tables)), _stream())
     _lib.check(rc, "distmult_bwd")
 
 

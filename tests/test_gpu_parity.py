@@ -651,6 +651,44 @@ def test_distmult_backward_counts_every_occurrence_once(shared):
     assert torch.equal(rel.grad.cpu(), cot.sum().view(1, 1).expand(1, d))
 
 
+@pytest.mark.parametrize("shared", [True, False])
+def test_distmult_backward_clears_its_tables_itself(shared):
+    """``zero_tables``: the first launch of the head's backward clears the indexed gradient tables (extra workgroups) -
+    buffers full of NaN give the bits of caller-zeroed ones, for one shared table and for two, in both entry points"""
+    dev = need_gpu()
+    gen = torch.Generator().manual_seed(5)
+    b, d, rows = 700, 128, 1000
+    emb, emb2, rel = (torch.randn(n, d, generator=gen).to(dev) for n in (rows, 333, 3))
+    tail_table = emb if shared else emb2
+    hi = torch.randint(0, rows, (b,), generator=gen).to(dev)
+    ti = torch.randint(0, tail_table.size(0), (b,), generator=gen).to(dev)
+    ri = torch.randint(0, 3, (b,), generator=gen).to(dev)
+    gs = torch.randn(b, generator=gen).to(dev)
+    labels = (torch.rand(b, generator=gen) > 0.5).float().to(dev)
+    scores = ops.distmult_fwd(emb, hi, tail_table, ti, rel, ri, b)
+    one = torch.ones(1, device=dev)
+
+    def run(zero_tables, fill):
+        out = []
+        for bce in (False, True):
+            gh = torch.full_like(emb, fill)
+            gt = gh if shared else torch.full_like(tail_table, fill)
+            gr = torch.full_like(rel, fill)
+            if bce:
+                ops.distmult_bce_bwd(one, scores, labels, emb, hi, tail_table, ti, rel, ri, b, gh, gt, gr,
+                                     zero_tables=zero_tables)
+            else:
+                ops.distmult_bwd(gs, emb, hi, tail_table, ti, rel, ri, b, gh, gt, gr, zero_tables=zero_tables)
+            out += [gh, gt, gr]
+        return out
+
+    want = run(False, 0.0)
+    got = run(True, float("nan"))
+    for a, w in zip(got, want):
+        assert torch.equal(a, w)
+    assert float(want[0].abs().sum()) > 0 and int((want[0].abs().sum(1) == 0).sum()) > 0     # touched and untouched rows exist
+
+
 def test_distmult_backward_is_deterministic_with_heavy_duplicates():
     """no float atomics in the head's backward: hub rows (one row the head of a third of the batch), head and tail
     from ONE table (one key space) or from two, relation table rows taking every sample - two runs give the

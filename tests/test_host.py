@@ -65,9 +65,9 @@ def test_null_handle_and_bad_args_return_codes_without_a_gpu():
     assert lib.rgcn_transform_fwd(None, None, None, None, None, 0, None, 10, 3, 8, 8, None, None) == A   # null operands
     assert lib.rgcn_transform_bwd_input(None, None, None, None, None, None, 10, 0, 8, 8, None, None) == A
     assert lib.rgcn_transform_bwd_params(None, None, None, None, 10, 3, 8, 8, None, None, None, None, 0, None) == A
-    assert lib.distmult_bwd(None, None, None, 1, None, None, 1, None, None, 1, 4, 8, None, None, None, None, 0, None) == E
+    assert lib.distmult_bwd(None, None, None, 1, None, None, 1, None, None, 1, 4, 8, None, None, None, None, 0, 0, None) == E
     assert lib.distmult_bce_fwd(None, None, 1, None, None, 1, None, None, 1, None, 4, 8, None, None, None) == E
-    assert lib.distmult_bce_bwd(None, None, None, None, None, 1, None, None, 1, None, None, 1, 4, 8, None, None, None, None, 0, None) == E
+    assert lib.distmult_bce_bwd(None, None, None, None, None, 1, None, None, 1, None, None, 1, 4, 8, None, None, None, None, 0, 0, None) == E
     assert lib.distmult_bce_fwd(None, None, 1, None, None, 1, None, None, 1, None, 0, 8, None, None, None) == _lib.RGCN_OK
     assert lib.distmult_rank_tails(None, None, None, None, 4, 100, 48, None, None) != _lib.RGCN_OK       # d % 32
     assert lib.rgcn_sample_batch(None, None, 10, None, None, 4, 1, 0, None, None, None, None, None, None) == E
