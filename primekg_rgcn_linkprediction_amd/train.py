@@ -269,11 +269,20 @@ class Trainer:
         loss_sum = torch.zeros((), device=self.device, dtype=torch.float64)
         correct = torch.zeros((), device=self.device, dtype=torch.int64)
         seen = 0
+        # The reference re-runs the encoder for every validation batch (train.py:389-395); in eval mode nothing it
+        # reads changes between the batches, so the node embeddings are computed ONCE here - the same rows - and every
+        # batch is the head's two launches (scores + loss, then mean / running sums).  Negatives: the reference's
+        # sampler on torch's RNG stream, as there.
+        fused = self._fused_bookkeeping and hasattr(self.model, "encoder") and hasattr(self.model, "decoder")
+        emb = self.model.encoder(self.full_edge_index, self.full_edge_type) if fused else None
         for head, tail, rel in self._batches(self.val_edge_index, self.val_edge_type, shuffle=False):
             heads, tails, rels, labels = self._with_negatives(head, tail, rel)
-            scores = self.model(self.full_edge_index, self.full_edge_type, heads, tails, rels)
-            loss_sum += self.criterion(scores, labels).double() * labels.numel()
-            correct += ((scores > 0) == (labels > 0.5)).sum()
+            if fused:
+                self.model.decoder.bce_loss(emb, heads, tails, rels, labels, stats=(loss_sum, correct, None, 0))
+            else:
+                scores = self.model(self.full_edge_index, self.full_edge_type, heads, tails, rels)
+                loss_sum += self.criterion(scores, labels).double() * labels.numel()
+                correct += ((scores > 0) == (labels > 0.5)).sum()
             seen += labels.numel()
         result = (loss_sum / max(seen, 1)).item(), correct.item() / max(seen, 1)
         ops.check_indices(self.device)

@@ -180,6 +180,26 @@ def test_short_run_learns_and_checkpoints(tmp_path):
 
 
 @pytest.mark.gpu
+def test_validate_with_one_encoder_pass_equals_the_reference_protocol(tmp_path, monkeypatch):
+    """``Trainer.validate`` computes the node embeddings once and scores every batch with the fused head; the reference
+    (train.py:389-395) re-runs the encoder per batch and applies ``BCEWithLogitsLoss`` - same negatives (torch's RNG
+    stream), same accuracy, the loss to float32 rounding"""
+    dev = need_gpu()
+    torch.manual_seed(3)
+    tr, va, full, _ = T.synthetic_data(num_edges=30000, seed=9)
+    args = _args(epochs=1, batch_size=512, output_dir=str(tmp_path), device="cuda")
+    trainer = T.Trainer(T.create_model(tr["num_nodes"], 3, args), tr, va, full, dev, args)
+    trainer.train_epoch(max_steps=3)
+    torch.manual_seed(77)
+    loss_fused, acc_fused = trainer.validate()
+    monkeypatch.setattr(T.Trainer, "_fused_bookkeeping", property(lambda self: False))
+    torch.manual_seed(77)
+    loss_ref, acc_ref = trainer.validate()
+    assert acc_fused == acc_ref and 0.3 < acc_ref < 1.0
+    assert abs(loss_fused - loss_ref) <= 2e-6 * max(1.0, abs(loss_ref))
+
+
+@pytest.mark.gpu
 def test_fp16_gather_training_reaches_the_same_auc(tmp_path):
     """configs[4] second half, at C2's size (849,456 edge columns, one epoch = 830 optimizer steps): the run
     with fp16 feature tables, fp16 forward transforms AND one-pass fp16 gradient GEMMs lands within +-0.005
