@@ -1,0 +1,109 @@
+"""Fuzz of the two-layer encoder against the float64 oracle (not a test: a one-off search for shapes the fixed test
+cases miss).  Random graphs with the features that break index arithmetic - empty relations, isolated nodes, self
+loops, duplicate edges, one hub, node counts around the 32 / 64 / 128-row tile sizes, relation counts up to 33 (the
+relation-skipping masks hold 32), widths 32 ... 256 - each through the three routes of tests/test_gpu_parity.py's
+``_encoder_vs_oracle`` (gates: forward 1e-5, gradients 1e-4 of their largest entry) and then four more steps of
+``rgcn_encoder2`` on fresh inputs, so that the recorded (native) replay of the pass is compared with the oracle too.
+
+    python tools/fuzz_encoder.py [cases] [seed]
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_parity as P  # noqa: E402
+from oracle import rgcn_oracle as O  # noqa: E402
+from primekg_rgcn_linkprediction_amd import RGCNConv, rgcn_encoder2  # noqa: E402
+
+dev = torch.device("cuda:0")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+gen = torch.Generator().manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
+
+
+def rnd(lo, hi):
+    return int(torch.randint(lo, hi + 1, (1,), generator=gen))
+
+
+def graph(n, e, r):
+    src = torch.randint(0, n, (e,), generator=gen)
+    dst = torch.randint(0, n, (e,), generator=gen)
+    et = torch.randint(0, r, (e,), generator=gen)
+    kind = rnd(0, 5)
+    if kind == 0 and r > 1:                       # an empty relation (and the last one, if there are three)
+        et[et == rnd(0, r - 1)] = 0
+        if r > 2:
+            et[et == r - 1] = 1
+    elif kind == 1:                               # a hub: a third of the edges end in one node, many start in another
+        dst[torch.rand(e, generator=gen) < 0.33] = rnd(0, n - 1)
+        src[torch.rand(e, generator=gen) < 0.2] = rnd(0, n - 1)
+    elif kind == 2:                               # self loops and duplicates
+        k = e // 4
+        src[:k] = dst[:k]
+        src[k:2 * k], dst[k:2 * k], et[k:2 * k] = src[:k], dst[:k], et[:k]
+    elif kind == 3:                               # the upper half of the nodes is isolated
+        src, dst = src % max(1, n // 2), dst % max(1, n // 2)
+    elif kind == 4 and r > 1:                     # relations live on disjoint row ranges (tile masks with holes)
+        dst = (dst % max(1, n // r)) + et * max(1, n // r)
+        dst = dst.clamp(max=n - 1)
+    return torch.stack([src, dst]), et, kind
+
+
+t0 = time.time()
+worst = {"fwd": 0.0, "grad": 0.0}
+for case in range(cases):
+    n = [rnd(1, 40), rnd(60, 70), rnd(120, 135), rnd(250, 260), rnd(1000, 3000), rnd(5000, 20000)][rnd(0, 5)]
+    r = [1, 2, 3, 5, 16, 33][rnd(0, 5)]
+    e = [0, rnd(1, 50), rnd(100, 2000), rnd(5000, 60000)][rnd(0, 3)] if n < 1000 else rnd(1000, 120000)
+    dims = [(32, 32, 32), (64, 128, 128), (64, 64, 32), (128, 128, 64), (32, 96, 160), (64, 256, 256), (96, 32, 64)][rnd(0, 6)]
+    if r == 33 and max(dims) > 128:
+        dims = (64, 128, 128)
+    ei, et, kind = graph(n, e, r)
+    label = f"case {case}: n={n} e={e} r={r} dims={dims} kind={kind}"
+    try:
+        note = ""
+        if e > 0:
+            P._check_bucket(dev, ei, et, n, r)       # bucketing: bit-equal to the oracle's stable sort, both directions
+        try:
+            P._encoder_vs_oracle(dev, ei, et, n, r, dims, seed=case)
+        except AssertionError as exc:
+            # every gate of that helper carries a message except its last line, the BITWISE equality of the three
+            # routes - which holds while they take the same kernels; conv2 with d_out >= 2 d_in takes the
+            # transform-first input gradient as a layer of its own and gather-first inside rgcn_encoder2
+            if str(exc) or not (dims[2] >= 2 * dims[1]):
+                raise
+            note = "  (routes differ in bits: conv2's input gradient is transform-first as a single layer)"
+        # the recorded pass: four more steps on fresh inputs, each against float64
+        torch.manual_seed(1000 + case)
+        convs = [RGCNConv(dims[0], dims[1], r).to(dev), RGCNConv(dims[1], dims[2], r).to(dev)]
+        eid, etd = ei.to(dev), et.to(dev)
+        for step in range(4):
+            emb = torch.randn(n, dims[0]) * (0.5 + step)
+            cot = torch.randn(n, dims[2])
+            e_gpu = emb.to(dev).requires_grad_(True)
+            for c in convs:
+                c.zero_grad(set_to_none=True)
+            out = rgcn_encoder2(e_gpu, eid, etd, convs[0], convs[1])
+            (out * cot.to(dev)).sum().backward()
+            with torch.no_grad():
+                mask = (convs[0](emb.to(dev), eid, etd, activation="relu") > 0).cpu()
+            p64 = [{k: v.detach().cpu() for k, v in c.named_parameters()} for c in convs]
+            f64 = O.encoder_explicit_f64(emb, p64[0], p64[1], ei, et, cot, relu_mask=mask)
+            scale = max(1.0, float(f64["out"].abs().max()))
+            fe = float((out.detach().double().cpu() - f64["out"]).abs().max()) / scale
+            ge = float(P.rel_err(e_gpu.grad, f64["grads"]["emb"]))
+            worst["fwd"], worst["grad"] = max(worst["fwd"], fe), max(worst["grad"], ge)
+            assert fe <= 1e-5, f"forward {fe:.2e} at step {step}"
+            assert ge <= 1e-4, f"grad_emb {ge:.2e} at step {step}"
+            for name, c in zip(("conv1", "conv2"), convs):
+                for k, v in c.named_parameters():
+                    pe = float(P.rel_err(v.grad, f64["grads"][f"{name}.{k}"]))
+                    assert pe <= 1e-4, f"{name}.{k} {pe:.2e} at step {step}"
+        print(f"ok   {label}{note}", flush=True)
+    except Exception as exc:  # noqa: BLE001
+        print(f"FAIL {label}: {type(exc).__name__}: {exc}", flush=True)
+print(f"{cases} cases in {time.time() - t0:.0f} s; worst forward {worst['fwd']:.2e} (relative to max(1, |out|)), worst grad_emb {worst['grad']:.2e}")
