@@ -63,13 +63,14 @@ for case in range(cases):
     if r == 33 and max(dims) > 128:
         dims = (64, 128, 128)
     ei, et, kind = graph(n, e, r)
-    label = f"case {case}: n={n} e={e} r={r} dims={dims} kind={kind}"
+    bases = [None, None, 2, 4][rnd(0, 3)]         # basis-decomposed weights (configs[2]) in half of the cases
+    label = f"case {case}: n={n} e={e} r={r} dims={dims} kind={kind} num_bases={bases}"
     try:
         note = ""
         if e > 0:
             P._check_bucket(dev, ei, et, n, r)       # bucketing: bit-equal to the oracle's stable sort, both directions
         try:
-            P._encoder_vs_oracle(dev, ei, et, n, r, dims, seed=case)
+            P._encoder_vs_oracle(dev, ei, et, n, r, dims, num_bases=bases, seed=case)
         except AssertionError as exc:
             # every gate of that helper carries a message except its last line, the BITWISE equality of the three
             # routes - which holds while they take the same kernels; conv2 with d_out >= 2 d_in takes the
@@ -79,7 +80,7 @@ for case in range(cases):
             note = "  (routes differ in bits: conv2's input gradient is transform-first as a single layer)"
         # the recorded pass: four more steps on fresh inputs, each against float64
         torch.manual_seed(1000 + case)
-        convs = [RGCNConv(dims[0], dims[1], r).to(dev), RGCNConv(dims[1], dims[2], r).to(dev)]
+        convs = [RGCNConv(dims[0], dims[1], r, num_bases=bases).to(dev), RGCNConv(dims[1], dims[2], r, num_bases=bases).to(dev)]
         eid, etd = ei.to(dev), et.to(dev)
         for step in range(4):
             emb = torch.randn(n, dims[0]) * (0.5 + step)
