@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 22
+#define RGCN_ABI_VERSION 23
 
 enum {
   RGCN_OK = 0,
@@ -525,6 +525,20 @@ int distmult_rank_tails(const float* hr, const float* emb, const float* true_sco
 int distmult_score_all_tails(const float* head, const float* rel, const int64_t* rel_idx, int64_t num_relations,
                              const float* emb, int64_t batch, int64_t num_entities, int64_t d, float* hr, float* scores,
                              void* stream);
+
+/* Basis-decomposed relation weights (PyG RGCNConv with num_bases = B, BASELINE configs[2]:
+ * `weight = (comp @ weight.view(num_bases, -1)).view(num_relations, in_channels, out_channels)`).
+ * rgcn_basis_compose: weight[r, j] = sum_b comp[r, b] * basis[b, j], j over inner = in * out (a multiple of 4), b
+ * ascending.  rgcn_basis_compose_bwd: grad_basis[b, j] = sum_r comp[r, b] * grad_weight[r, j] and grad_comp[r, b] =
+ * sum_j grad_weight[r, j] * basis[b, j] - the latter as per-workgroup partial sums added in a fixed order (no float
+ * atomics: two runs give the same bits); either output may be NULL.  workspace: rgcn_basis_compose_bwd_workspace_bytes
+ * (needed for grad_comp only).  R * B <= 4096. */
+int rgcn_basis_compose(const float* comp, const float* basis, int64_t R, int64_t B, int64_t inner, float* weight,
+                       void* stream);
+size_t rgcn_basis_compose_bwd_workspace_bytes(int64_t R, int64_t B, int64_t inner);
+int rgcn_basis_compose_bwd(const float* grad_weight, const float* comp, const float* basis, int64_t R, int64_t B,
+                           int64_t inner, float* grad_comp, float* grad_basis, void* workspace, size_t workspace_bytes,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------
  * A recorded pass issued by ONE call.  The reference re-runs its encoder from Python for every 1,024-edge batch

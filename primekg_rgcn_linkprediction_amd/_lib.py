@@ -13,7 +13,7 @@ from ctypes import c_float, POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -127,6 +127,9 @@ PROTOTYPES = {
     "rgcn_segment_sum_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),
     "rgcn_segment_sum": (c_int, [_P, _P, _I64, _I64, _I64, _P, _P, c_size_t, _P]),
     "distmult_rank_tails": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _P, _P]),
+    "rgcn_basis_compose": (c_int, [_P, _P, _I64, _I64, _I64, _P, _P]),
+    "rgcn_basis_compose_bwd_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),
+    "rgcn_basis_compose_bwd": (c_int, [_P, _P, _P, _I64, _I64, _I64, _P, _P, _P, c_size_t, _P]),
     "distmult_bce_reduce": (c_int, [_P, _P, _P, _I64, _P, _P, _P, _P, _I64, _P]),
     "distmult_score_all_tails": (c_int, [_P, _P, _P, _I64, _P, _I64, _I64, _I64, _P, _P, _P]),
     "distmult_bwd": (c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, c_size_t, c_int, _P]),

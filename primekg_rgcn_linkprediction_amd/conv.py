@@ -43,24 +43,22 @@ def _table(x: Tensor, gather_dtype) -> Tensor:
 
 
 class _BasisCompose(torch.autograd.Function):
-    """``W[r] = sum_b comp[r, b] * basis[b]`` (PyG: ``(comp @ weight.view(B, -1)).view(R, in, out)``).
-    Plain torch ops, but the backward is spelled out: autograd's ``grad_comp = gW @ basis^T`` is a
-    [R, in*out] x [in*out, B] product with 12 outputs and K = 65,536, for which the GEMM library
-    picks a one-tile kernel (63 us per layer measured at hidden 256); a broadcast multiply and a
-    row sum do it in a few microseconds."""
+    """``W[r] = sum_b comp[r, b] * basis[b]`` (PyG: ``(comp @ weight.view(B, -1)).view(R, in, out)``; SURVEY row A5,
+    BASELINE configs[2]).  One elementwise launch forward; the backward is ``grad_basis = comp^T gW`` and the R * B dot
+    products ``grad_comp = gW basis^T`` of length in * out as two launches with a fixed summation order
+    (``csrc/rgcn_basis.hip``) - through round 2 torch ops: per step of configs[2] four small library GEMMs, two
+    broadcast multiplies and two row sums."""
 
     @staticmethod
     def forward(ctx, comp: Tensor, basis: Tensor) -> Tensor:
+        comp, basis = comp.contiguous(), basis.contiguous()
         ctx.save_for_backward(comp, basis)
-        return (comp @ basis.view(basis.size(0), -1)).view(comp.size(0), basis.size(1), basis.size(2))
+        return ops.basis_compose(comp, basis)
 
     @staticmethod
     def backward(ctx, gw: Tensor):
         comp, basis = ctx.saved_tensors
-        gw2, b2 = gw.reshape(comp.size(0), -1), basis.view(basis.size(0), -1)
-        g_comp = (gw2.unsqueeze(1) * b2.unsqueeze(0)).sum(-1) if ctx.needs_input_grad[0] else None
-        g_basis = (comp.t() @ gw2).view_as(basis) if ctx.needs_input_grad[1] else None
-        return g_comp, g_basis
+        return ops.basis_compose_bwd(gw.contiguous(), comp, basis, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
 
 
 class _Scales:

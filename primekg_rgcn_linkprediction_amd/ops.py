@@ -1486,6 +1486,44 @@ def distmult_bce_fwd(h, h_idx, t, t_idx, r, r_idx, labels, batch: int):
     return scores, loss
 
 
+def basis_compose(comp: torch.Tensor, basis: torch.Tensor) -> torch.Tensor:
+    """``(comp @ basis.view(B, -1)).view(R, d_in, d_out)`` - PyG's basis-decomposed relation weights (``rgcn_basis_compose``)."""
+    _need_gpu("comp", comp, torch.float32)
+    _need_gpu("basis", basis, torch.float32)
+    if comp.dim() != 2 or basis.dim() != 3 or comp.size(1) != basis.size(0):
+        raise ValueError("comp [R, B] and basis [B, d_in, d_out] expected")
+    r, b = comp.shape
+    inner = basis.size(1) * basis.size(2)
+    lib = _L()
+    with _on(comp.device):
+        out = _empty((r, basis.size(1), basis.size(2)), dtype=torch.float32, device=comp.device)
+        rc = lib.rgcn_basis_compose(_ptr(comp), _ptr(basis), r, b, inner, _ptr(out), _stream())
+    _lib.check(rc, "rgcn_basis_compose")
+    return out
+
+
+def basis_compose_bwd(grad_weight: torch.Tensor, comp: torch.Tensor, basis: torch.Tensor, need_comp: bool = True,
+                      need_basis: bool = True):
+    """-> (grad_comp | None, grad_basis | None) of ``basis_compose``; deterministic (``rgcn_basis_compose_bwd``)."""
+    _need_gpu("grad_weight", grad_weight, torch.float32)
+    _need_gpu("comp", comp, torch.float32)
+    _need_gpu("basis", basis, torch.float32)
+    r, b = comp.shape
+    inner = basis.size(1) * basis.size(2)
+    if grad_weight.numel() != r * inner:
+        raise ValueError("grad_weight must be [R, d_in, d_out]")
+    lib = _L()
+    with _on(comp.device):
+        g_comp = _empty((r, b), dtype=torch.float32, device=comp.device) if need_comp else None
+        g_basis = _empty(tuple(basis.shape), dtype=torch.float32, device=comp.device) if need_basis else None
+        nbytes = lib.rgcn_basis_compose_bwd_workspace_bytes(r, b, inner) if need_comp else 0
+        ws = _workspace(nbytes, comp.device) if need_comp else None
+        rc = lib.rgcn_basis_compose_bwd(_ptr(grad_weight), _ptr(comp), _ptr(basis), r, b, inner, _ptr(g_comp), _ptr(g_basis),
+                                        _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "rgcn_basis_compose_bwd")
+    return g_comp, g_basis
+
+
 def distmult_bce_reduce(loss: torch.Tensor, scores: torch.Tensor, labels: torch.Tensor, loss_sum=None, correct=None,
                         cursor=None, cursor_add: int = 0) -> torch.Tensor:
     """-> ``mean(loss)`` as a one-element tensor, in ONE launch together with the epoch's device-resident running sums

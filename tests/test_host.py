@@ -96,7 +96,8 @@ def test_rgcnconv_parameters_and_init():
     b = RGCNConv(in_channels=64, out_channels=256, num_relations=3, num_bases=4)
     assert b.weight.shape == (4, 64, 256) and b.comp.shape == (3, 4)
     assert [n for n, _ in b.named_parameters()] == ["weight", "comp", "root", "bias"]
-    assert b.effective_weight().shape == (3, 64, 256)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):          # the basis composition is a kernel too
+        b.effective_weight()
     nb = RGCNConv(8, 8, 2, root_weight=False, bias=False)
     assert nb.root is None and nb.bias is None
 
