@@ -560,6 +560,10 @@ def main():
             "frac": domg["tflops"] / F32_MATRIX_PEAK_TF,
             "executed_tflops": executed / (domg["avg_us"] * 1e-6) / 1e12,
             "executed_peak": F16_MATRIX_PEAK_TF if domg["arithmetic"] in ("split", "f16") else F32_MATRIX_PEAK_TF,
+            # what a register-fed loop of that instruction sustains on this chip (tools/mfma_f16_peak.hip, a committed
+            # measurement, not part of this run): 20.5 ns per v_mfma_f32_32x32x16_f16 and SIMD, ~1.56 GHz under matrix load
+            "executed_peak_sustained_measured": 1640.0 if domg["arithmetic"] in ("split", "f16") else None,
+            "executed_peak_sustained_source": "profiles/r03_mfma_f16_peak.txt",
             "note": ("flops = 2 M K N of the fp32 contraction the caller asked for, against the fp32 matrix peak; "
                      "in split precision the call executes 3 fp16 MFMA passes (`executed_tflops`, against the dense fp16 "
                      "peak) and its bracket includes the operand scan and the weight split launches"),
