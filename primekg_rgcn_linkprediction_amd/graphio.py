@@ -19,7 +19,7 @@ quirks, which the rest of the pipeline depends on:
 from __future__ import annotations
 
 from pathlib import Path
-from typing import Dict, List, Tuple
+from typing import Dict, Tuple
 
 import numpy as np
 import torch

@@ -1,5 +1,5 @@
 """Diagnostic: time the transform kernels in isolation (back-to-back launches, HIP events)."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from primekg_rgcn_linkprediction_amd import ops
