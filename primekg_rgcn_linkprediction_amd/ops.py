@@ -1711,6 +1711,15 @@ def materialize(t):
     return t.tensor() if isinstance(t, Lazy) else t
 
 
+def _signature(t):
+    """(dtype, shape, device index) of a pass's input - a tensor or the arena view of an earlier pass - or None"""
+    if t is None:
+        return None
+    if isinstance(t, Lazy):
+        return (t.dtype, tuple(t.shape), t.arena.device.index)
+    return (t.dtype, tuple(t.shape), t.device.index if t.is_cuda else -1)
+
+
 class _Proxy:
     def __init__(self, rec):
         self._rec, self._real = rec, _lib.load()
@@ -1750,6 +1759,7 @@ class _Recorder:
             self.base = self.arena.data_ptr()
             self.inputs = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) if t is not None else None
                            for t in inputs]
+            self.input_signature = [_signature(t) for t in inputs]
             self.proxy = _Proxy(self)
 
     def alloc(self, shape, dtype, device):
@@ -1856,6 +1866,17 @@ class _Plan:
         self.arena_bytes, self.device = rec.arena_bytes, rec.device
         self.outputs = outputs                               # per output: ("arena", off, shape, dtype) | ("input", k) | None
         self.num_jobs = len(rec.jobs)
+        # what the recorded addresses stand for: a later call whose inputs differ in type, shape or place must not be
+        # replayed (the wrappers would have refused it; the native list would read the wrong bytes)
+        self.signature = rec.input_signature
+
+    def matches(self, inputs) -> bool:
+        if len(inputs) != len(self.signature):
+            return False
+        for t, sig in zip(inputs, self.signature):
+            if _signature(t) != sig:
+                return False
+        return True
 
     def run(self, inputs, want, zero=False):
         """-> list of outputs: tensors for the positions in `want`, Lazy for the rest"""
@@ -1898,7 +1919,9 @@ class Region:
         full_key = (self.name, key, GEMM_PRECISION)
         state = store.get(full_key)
         if isinstance(state, _Plan):
-            return state.run(tensors, want)
+            if state.matches(tensors):
+                return state.run(tensors, want)
+            return self._eager(tensors, static)              # (the wrappers say what is wrong with these inputs)
         if state == self.DISABLED or torch.cuda.is_current_stream_capturing():
             return self._eager(tensors, static)
         if any(isinstance(t, Lazy) for t in tensors):

@@ -1665,6 +1665,32 @@ def test_fused_input_gradient_is_bit_identical_to_gather_then_transform(n, e, r,
 
 
 @pytest.mark.gpu
+def test_a_recorded_pass_is_not_replayed_on_inputs_of_another_type():
+    """once a pass is issued natively, a call whose inputs differ from the recorded ones in dtype or device goes back
+    through the wrappers, which refuse it by name - the recorded launch list would read the wrong bytes (a float16 table
+    is half as long)"""
+    dev = need_gpu()
+    ei, et, n, r = synth.primekg_like(num_edges=40000, seed=3)
+    eid, etd = ei.to(dev), et.to(dev)
+    torch.manual_seed(3)
+    convs = [RGCNConv(64, 128, r).to(dev), RGCNConv(128, 128, r).to(dev)]
+    x = torch.randn(n, 64, device=dev)
+    with torch.no_grad():
+        outs = [rgcn_encoder2(x, eid, etd, convs[0], convs[1]) for _ in range(5)]      # plain, sizes, record, replay, replay
+    graph = ops.bucket(eid, etd, n, r)
+    assert any(isinstance(s, ops._Plan) for s in graph.__dict__.get("_regions", {}).values())
+    assert torch.equal(outs[-1], outs[0])
+    with torch.no_grad():
+        with pytest.raises(TypeError, match="float32"):
+            rgcn_encoder2(x.double(), eid, etd, convs[0], convs[1])
+        with pytest.raises(TypeError, match="float32"):
+            rgcn_encoder2(x.half(), eid, etd, convs[0], convs[1])
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            rgcn_encoder2(x.cpu(), eid, etd, convs[0], convs[1])
+        assert torch.equal(rgcn_encoder2(x, eid, etd, convs[0], convs[1]), outs[0])     # and the plan still serves the right call
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dims", [(64, 128, 128), (128, 128, 64)])
 def test_first_launch_riding_in_the_first_gather_changes_no_bit(dims, monkeypatch):
     """``rgcn_aggregate_prep``: max |x|, the cleared amax slots and both layers' split weight images as extra workgroups
