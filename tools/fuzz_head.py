@@ -62,7 +62,7 @@ for case in range(cases):
         if d % 4 == 0 and shared:
             loss, sc2 = dec.bce_loss(e, hi.to(dev), ti.to(dev), ri.to(dev), labels.to(dev))
             assert torch.equal(sc2, sc.detach())
-            assert abs(float(loss.detach()) - float(loss64.detach())) <= 2e-6 * max(1.0, abs(float(loss64))), "loss"
+            assert abs(float(loss.detach()) - float(loss64.detach())) <= 2e-6 * max(1.0, abs(float(loss64.detach()))), "loss"
             ((sc * cot.to(dev)).sum() + 3.0 * loss).backward()
             r_grad = r.grad + dec.relation_embeddings.weight.grad
         else:
