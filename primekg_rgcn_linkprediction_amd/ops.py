@@ -1716,8 +1716,8 @@ def _signature(t):
     if t is None:
         return None
     if isinstance(t, Lazy):
-        return (t.dtype, tuple(t.shape), t.arena.device.index)
-    return (t.dtype, tuple(t.shape), t.device.index if t.is_cuda else -1)
+        return (t.dtype, tuple(t.shape), t.arena.get_device())
+    return (t.dtype, tuple(t.shape), t.get_device())           # (-1 on the host)
 
 
 class _Proxy:
@@ -1871,10 +1871,21 @@ class _Plan:
         self.signature = rec.input_signature
 
     def matches(self, inputs) -> bool:
-        if len(inputs) != len(self.signature):
+        """the inputs of this call are what the recorded addresses stand for (a few attribute reads per input: this runs
+        on every replay)"""
+        sigs = self.signature
+        if len(inputs) != len(sigs):
             return False
-        for t, sig in zip(inputs, self.signature):
-            if _signature(t) != sig:
+        for t, sig in zip(inputs, sigs):
+            if t is None or sig is None:
+                if t is not None or sig is not None:
+                    return False
+                continue
+            dtype, shape, index = sig
+            if isinstance(t, Lazy):
+                if t.dtype is not dtype or t.shape != shape:
+                    return False
+            elif t.dtype is not dtype or t.shape != shape or t.get_device() != index:
                 return False
         return True
 
