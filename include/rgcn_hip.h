@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RGCN_ABI_VERSION 23
+#define RGCN_ABI_VERSION 24
 
 enum {
   RGCN_OK = 0,
@@ -129,6 +129,7 @@ typedef struct rgcn_slab_job {
   float* grad_weight;
   float* grad_root;
   float* grad_bias;
+  int32_t bias_splits; /* rows of bias_part (0: `splits`) - the plane kernels take grad_bias partials from elsewhere */
 } rgcn_slab_job;
 
 /* ------------------------------------------------------------------------------------
@@ -351,8 +352,32 @@ int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const floa
 int rgcn_transform_first_split(const float* g, const void* packed, int has_root, int64_t num_nodes,
                                int64_t num_relations, int64_t d_in, int64_t d_out, const float* g_amax, int half,
                                float* t_out, void* workspace, size_t workspace_bytes, void* stream);
+/* "Planes" (round 4): a tensor T[M][K] (K % 8 == 0) the split kernels would split in their loops, stored split: two
+ * DEVICE IEEE-fp16 images hi[M][K], lo[M][K] (row-major, K halves per row) with hi = fp16(T * 2^e), lo = fp16(T * 2^e
+ * - hi) under the power-of-two scale that puts amax * amax_mul into [2^14, 2^15) - the two numbers the kernels form in
+ * registers anyway, written once by whoever holds T in registers (the gather in its plane mode, an NT transform for
+ * the fp32 block it splits) instead of re-formed by every consumer.  rgcn_split_planes is the stand-alone producer
+ * (lo may be NULL: one-pass arithmetic reads hi only).  numel % 8 == 0. */
+int rgcn_split_planes(const float* src, int64_t numel, const float* amax, float amax_mul, void* hi, void* lo,
+                      void* stream);
 size_t rgcn_transform_bwd_params_split_workspace_bytes(int64_t num_nodes, int64_t num_relations,
                                                        int64_t d_in, int64_t d_out);
+/* The slab GEMM of the parameter gradients on operands given as planes (A7: grad_[W ; root] = [agg | x]^T g,
+ * /root/reference/src/models/rgcn.py:123,128 backward): nothing is converted in the kernel - the m-tiles arrive by
+ * LDS-DMA and are read as MFMA fragments with gfx950's transposing LDS read.  Same MFMA operands in the same order
+ * as rgcn_transform_bwd_params_split_begin on the fp32 tensors the planes were split from: the same bits.
+ * agg_* [N][R * d_in], x_* [N][d_in] (grad_root != NULL), g_* [N][d_out]; the amax arguments name the scales the
+ * planes were split under (all required).  d_in % 64 == 0, d_out % 8 == 0.  There is no fp32 g here, so the column
+ * sums of g come from its producer: bias_part[bias_splits][d_out] partial sums (grad_bias != NULL), added in row
+ * order by the pending reduction.  workspace: rgcn_transform_bwd_params_split_workspace_bytes. */
+int rgcn_transform_bwd_params_planes_begin(const void* agg_hi, const void* agg_lo, const void* x_hi, const void* x_lo,
+                                           const void* g_hi, const void* g_lo, const uint32_t* tile_mask,
+                                           int64_t num_nodes, int64_t num_relations, int64_t d_in, int64_t d_out,
+                                           const float* agg_amax, float agg_amax_mul, const float* x_amax,
+                                           const float* g_amax, int half, float* grad_weight, float* grad_root,
+                                           float* grad_bias, const float* bias_part, int bias_splits,
+                                           void* workspace, size_t workspace_bytes, void* stream,
+                                           rgcn_slab_job* job);
 /* slab GEMM in split precision; the pending fixed-order reduction is consumed exactly like the one of
  * rgcn_transform_bwd_params_begin (rgcn_slab_reduce / rgcn_aggregate_and_reduce / rgcn_aggregate_amax) */
 int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, const float* g,

@@ -13,7 +13,7 @@ from ctypes import c_float, POINTER, c_char_p, c_int, c_int64, c_size_t, c_void_
 
 import torch  # noqa: F401  (loads the HIP runtime first)
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 LIB_NAME = "librgcn_hip.so"
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
@@ -31,7 +31,7 @@ class SlabJob(ctypes.Structure):
     """``rgcn_slab_job``: a pending parameter-gradient slab reduction (plain device pointers)."""
     _fields_ = [("slab", c_void_p), ("bias_part", c_void_p), ("splits", ctypes.c_int32), ("K1", ctypes.c_int32),
                 ("Kc", ctypes.c_int32), ("N", ctypes.c_int32), ("grad_weight", c_void_p), ("grad_root", c_void_p),
-                ("grad_bias", c_void_p)]
+                ("grad_bias", c_void_p), ("bias_splits", ctypes.c_int32)]
 
 
 class SeqArg(ctypes.Structure):
@@ -115,6 +115,9 @@ PROTOTYPES = {
     "rgcn_transform_bwd_params_split_workspace_bytes": (c_size_t, [_I64, _I64, _I64, _I64]),
     "rgcn_transform_bwd_params_split_begin": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P, c_int,
                                                       _P, _P, _P, _P, c_size_t, _P, POINTER(SlabJob)]),
+    "rgcn_split_planes": (c_int, [_P, _I64, _P, c_float, _P, _P, _P]),
+    "rgcn_transform_bwd_params_planes_begin": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P,
+                                                       c_int, _P, _P, _P, _P, c_int, _P, c_size_t, _P, POINTER(SlabJob)]),
     "rgcn_layer_fwd_fused_supported": (c_int, [_I64, _I64, _I64]),
     "rgcn_layer_fwd_fused": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, c_int, _P, c_int, _I64, _I64, _P, _P, _P, _P, _P]),
     "rgcn_layer_bwd_input_fused_supported": (c_int, [_I64, _I64, _I64]),
