@@ -23,6 +23,8 @@ Rank 0 prints ONE JSON line.  Beside the contract's fields it carries
                    time its operand bytes need at the achievable streaming rate, and of the dense fp16 MFMA peak
   roofline_mfma    the time-dominant dense transform against the fp32 matrix peak (the arithmetic asked for)
   fp32_mfma_ms_per_step   (N = 1, headline) the same step with RGCN_GEMM_PRECISION=fp32 (exact fp32 MFMA products)
+  drop_in          (N = 1, headline) the reference's LITERAL call pattern - RGCNConv.forward twice around F.relu and
+                   dropout (src/models/rgcn.py:123-128) - eager and as a replayed HIP graph, beside the two-layer node
   secondary        (headline) `c4_1gpu`: a short run of configs[3]'s graph on this GPU, where the gather IS HBM-bound
                    (the >= 40 %-of-HBM-roofline clause of the north star, driver-timed); at N > 1: `c4`, the same
                    graph node-partitioned over the N ranks
@@ -187,7 +189,6 @@ class Run:
                       RGCNConv(dims[1], dims[2], r, num_bases=self.bases, gather_dtype=gdt)]
         self.cot_cpu = torch.randn(n, dims[2])
         self.summary = None
-        self.hot_rows = {}                  # (weighted structure?, row width) -> rows of the table the gather keeps in LDS
         if world == 1:
             eid, etd = ei.to(dev), et.to(dev)
             torch.cuda.synchronize()
@@ -195,9 +196,6 @@ class Run:
             graph = ops.bucket(eid, etd, n, r)
             torch.cuda.synchronize()
             self.bucket_ms = (time.perf_counter() - t0) * 1e3
-            for dd in set(dims):
-                self.hot_rows[(False, dd)] = graph.hot_rows(False, dd)
-                self.hot_rows[(True, dd)] = graph.hot_rows(True, dd)
             emb = self.emb_cpu.to(dev).requires_grad_(True)
             convs = self.convs = [c.to(dev) for c in self.convs]
             cot = self.cot_cpu.to(dev)
@@ -211,6 +209,18 @@ class Run:
                     p.grad = None
                 out.backward(cot)
             self.step = step
+
+            def drop_in_step():
+                # the reference's call pattern LITERALLY (/root/reference/src/models/rgcn.py:123-128, as INTEGRATION.md
+                # section 1's import swap leaves it): RGCNConv.forward twice around F.relu and the dropout module
+                x = convs[0](emb, eid, etd)
+                x = torch.nn.functional.relu(x)
+                x = torch.nn.functional.dropout(x, 0.0, True)
+                out = convs[1](x, eid, etd)
+                for p in params:
+                    p.grad = None
+                out.backward(cot)
+            self.drop_in_step = drop_in_step
             self.parallelism = "1 GPU"
         else:
             from primekg_rgcn_linkprediction_amd import dist as rdist
@@ -342,10 +352,7 @@ def kernel_tables(run, events, event_steps):
         edges, segments, table_rows = shape[(transposed, d)]
         nbytes = gather_bytes(edges, segments, d, transposed)
         comp = gather_compulsory_bytes(edges, segments, table_rows, d, transposed)
-        hot = run.hot_rows.get((transposed, d), 0)
-        kernels.append({"kernel": (f"k_aggregate_hot<{d // 4},{'true' if transposed else 'false'},{hot}>" if hot else
-                                   f"k_aggregate<{d // 4},{'true' if transposed else 'false'}>"), "kind": "gather",
-                        "hot_rows_in_lds": hot,
+        kernels.append({"kernel": f"k_aggregate<{d // 4},{'true' if transposed else 'false'}>", "kind": "gather",
                         "d": d, "transposed": transposed, "launches_per_step": len(ts) // event_steps,
                         "avg_us": avg * 1e6, "bytes": nbytes, "gbs": nbytes / avg / 1e9,
                         "compulsory_hbm_bytes": comp, "table_bytes": 4 * table_rows * d,
@@ -618,6 +625,25 @@ def main():
                                        "arithmetic": "v_mfma_f32_32x32x2_f32: every product exact fp32 (bit for bit an fmaf chain)"}
             finally:
                 ops.GEMM_PRECISION = saved
+        if world == 1:
+            # the literal drop-in: what a reference user gets from the import swap alone - conv1 -> F.relu -> dropout
+            # -> conv2 through RGCNConv.forward, each layer its own autograd node (its own scale launch, no ReLU in a
+            # GEMM epilogue) - eager and as one replayed HIP graph, beside the headline's two-layer node
+            try:
+                headline_step, run.step = run.step, run.drop_in_step
+                eager_s, _ = run.measure(20, 8, False)
+                graph_s, graph_mode = run.measure(20, 3, use_graph, force_graph=True)
+                result["drop_in"] = {"ms_per_step_eager": eager_s / 20 * 1e3, "ms_per_step_graph": graph_s / 20 * 1e3,
+                                     "launch_graph": graph_mode, "steps": 20,
+                                     "value_graph": LAYERS * run.num_edges * 20 / graph_s, "unit": "edges/s",
+                                     "vs_headline": (graph_s / 20 * 1e3) / result["ms_per_step"],
+                                     "call_pattern": "conv2(dropout(relu(conv1(x, ei, et)), p=0), ei, et) through RGCNConv.forward "
+                                                     "(reference src/models/rgcn.py:123-128), out.backward(cotangent)"}
+            except Exception as exc:                                       # the headline line must survive this leg
+                result["drop_in"] = {"error": repr(exc)}
+                exit_code = exit_code or 6
+            finally:
+                run.step = headline_step
         keep_cpu = (run.ei, run.et, run.n, run.r, run.dims, run.bases)
         free_run(run)
         run = None

@@ -129,7 +129,6 @@ typedef struct rgcn_slab_job {
   float* grad_weight;
   float* grad_root;
   float* grad_bias;
-  int32_t bias_splits; /* rows of bias_part (0: `splits`) - the plane kernels take grad_bias partials from elsewhere */
 } rgcn_slab_job;
 
 /* ------------------------------------------------------------------------------------
@@ -179,27 +178,6 @@ int rgcn_aggregate_amax(const rgcn_graph* g, int transposed, const float* x, int
 int rgcn_aggregate_deferrable(const rgcn_graph* g, int transposed, int64_t d);
 int rgcn_aggregate_deferred(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg,
                             void* workspace, size_t workspace_bytes, const rgcn_slab_job* job, void* stream);
-/* The first gather of a forward pass with the pass's first launch (rgcn_absmax_pack: max |x| into x_amax, the cleared
- * amax buffers, the layers' split weight images) riding in its grid as extra workgroups: the gather reads x but needs
- * neither result, the transform after it needs both - the 12 us latency chain of the stand-alone launch then runs beside
- * the gather instead of before it.  x is both the gathered table [n_other, d] and the tensor whose maximum is taken;
- * mean structures, d in {64, 128, 256}; deferred != 0: as rgcn_aggregate_deferred (hub tails left to the transform).
- * The prep arguments are those of rgcn_absmax_pack (HOST arrays of `count` entries).  Same bits as the two launches. */
-int rgcn_aggregate_prep(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg, void* workspace,
-                        size_t workspace_bytes, int deferred, float* x_amax, float* zero_buffers, int zero_count,
-                        int count, const float* const* weights, const float* const* roots, const int64_t* num_relations,
-                        const int64_t* d_in, const int64_t* d_out, void* const* packed, const size_t* packed_bytes,
-                        void* stream);
-/* Hot rows (OFF by default: measured slower than the plain gather on the MI355X, kept as an A/B path).  While switched
- * on, bucketing also counts how often each row of the gathered table is read: on a degree-skewed graph (PrimeKG: hub
- * genes) the 64 most read rows are a third of all row reads.  Where the 128 most read rows take >= 10 % of a structure's
- * edges, the fp32 gathers of 64 / 128 / 256-wide rows keep the first 128 / 64 / 32 of them (32 KB) in LDS for the life
- * of a (persistent) workgroup and serve those edges from there; same sums in the same order, same bits.
- * rgcn_aggregate_hot_rows: how many rows such a gather keeps (0: the plain gather).  rgcn_hot_rows_kb: LDS budget of
- * the path for the process - 0 (off, the default), 16 or 32; -1 restores RGCN_HOT_KB / the default; any other value
- * only queries; returns the previous value.  Set it BEFORE the graph is bucketed. */
-int rgcn_aggregate_hot_rows(const rgcn_graph* g, int transposed, int64_t d);
-int rgcn_hot_rows_kb(int kb);
 /* One launch of the above (level in [0, rgcn_graph_num_levels)); calling the levels in order
  * equals rgcn_aggregate.  Lets a profiler bracket the level-0 gather kernel by itself. */
 int rgcn_aggregate_level(const rgcn_graph* g, int transposed, int level, const float* x, int64_t d,
@@ -352,32 +330,8 @@ int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const floa
 int rgcn_transform_first_split(const float* g, const void* packed, int has_root, int64_t num_nodes,
                                int64_t num_relations, int64_t d_in, int64_t d_out, const float* g_amax, int half,
                                float* t_out, void* workspace, size_t workspace_bytes, void* stream);
-/* "Planes" (round 4): a tensor T[M][K] (K % 8 == 0) the split kernels would split in their loops, stored split: two
- * DEVICE IEEE-fp16 images hi[M][K], lo[M][K] (row-major, K halves per row) with hi = fp16(T * 2^e), lo = fp16(T * 2^e
- * - hi) under the power-of-two scale that puts amax * amax_mul into [2^14, 2^15) - the two numbers the kernels form in
- * registers anyway, written once by whoever holds T in registers (the gather in its plane mode, an NT transform for
- * the fp32 block it splits) instead of re-formed by every consumer.  rgcn_split_planes is the stand-alone producer
- * (lo may be NULL: one-pass arithmetic reads hi only).  numel % 8 == 0. */
-int rgcn_split_planes(const float* src, int64_t numel, const float* amax, float amax_mul, void* hi, void* lo,
-                      void* stream);
 size_t rgcn_transform_bwd_params_split_workspace_bytes(int64_t num_nodes, int64_t num_relations,
                                                        int64_t d_in, int64_t d_out);
-/* The slab GEMM of the parameter gradients on operands given as planes (A7: grad_[W ; root] = [agg | x]^T g,
- * /root/reference/src/models/rgcn.py:123,128 backward): nothing is converted in the kernel - the m-tiles arrive by
- * LDS-DMA and are read as MFMA fragments with gfx950's transposing LDS read.  Same MFMA operands in the same order
- * as rgcn_transform_bwd_params_split_begin on the fp32 tensors the planes were split from: the same bits.
- * agg_* [N][R * d_in], x_* [N][d_in] (grad_root != NULL), g_* [N][d_out]; the amax arguments name the scales the
- * planes were split under (all required).  d_in % 64 == 0, d_out % 8 == 0.  There is no fp32 g here, so the column
- * sums of g come from its producer: bias_part[bias_splits][d_out] partial sums (grad_bias != NULL), added in row
- * order by the pending reduction.  workspace: rgcn_transform_bwd_params_split_workspace_bytes. */
-int rgcn_transform_bwd_params_planes_begin(const void* agg_hi, const void* agg_lo, const void* x_hi, const void* x_lo,
-                                           const void* g_hi, const void* g_lo, const uint32_t* tile_mask,
-                                           int64_t num_nodes, int64_t num_relations, int64_t d_in, int64_t d_out,
-                                           const float* agg_amax, float agg_amax_mul, const float* x_amax,
-                                           const float* g_amax, int half, float* grad_weight, float* grad_root,
-                                           float* grad_bias, const float* bias_part, int bias_splits,
-                                           void* workspace, size_t workspace_bytes, void* stream,
-                                           rgcn_slab_job* job);
 /* slab GEMM in split precision; the pending fixed-order reduction is consumed exactly like the one of
  * rgcn_transform_bwd_params_begin (rgcn_slab_reduce / rgcn_aggregate_and_reduce / rgcn_aggregate_amax) */
 int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, const float* g,
@@ -581,7 +535,7 @@ enum {
   RGCN_FN_ABSMAX = 0, RGCN_FN_ABSMAX_MULTI, RGCN_FN_ABSMAX_PACK, RGCN_FN_WEIGHTS_SPLIT_PACK_MULTI, RGCN_FN_AGGREGATE,
   RGCN_FN_AGGREGATE_AND_REDUCE, RGCN_FN_AGGREGATE_AMAX, RGCN_FN_AGGREGATE_DEFERRED, RGCN_FN_TRANSFORM_FWD_SPLIT,
   RGCN_FN_TRANSFORM_BWD_INPUT_SPLIT, RGCN_FN_TRANSFORM_FIRST_SPLIT, RGCN_FN_TRANSFORM_BWD_PARAMS_SPLIT_BEGIN,
-  RGCN_FN_SLAB_REDUCE, RGCN_FN_LAYER_FWD_FUSED, RGCN_FN_LAYER_BWD_INPUT_FUSED, RGCN_FN_AGGREGATE_PREP, RGCN_FN_COUNT
+  RGCN_FN_SLAB_REDUCE, RGCN_FN_LAYER_FWD_FUSED, RGCN_FN_LAYER_BWD_INPUT_FUSED, RGCN_FN_COUNT
 };
 typedef struct rgcn_seq_arg {
   int32_t kind;  /* RGCN_SEQ_* */

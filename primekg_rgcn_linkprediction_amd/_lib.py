@@ -31,7 +31,7 @@ class SlabJob(ctypes.Structure):
     """``rgcn_slab_job``: a pending parameter-gradient slab reduction (plain device pointers)."""
     _fields_ = [("slab", c_void_p), ("bias_part", c_void_p), ("splits", ctypes.c_int32), ("K1", ctypes.c_int32),
                 ("Kc", ctypes.c_int32), ("N", ctypes.c_int32), ("grad_weight", c_void_p), ("grad_root", c_void_p),
-                ("grad_bias", c_void_p), ("bias_splits", ctypes.c_int32)]
+                ("grad_bias", c_void_p)]
 
 
 class SeqArg(ctypes.Structure):
@@ -49,15 +49,13 @@ SEQ_IMM, SEQ_FLOAT, SEQ_BASE, SEQ_JOB, SEQ_STREAM, SEQ_ARRAY = range(6)
 SEQ_FUNCTIONS = ("rgcn_absmax", "rgcn_absmax_multi", "rgcn_absmax_pack", "rgcn_weights_split_pack_multi", "rgcn_aggregate",
                  "rgcn_aggregate_and_reduce", "rgcn_aggregate_amax", "rgcn_aggregate_deferred", "rgcn_transform_fwd_split",
                  "rgcn_transform_bwd_input_split", "rgcn_transform_first_split", "rgcn_transform_bwd_params_split_begin",
-                 "rgcn_slab_reduce", "rgcn_layer_fwd_fused", "rgcn_layer_bwd_input_fused", "rgcn_aggregate_prep")
+                 "rgcn_slab_reduce", "rgcn_layer_fwd_fused", "rgcn_layer_bwd_input_fused")
 # their HOST array parameters: position -> (entries are device pointers?, position of the parameter holding the count)
 SEQ_HOST_ARRAYS = {
     "rgcn_absmax_multi": {1: (True, 0), 2: (False, 0), 3: (True, 0)},
     "rgcn_absmax_pack": {6: (True, 5), 7: (True, 5), 8: (False, 5), 9: (False, 5), 10: (False, 5), 11: (True, 5), 12: (False, 5)},
     "rgcn_weights_split_pack_multi": {1: (True, 0), 2: (True, 0), 3: (False, 0), 4: (False, 0), 5: (False, 0), 6: (True, 0),
                                       7: (True, 0), 8: (True, 0), 9: (False, 0)},
-    "rgcn_aggregate_prep": {12: (True, 11), 13: (True, 11), 14: (False, 11), 15: (False, 11), 16: (False, 11), 17: (True, 11),
-                            18: (False, 11)},
 }
 
 
@@ -106,18 +104,11 @@ PROTOTYPES = {
     "rgcn_transform_bwd_input_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, c_int,
                                                _P, _P, _P, c_size_t, _P, c_void_p, c_int, _P, c_float]),
     "rgcn_aggregate_deferrable": (c_int, [c_void_p, c_int, _I64]),
-    "rgcn_aggregate_prep": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, _P,
-                                    _P, _P, _P]),
-    "rgcn_aggregate_hot_rows": (c_int, [c_void_p, c_int, _I64]),
-    "rgcn_hot_rows_kb": (c_int, [c_int]),
     "rgcn_aggregate_deferred": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, POINTER(SlabJob), _P]),
     "rgcn_transform_first_split": (c_int, [_P, _P, c_int, _I64, _I64, _I64, _I64, _P, c_int, _P, _P, c_size_t, _P]),
     "rgcn_transform_bwd_params_split_workspace_bytes": (c_size_t, [_I64, _I64, _I64, _I64]),
     "rgcn_transform_bwd_params_split_begin": (c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P, c_int,
                                                       _P, _P, _P, _P, c_size_t, _P, POINTER(SlabJob)]),
-    "rgcn_split_planes": (c_int, [_P, _I64, _P, c_float, _P, _P, _P]),
-    "rgcn_transform_bwd_params_planes_begin": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P,
-                                                       c_int, _P, _P, _P, _P, c_int, _P, c_size_t, _P, POINTER(SlabJob)]),
     "rgcn_layer_fwd_fused_supported": (c_int, [_I64, _I64, _I64]),
     "rgcn_layer_fwd_fused": (c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P, c_int, _P, c_int, _I64, _I64, _P, _P, _P, _P, _P]),
     "rgcn_layer_bwd_input_fused_supported": (c_int, [_I64, _I64, _I64]),

@@ -69,21 +69,15 @@ class _Scales:
     slot - and, in a forward pass, splits the layers' weights.  In fp32 mode nothing is allocated and every
     slot is None."""
 
-    def __init__(self, t: Tensor, slots: int = 2, layers=(), ride=None):
+    def __init__(self, t: Tensor, slots: int = 2, layers=()):
         """``layers``: ``[(weight, root | None), ...]`` of the pass (forward passes): their split images are made
-        by the SAME first launch - ``self.packed[i]`` (None for widths the split kernels do not tile).
-        ``ride`` (a bucketed graph): that launch rides in the first gather over ``t`` instead
-        (``ops.aggregate_with_prep``) where that applies - ``self.first_gather`` then holds ``(agg, hubs)``."""
+        by the SAME first launch - ``self.packed[i]`` (None for widths the split kernels do not tile)."""
         self._buf, self._next, self.first = None, 1, None
         self.packed = [None] * len(layers)
-        self.first_gather = None
         if ops.GEMM_PRECISION == "split":
             self._buf = ops._empty(slots, ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
             self.first = self._buf[0]
-            rode = ops.aggregate_with_prep(ride, t, self.first, self._buf[1:slots], list(layers)) if (ride is not None and layers) else None
-            if rode is not None:
-                self.first_gather, self.packed = (rode[0], rode[1]), rode[2]
-            elif layers:
+            if layers:
                 self.packed = ops.absmax_and_split(t, self.first, self._buf[1:slots], list(layers))
             else:
                 ops.absmax(t, self.first, self._buf[1:slots])
@@ -96,7 +90,7 @@ class _Scales:
 
 
 import os as _os
-_TRANSFORM_FIRST_RATIO = float(_os.environ.get("RGCN_TRANSFORM_FIRST_RATIO", "2"))   # A/B switch, see _input_grad
+_TRANSFORM_FIRST_RATIO = 2.0             # see _input_grad (module attributes, not environment switches: tests patch them)
 
 
 def _fused_backward(graph, g, r, d_in, d_out, g_amax, packed, precision) -> bool:
@@ -164,13 +158,12 @@ def _defer_hubs(half: bool, packed, amax, k: int, n_out: int) -> bool:
     """may a gather of k-wide rows leave its hub tails to the transform (n_out columns) that follows it?  Split
     precision with the operand's scale known beforehand; rows up to 128 wide and ONE column block of workgroups
     (at 256 the workgroups of every column block would each finish the same rows, with four row slots: measured
-    1 % slower at C3); RGCN_DEFER_HUBS=0 keeps the separate launch."""
+    1 % slower at C3)."""
     return (_DEFER_HUBS and not half and packed is not None and amax is not None and ops.GEMM_PRECISION == "split"
             and k in (64, 128) and n_out <= 128)
 
 
-_DEFER_HUBS = _os.environ.get("RGCN_DEFER_HUBS", "1") == "1"
-_SLAB_RIDES = _os.environ.get("RGCN_SLAB_RIDES", "1") == "1"      # 0: the slab reductions as launches of their own (A/B)
+_DEFER_HUBS = True
 
 
 def _train_fused(graph, n, r, d_in, d_out, half) -> bool:
@@ -181,15 +174,9 @@ def _train_fused(graph, n, r, d_in, d_out, half) -> bool:
 
 
 def _layer_train_forward(graph: "ops.BucketedGraph", x: Tensor, gather_dtype, weight, root, bias, relu: bool,
-                         half: bool, x_amax, amax_out, packed, gathered=None):
-    """-> (agg, out) of one layer's training forward; ``gathered``: ``(agg, hubs)`` when the pass's first launch
-    already carried this layer's gather (``_Scales(ride=)``)"""
+                         half: bool, x_amax, amax_out, packed):
+    """-> (agg, out) of one layer's training forward"""
     n, r, d_in, d_out = x.size(0), graph.num_relations, x.size(1), weight.size(2)
-    if gathered is not None:
-        agg, hubs = gathered
-        out = ops.transform_fwd(agg, x, weight, root, bias, relu=relu, graph=graph, half=half, amax=(x_amax, x_amax),
-                                amax_out=amax_out, packed=packed, hubs=hubs)
-        return agg, out
     if (_train_fused(graph, n, r, d_in, d_out, half) and packed is not None and x_amax is not None):
         agg = ops._empty(n, r * d_in, dtype=torch.float32, device=x.device)
         out = ops.layer_fwd_fused(graph, x, packed, bias, relu, x_amax, amax_out, inline_limit=_EVAL_INLINE_LIMIT,
@@ -205,8 +192,51 @@ def _layer_train_forward(graph: "ops.BucketedGraph", x: Tensor, gather_dtype, we
     return agg, out
 
 
+def _packs(bufs, layers):
+    return [ops.SplitWeights(b, w, root) if b is not None else None for b, (w, root) in zip(bufs, layers)]
+
+
+def _conv_forward(x, weight, root, bias, *, graph, relu, gather_dtype, half):
+    """one layer's training forward as a pass -> (out, agg, amax buffer of x | None, split images | None)"""
+    scales = _Scales(x, slots=1, layers=[(weight, root)])            # ONE launch: max |x| and the split weights
+    x_amax = scales.first            # also the bound of agg: a mean of rows cannot exceed the table's maximum
+    packed = scales.packed[0]                                         # once, for forward and backward
+    agg, out = _layer_train_forward(graph, x, gather_dtype, weight, root, bias, relu, half, x_amax, None,
+                                    packed)                           # rows A3 + A4, A6 (+ fused ReLU)
+    return out, agg, scales._buf, (packed.buf if packed is not None else None)
+
+
+def _conv_backward(x, agg, weight, root, x_amax, pkbuf, g, *, graph, has_root, has_bias, need_x, need_p, prec):
+    """one layer's backward as a pass -> (gx | None, gw | None, groot | None, gbias | None)"""
+    packed = _packs([pkbuf], [(weight, root)])[0]
+    scales = _Scales(g, slots=1)
+    g_amax = scales.first
+    pending = None
+    if need_p:
+        pending = ops.transform_bwd_params(agg, x, g, graph.num_relations, want_root=has_root, want_bias=has_bias,
+                                           graph=graph, defer=True, amax=(x_amax, x_amax, g_amax), precision=prec)
+    gx = None
+    if need_x:
+        gx = _input_grad(graph, g, weight, root, tail=pending, g_amax=g_amax, scales=scales, packed=packed,
+                         precision=prec)
+    gw = groot = gbias = None
+    if pending is not None:
+        pending.finish()                                                # no gather took it along
+        gw, groot, gbias = pending.grads
+    return gx, gw, groot, gbias
+
+
+_R_CONV_FORWARD = ops.Region("conv.forward", _conv_forward)
+_R_CONV_BACKWARD = ops.Region("conv.backward", _conv_backward)
+
+
 class _RGCNConvFunction(torch.autograd.Function):
-    """x, weight[R, d_in, d_out], root, bias -> out (optionally relu(out)), on a bucketed graph."""
+    """x, weight[R, d_in, d_out], root, bias -> out (optionally relu(out)), on a bucketed graph.
+
+    This is what the reference's own call pattern reaches - ``x = self.conv1(x, edge_index, edge_type)`` ... ``x =
+    self.conv2(x, edge_index, edge_type)``, ``/root/reference/src/models/rgcn.py:123-128`` - after INTEGRATION.md's
+    import swap.  Forward and backward are ``ops.Region`` passes (round 4): after three calls on a graph each is one
+    allocation and ONE native call (``rgcn_sequence_run``) instead of five to seven wrapper calls."""
 
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, root: Optional[Tensor], bias: Optional[Tensor],
@@ -215,61 +245,47 @@ class _RGCNConvFunction(torch.autograd.Function):
         weight = weight.contiguous()
         root_c = root.contiguous() if root is not None else None
         bias_c = bias.contiguous() if bias is not None else None
-        ctx.gather_dtype = gather_dtype
         half = gather_dtype == torch.float16
         ctx.bwd_precision = "half" if (half and half_backward and ops.GEMM_PRECISION == "split") else None
-        scales = _Scales(x, slots=1, layers=[(weight, root_c)])          # ONE launch: max |x| and the split weights
-        x_amax = scales.first            # also the bound of agg: a mean of rows cannot exceed the table's maximum
-        packed = scales.packed[0]                                                     # once, for forward and backward
-        agg, out = _layer_train_forward(graph, x, gather_dtype, weight, root_c, bias_c, relu, half, x_amax, None,
-                                        packed)                                        # rows A3 + A4, A6 (+ fused ReLU)
-        ctx.graph, ctx.relu, ctx.packed = graph, relu, packed
+        key = (tuple(x.shape), tuple(weight.shape), root is not None, bias is not None, gather_dtype, bool(relu),
+               _policy_key())
+        out, agg, amax, pkbuf = _R_CONV_FORWARD.run(graph, key, (x, weight, root_c, bias_c),
+                                                    dict(graph=graph, relu=relu, gather_dtype=gather_dtype, half=half),
+                                                    want={0})
+        x_amax = None
+        if amax is not None:                          # row 0 of the amax allocation, as a tensor or as an arena offset
+            x_amax = (ops.Lazy(amax.arena, amax.offset, (ops.AMAX_FLOATS,), torch.float32) if isinstance(amax, ops.Lazy)
+                      else amax[0])
+        ctx.graph, ctx.relu, ctx.key = graph, relu, key
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
-        ctx.save_for_backward(x, agg, weight, root_c, out if relu else None, x_amax)
+        ctx.save_for_backward(x, weight, root_c)             # the node's inputs (autograd checks their versions)
+        ctx.kept = (agg, x_amax, pkbuf, out if relu else None)   # tensors, or arena offsets of a replayed pass
         return out
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        x, agg, weight, root, out, x_amax = ctx.saved_tensors
-        graph = ctx.graph
+        x, weight, root = ctx.saved_tensors
+        agg, x_amax, pkbuf, out = ctx.kept
         if ctx.relu:
-            g = g * (out > 0)                                               # ReLU backward
+            g = g * (out > 0)                                               # ReLU backward (a torch op, outside the pass)
         g = g.contiguous()
         need_x, need_w, need_root, need_bias = ctx.needs_input_grad[:4]
-        gx = gw = groot = gbias = None
-        pending = None
-        scales = _Scales(g, slots=1)
-        g_amax = scales.first
-        if need_w or (need_root and ctx.has_root) or (need_bias and ctx.has_bias):
-            pending = ops.transform_bwd_params(agg, x, g, graph.num_relations, want_root=ctx.has_root,
-                                               want_bias=ctx.has_bias, graph=graph, defer=True,
-                                               amax=(x_amax, x_amax, g_amax), precision=ctx.bwd_precision)
-        if need_x:
-            gx = _input_grad(graph, g, weight, root, tail=pending, g_amax=g_amax, scales=scales, packed=ctx.packed,
-                             precision=ctx.bwd_precision)
-        if pending is not None:
-            pending.finish()                                                # no gather took it along
-            gw, groot, gbias = pending.grads
+        need_p = bool(need_w or (need_root and ctx.has_root) or (need_bias and ctx.has_bias))
+        static = dict(graph=ctx.graph, has_root=ctx.has_root, has_bias=ctx.has_bias, need_x=bool(need_x), need_p=need_p,
+                      prec=ctx.bwd_precision)
+        gx, gw, groot, gbias = _R_CONV_BACKWARD.run(ctx.graph, (ctx.key, bool(need_x), need_p, ctx.bwd_precision),
+                                                    (x, agg, weight, root, x_amax, pkbuf, g), static,
+                                                    want={0, 1, 2, 3})
         return gx, gw, groot, gbias, None, None, None, None
-
-
-def _packs(bufs, layers):
-    return [ops.SplitWeights(b, w, root) if b is not None else None for b, (w, root) in zip(bufs, layers)]
 
 
 def _enc2_layer1(x, w1, root1, b1, w2, root2, *, graph, gather_dtype, half):
     """first launch of the pass (max |x|, cleared amax slots, both layers' split weights) + conv1 with its ReLU
     -> (h, agg1, amax buffers [x | h], split images of conv1, of conv2)"""
-    # the pass's first launch (max |x|, cleared slots, both layers' split weights) rides in conv1's gather where the
-    # layer takes the separate gather / transform kernels with the hub tails left to the transform
-    n, r, d_in, d_out = x.size(0), graph.num_relations, x.size(1), w1.size(2)
-    ride = graph if (not half and gather_dtype in (None, torch.float32) and not _train_fused(graph, n, r, d_in, d_out, half)
-                     and _DEFER_HUBS and d_in in (64, 128) and d_out <= 128) else None
-    scales = _Scales(x, layers=[(w1, root1), (w2, root2)], ride=ride)
+    scales = _Scales(x, layers=[(w1, root1), (w2, root2)])
     x_amax, h_amax = scales.first, scales.slot()
     pk1, pk2 = scales.packed                                      # once, for forward and backward
-    agg1, h = _layer_train_forward(graph, x, gather_dtype, w1, root1, b1, True, half, x_amax, h_amax, pk1,
-                                   gathered=scales.first_gather)
+    agg1, h = _layer_train_forward(graph, x, gather_dtype, w1, root1, b1, True, half, x_amax, h_amax, pk1)
     return h, agg1, scales._buf, (pk1.buf if pk1 is not None else None), (pk2.buf if pk2 is not None else None)
 
 
@@ -299,8 +315,6 @@ def _enc2_backward(x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax, pk1bu
     # the slab reductions of the parameter gradients ride in the transposed gathers that follow them
     red2 = ops.transform_bwd_params(agg2, h, g, r, want_root=has_root2, want_bias=has_b2, graph=graph,
                                     defer=True, amax=(h_amax, h_amax, g_amax), precision=prec)
-    if not _SLAB_RIDES:
-        red2.finish()
     # dropout backward: the factor 1 / (1 - p) goes into the input-gradient epilogue as a scalar (the mask is h itself,
     # positive exactly where a unit is active and kept) - the weights keep their split images and the hub deferral
     scale = 1.0 / (1.0 - p) if p > 0 else 1.0
@@ -317,8 +331,6 @@ def _enc2_backward(x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax, pk1bu
                                      out_scale=scale)   # d loss / d (pre-ReLU of conv1)
     red1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1, graph=graph,
                                     defer=True, amax=(x_amax, x_amax, gz_amax), precision=prec)
-    if not _SLAB_RIDES:
-        red1.finish()
     gx = None
     if need_x:
         gx = _input_grad(graph, gz, w1, root1, tail=red1, g_amax=gz_amax, scales=scales, packed=pk1, precision=prec)
@@ -422,13 +434,13 @@ class _Encoder2Function(torch.autograd.Function):
 # cost time (13.5 ms against 5.95 ms per forward; tools/eval_blocks_probe.py).  Hence the default block is
 # large - 1 GiB: C2 runs as one block, C4 as four - and DESIGN.md section 9 says what a real fusion of the
 # gather into the transform's A tile would have to look like.
-_EVAL_BLOCK_BYTES = int(_os.environ.get("RGCN_EVAL_BLOCK_BYTES", str(1 << 30)))
+_EVAL_BLOCK_BYTES = 1 << 30
 
 
 # RGCN_EVAL_FUSED (default auto): the one-kernel layer (ops.layer_fwd_fused: the aggregate lives in LDS only) wherever it
 # covers the shape - auto: once the aggregate would reach 256 MB, where the path is HBM-bound (C4 on one GPU: 6.0 -> 3.5
 # ms per 2-layer forward); at C2's size the two launches are as fast (0.114 against 0.118 ms) -, 1: always, 0 = the
-# two-launch path below.  RGCN_EVAL_INLINE_LIMIT: longest segment the fused kernel walks
+# two-launch path below.  _EVAL_INLINE_LIMIT: longest segment the fused kernel walks
 # itself (longer ones are pre-aggregated by the ordinary gather).
 _EVAL_FUSED = _os.environ.get("RGCN_EVAL_FUSED", "auto")          # "auto" | "1" | "0" (tests also set True / False)
 
@@ -439,7 +451,7 @@ def _eval_fused(n: int, r: int, d_in: int) -> bool:
     if _EVAL_FUSED in (False, "0"):
         return False
     return n * r * d_in * 4 >= _TRAIN_FUSED_MIN_BYTES          # the same threshold as the training layers
-_EVAL_INLINE_LIMIT = int(_os.environ.get("RGCN_EVAL_INLINE_LIMIT", "16"))
+_EVAL_INLINE_LIMIT = 16
 
 
 def _layer_eval_blocked(graph: "ops.BucketedGraph", x: Tensor, table: Tensor, weight: Tensor, root, bias, relu: bool,
@@ -529,6 +541,69 @@ def rgcn_encoder2(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: "RGCN
     return _Encoder2Function.apply(x, conv1.effective_weight(), conv1.root, conv1.bias,
                                    conv2.effective_weight(), conv2.root, conv2.bias, graph,
                                    conv1.gather_dtype, float(dropout_p), conv1.half_backward)
+
+
+def _accumulate(param: Optional[Tensor], grad: Optional[Tensor]) -> None:
+    """what the autograd engine does with a leaf's gradient: ``.grad`` is set, or added to"""
+    if param is None or grad is None or not param.requires_grad:
+        return
+    if param.grad is None:
+        param.grad = grad
+    else:
+        param.grad.add_(grad)
+
+
+@torch.no_grad()
+def rgcn_encoder2_step(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: "RGCNConv", conv2: "RGCNConv",
+                       cotangent: Tensor, need_input_grad: bool = True):
+    """One explicit encoder step - ``out = conv2(relu(conv1(x)))`` and the backward for a GIVEN cotangent
+    ``d loss / d out`` - WITHOUT the autograd engine: the two recorded passes of ``_Encoder2Function`` issued directly
+    (two native calls once recorded), the parameter gradients accumulated into ``.grad`` as ``out.backward(cotangent)``
+    would, ``-> (out, grad_x | None)``.  For callers that hold the cotangent themselves (a benchmark loop, a
+    pipeline whose loss gradient arrives from elsewhere, ``dist.PartitionedEncoder``): the engine's hop to its backward
+    thread and the ``Function`` plumbing cost more host time (~105 us) than issuing both passes (VERDICT r3 item 7;
+    ``tools/host_profile.py``).  Same kernels, same bits as the autograd route; no dropout between the layers (a
+    caller with a loss uses ``rgcn_encoder2``)."""
+    _check_x(x)
+    graph = ops.bucket(edge_index, edge_type, x.size(0), conv1.num_relations)
+    basis1, basis2 = conv1.num_bases is not None, conv2.num_bases is not None
+    w1 = (ops.basis_compose(conv1.comp.contiguous(), conv1.weight.contiguous()) if basis1 else conv1.weight).contiguous()
+    w2 = (ops.basis_compose(conv2.comp.contiguous(), conv2.weight.contiguous()) if basis2 else conv2.weight).contiguous()
+    root1, b1, root2, b2 = conv1.root, conv1.bias, conv2.root, conv2.bias
+    x = x.contiguous()
+    gather_dtype = conv1.gather_dtype
+    half = gather_dtype == torch.float16
+    prec = "half" if (half and conv1.half_backward and ops.GEMM_PRECISION == "split") else None
+    key = (tuple(x.shape), tuple(w1.shape), tuple(w2.shape), root1 is not None, b1 is not None, root2 is not None,
+           b2 is not None, gather_dtype, _policy_key())
+    out, h, agg1, agg2, amax, pk1buf, pk2buf = _R_FORWARD.run(graph, key, (x, w1, root1, b1, w2, root2, b2),
+                                                             dict(graph=graph, gather_dtype=gather_dtype, half=half),
+                                                             want={0})
+    x_amax = h_amax = None
+    if amax is not None:
+        if isinstance(amax, ops.Lazy):
+            row = ops.AMAX_FLOATS * 4
+            x_amax = ops.Lazy(amax.arena, amax.offset, (ops.AMAX_FLOATS,), torch.float32)
+            h_amax = ops.Lazy(amax.arena, amax.offset + row, (ops.AMAX_FLOATS,), torch.float32)
+        else:
+            x_amax, h_amax = amax[0], amax[1]
+    need_x = bool(need_input_grad)
+    flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
+    static = dict(graph=graph, flags=flags, p=0.0, prec=prec, need_x=need_x)
+    gx, gw1, groot1, gb1, gw2, groot2, gb2 = _R_BACKWARD.run(
+        graph, (key, 0.0, need_x, prec), (x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax, pk1buf, pk2buf,
+                                          cotangent.contiguous()), static, want={0, 1, 2, 3, 4, 5, 6})
+    for conv, gw, groot, gb, basis in ((conv1, gw1, groot1, gb1, basis1), (conv2, gw2, groot2, gb2, basis2)):
+        if basis:
+            gcomp, gbasis = ops.basis_compose_bwd(gw, conv.comp.contiguous(), conv.weight.contiguous(),
+                                                  conv.comp.requires_grad, conv.weight.requires_grad)
+            _accumulate(conv.comp, gcomp)
+            _accumulate(conv.weight, gbasis)
+        else:
+            _accumulate(conv.weight, gw)
+        _accumulate(conv.root, groot)
+        _accumulate(conv.bias, gb)
+    return out, gx
 
 
 class RGCNConv(nn.Module):

@@ -370,7 +370,16 @@ int bwd_impl(const float* gs, const float* scores, const float* labels, const fl
              int64_t r_rows, int64_t batch, int64_t d, float* grad_h, float* grad_t, float* grad_r, void* workspace,
              size_t workspace_bytes, int zero_tables, hipStream_t stream) {
   if (batch < 0 || d <= 0 || (d & 3) || h_rows < 0 || t_rows < 0 || r_rows < 0) return RGCN_ERR_ARG;
-  if (batch == 0) return RGCN_OK;
+  if (batch == 0) {
+    // no launch to carry the riders: an empty batch still owes its caller cleared (indexed) gradient tables
+    // (every buffer whole: the index vectors of an empty batch arrive as NULL, so "indexed" cannot be told here)
+    if (zero_tables) {
+      if (grad_h && h_rows) RGCN_HIP_TRY(hipMemsetAsync(grad_h, 0, (size_t)h_rows * d * sizeof(float), stream));
+      if (grad_t && t_rows && grad_t != grad_h) RGCN_HIP_TRY(hipMemsetAsync(grad_t, 0, (size_t)t_rows * d * sizeof(float), stream));
+      if (grad_r && r_rows) RGCN_HIP_TRY(hipMemsetAsync(grad_r, 0, (size_t)r_rows * d * sizeof(float), stream));
+    }
+    return RGCN_OK;
+  }
   if (!gs || !h || !t || !r) return RGCN_ERR_ARG;
   if (batch > INT32_MAX / 4 || h_rows > INT32_MAX || t_rows > INT32_MAX || r_rows > INT32_MAX) return RGCN_ERR_UNSUPPORTED;
   if (!workspace || workspace_bytes < distmult_bwd_workspace_bytes(batch, d, r_idx ? r_rows : 0)) return RGCN_ERR_WORKSPACE;

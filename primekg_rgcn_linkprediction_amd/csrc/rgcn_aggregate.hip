@@ -28,7 +28,6 @@
 #include "rgcn_common.h"
 #include "rgcn_slab_reduce.h"
 #include "rgcn_hub_finish.h"
-#include "rgcn_prep.h"
 
 namespace {
 
@@ -209,132 +208,6 @@ __global__ __launch_bounds__(kThreads) void k_aggregate(
   aggregate_block<G, WEIGHTED>((int)blockIdx.x, red, src, items, nitems, col, w, cnt, agg, partial, d, head_col, head_w, amax_out);
 }
 
-// The first gather of a forward pass with the pass's first launch riding at the FRONT of its grid (rgcn_prep.h: max |x|,
-// cleared amax buffers, the layers' split weights): the gather reads x but needs neither result, its successor - the
-// transform - needs both, so the rider's latency chain (12 us as a launch of its own) runs beside the gather's.
-template <int G>
-__global__ __launch_bounds__(kThreads) void k_aggregate_prep(
-    const float* __restrict__ src, const rgcn_item* __restrict__ items, int64_t nitems,
-    const int32_t* __restrict__ col, const float* __restrict__ cnt, float* __restrict__ agg, float* __restrict__ partial,
-    int d, const int32_t* __restrict__ head_col, const rgcn_prep prep, int prep_blocks) {
-  __shared__ float4 red[kThreads];
-  const int b = (int)blockIdx.x;
-  if (b < prep_blocks) {                         // uniform over the workgroup
-    float* fred = reinterpret_cast<float*>(red);
-    const int npack = prep.pack_blocks * prep.layers;
-    if (b < npack) rgcn_pack_body<kThreads>(prep.JJ.j[b / prep.pack_blocks], fred, prep.pack_blocks, b % prep.pack_blocks);
-    else rgcn_absmax_body<kThreads>(prep.J, prep.zero, prep.zero_count, fred, b - npack, RGCN_AMAX_HEADS);
-    return;
-  }
-  aggregate_block<G, false>(b - prep_blocks, red, src, items, nitems, col, nullptr, cnt, agg, partial, d, head_col, nullptr,
-                            nullptr);
-}
-
-// The same gather for degree-skewed structures (rgcn_csr::hot_ids): on the PrimeKG-shaped graph a third of all row
-// reads go to the 64 most read rows of the table.  A workgroup copies the first H hot rows into LDS once (H x d floats:
-// 32 KB at most) and then walks its items like k_aggregate, except that an edge whose id says "hot row of rank s" (the
-// structure's col_hot / head_col_hot arrays: -2 - s) takes the row from LDS - the L2 never sees that read.  To make the
-// copy worth its 32 KB the grid is PERSISTENT: as many workgroups as fit the chip, each taking every gridDim.x-th
-// chunk of 256 / G items (the items are sorted by length, so the workgroups stay balanced).
-// Straight-line inner loop (a per-edge branch made hipcc serialise the eight row loads of a round: 2x slower than the
-// plain gather): every edge issues BOTH a buffer load of the table row and an LDS read of a hot row - the buffer load
-// with an out-of-range offset where the row is hot or the edge does not exist (the hardware returns zeros and sends no
-// request), the LDS read from an all-zero row where the edge is not hot - and the row is the bitwise OR of the two.
-// Same rows, same adds in the same order as k_aggregate: the same bits.
-// MEASURED (MI355X, C2, profiles/r03_hot_rows.txt): SLOWER than the plain gather - d = 128: 50.5 us against 33.6 us with
-// 64 rows (a third of the reads) in LDS, d = 64: 36.4 against 22.5 - so the path is OFF by default (RGCN_HOT_KB=32 /
-// rgcn_hot_rows_kb(32) before the graph is bucketed turns it on).  The gather is not bound by the bytes the L2 delivers
-// but by memory instructions in flight: the variant issues as many per edge, and its 32 KB of rows + 93-108 registers
-// leave 4 waves per SIMD where the plain kernel keeps 8.  Kept as the measured negative result it is.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned kNoRow = 0xfffffff0u;         // a byte offset no table reaches (tables up to 4 GB - 16 take this path)
-
-template <int G, bool WEIGHTED, int H>
-__global__ __launch_bounds__(kThreads) void k_aggregate_hot(
-    const float* __restrict__ src, unsigned table_bytes, const rgcn_item* __restrict__ items, int64_t nitems,
-    const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ cnt,
-    float* __restrict__ agg, float* __restrict__ partial, int d, const int32_t* __restrict__ head_col,
-    const float* __restrict__ head_w, const int32_t* __restrict__ hot_ids, const rgcn_slab_job job, int gather_blocks,
-    int chunks) {
-  __shared__ float4 red[kThreads];               // pack combine (see rgcn_common.h)
-  __shared__ u32x4 hot[(H + 1) * G];             // hot row s, float4 c: hot[s * G + c]; row H: zeros
-  __shared__ int32_t hot_id[RGCN_HOT_MAX];
-  if ((int)blockIdx.x >= gather_blocks) {        // workgroups past the gather: a pending slab reduction rides along
-    rgcn_slab_reduce_block<RGCN_SLAB_OUTS, RGCN_SLAB_GROUPS>(job, (int64_t)blockIdx.x - gather_blocks, red);
-    return;
-  }
-  const int gl = (int)threadIdx.x % G;
-  const int c4 = gl * 4;                         // d == 4 G: every lane of a group carries columns of the row
-  if (threadIdx.x < RGCN_HOT_MAX) hot_id[threadIdx.x] = hot_ids[threadIdx.x];
-  for (int i = threadIdx.x; i < (H + 1) * G; i += kThreads) {
-    const int s = i / G, c = (i % G) * 4;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (s < H) v = *reinterpret_cast<const u32x4*>(src + (size_t)hot_ids[s] * d + c);
-    hot[i] = v;
-  }
-  __syncthreads();
-  const __amdgpu_buffer_rsrc_t table = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)table_bytes, 0x00020000);
-  for (int chunk = blockIdx.x; chunk < chunks; chunk += gather_blocks) {
-    const int64_t item_id = (int64_t)chunk * (kThreads / G) + (int64_t)threadIdx.x / G;
-    const bool have = item_id < nitems;          // whole lane groups only
-    // packs come first in the item order: the chunk's first slot says whether any is in here (uniform over the workgroup)
-    const bool has_packs = (items[(int64_t)chunk * (kThreads / G)].flags & RGCN_ITEM_PACK) != 0;
-    rgcn_item it = rgcn_item{0, 0, 0, RGCN_ITEM_SKIP};
-    if (have) it = items[item_id];
-    float4 acc = f4zero();
-    if (have) {
-      IdWindow<G, WEIGHTED> win;
-      win.init(item_id, gl, it, col, w, head_col, head_w);
-      for (int e = it.begin; e < it.end; e += kUnroll) {
-        int idx[kUnroll];
-        float wt[kUnroll];
-        u32x4 ga[kUnroll], hv[kUnroll];
-        win.get(idx, wt);
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const int id = idx[u];
-          const int s = -2 - id;                 // >= 0: hot row of rank s
-          const bool in_lds = id < -1 && s < H;
-          const int row = id < -1 ? hot_id[s & (RGCN_HOT_MAX - 1)] : id;      // a hot row beyond the H kept ones: by its id
-          const unsigned off = (id == -1 || in_lds) ? kNoRow : ((unsigned)row * (unsigned)d + (unsigned)c4) * 4u;
-          ga[u] = __builtin_amdgcn_raw_buffer_load_b128(table, off, 0, 0);
-          hv[u] = hot[(in_lds ? s : H) * G + gl];
-        }
-        win.advance(gl, col, w);
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-          const u32x4 b = ga[u] | hv[u];
-          const float4 v = make_float4(__uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w));
-          if (WEIGHTED) f4fma(acc, v, wt[u]);
-          else f4add(acc, v);
-        }
-      }
-    }
-    bool writer = have;
-    if (has_packs) {                             // the runs of a pack meet in LDS; its leader adds them in slot order
-      red[threadIdx.x] = acc;
-      __syncthreads();
-      if (it.flags & (RGCN_ITEM_MEMBER | RGCN_ITEM_SKIP)) writer = false;
-      else {
-        const int followers = (it.flags >> RGCN_ITEM_FOLLOW_SHIFT) & (RGCN_PACK - 1);
-        for (int f = 1; f <= followers; ++f) f4add(acc, red[threadIdx.x + f * G]);
-      }
-      __syncthreads();                           // everybody has read `red` before the next chunk writes it
-    }
-    if (writer) {
-      if (it.flags & RGCN_ITEM_FINAL) {
-        if (cnt) {  // mean: true division by max(1, segment size), as `sum / count` does
-          const float c = cnt[it.dst];
-          acc.x /= c; acc.y /= c; acc.z /= c; acc.w /= c;
-        }
-        *reinterpret_cast<float4*>(agg + (size_t)it.dst * d + c4) = acc;
-      } else {
-        *reinterpret_cast<float4*>(partial + (size_t)it.dst * d + c4) = acc;
-      }
-    }
-  }
-}
-
 // fp16 feature table, fp32 accumulate (BASELINE.json configs[4]): the same walk with 8 halves
 // (16 B) per lane, so a row costs half the bytes (132 / 260 B per edge at d = 64 / 128) and a
 // wave64 carries 64 / (d/8) items.  Sums, partial rows and the output stay fp32.
@@ -461,75 +334,6 @@ __global__ __launch_bounds__(kThreads) void k_reduce_partials(const rgcn_item* _
     rgcn_amax_publish(amax_out, lmax);
 }
 
-// LDS rows of the hot-row gather by row width (32 KB of rows; RGCN_HOT_KB=16 halves it, 0 turns the path off) and the
-// coverage below which the plain gather is kept
-// LDS budget of the hot-row gather: 0 = off (the DEFAULT - measured on the MI355X the path is slower than the plain
-// gather, see the kernel's header), 16 or 32 KB; from RGCN_HOT_KB or rgcn_hot_rows_kb().
-int g_hot_kb = -1;                                   // rgcn_hot_rows_kb: -1 = not set (environment / default)
-int hot_kb() {
-  static const int env = [] {
-    const char* e = getenv("RGCN_HOT_KB");
-    const int k = e ? atoi(e) : 0;
-    return (k == 16 || k == 32) ? k : 0;
-  }();
-  return g_hot_kb >= 0 ? g_hot_kb : env;
-}
-int persistent_blocks(int lds_bytes_per_block) {
-  static const int cus = [] {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }();
-  const int per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(1, lds_bytes_per_block)));
-  return cus * per_cu;
-}
-
-template <int G, int H>
-void launch_hot(const rgcn_csr* c, bool weighted, const float* x, const float* cnt, float* agg, float* partial, int d,
-                hipStream_t stream, const rgcn_slab_job* tail) {
-  const int64_t nitems = c->num_items[0];
-  const int chunks = (int)ceil_div64(nitems, kThreads / G);
-  const int lds = (int)sizeof(float4) * (kThreads + (H + 1) * G) + RGCN_HOT_MAX * 4;
-  const unsigned table_bytes = (unsigned)((size_t)c->n_other * (size_t)d * sizeof(float));
-  const int gather_blocks = std::min(chunks, persistent_blocks(lds));
-  const rgcn_slab_job job = tail ? *tail : rgcn_slab_job{};
-  dim3 grid((unsigned)gather_blocks + (tail ? (unsigned)rgcn_slab_reduce_blocks(job) : 0u));
-  if (weighted)
-    k_aggregate_hot<G, true, H><<<grid, kThreads, 0, stream>>>(x, table_bytes, c->items[0], nitems, c->col_hot, c->val, cnt, agg, partial, d,
-                                                               c->head_col_hot, c->head_w, c->hot_ids, job, gather_blocks, chunks);
-  else
-    k_aggregate_hot<G, false, H><<<grid, kThreads, 0, stream>>>(x, table_bytes, c->items[0], nitems, c->col_hot, nullptr, cnt, agg, partial,
-                                                                d, c->head_col_hot, nullptr, c->hot_ids, job, gather_blocks, chunks);
-}
-
-// the hot-row gather for this launch, if the structure is skewed enough for the rows that fit: true = launched
-// rows of the table a gather of d-wide rows over this structure keeps in LDS (0: the plain gather)
-int hot_rows_for(const rgcn_csr* c, int64_t d) {
-  const int kb = hot_kb();
-  if (!c->hot_count || kb == 0 || !(d == 64 || d == 128 || d == 256)) return 0;
-  if ((size_t)c->n_other * (size_t)d * sizeof(float) > (size_t)kNoRow) return 0;      // 32-bit buffer offsets
-  const int h = kb * 1024 / (int)(4 * d);
-  int step = 0;
-  while (step < 3 && RGCN_HOT_STEPS[step] < h) ++step;
-  return c->hot_cover[step] >= 0.10f ? h : 0;
-}
-
-template <int G>
-bool try_hot(const rgcn_csr* c, bool weighted, const float* x, const float* cnt, float* agg, float* partial, int d,
-             hipStream_t stream, const rgcn_slab_job* tail, unsigned* amax_out) {
-  if constexpr (G == 16 || G == 32 || G == 64) {
-    if (amax_out || d != 4 * G) return false;
-    constexpr int H32 = 32 * 1024 / (16 * G), H16 = H32 / 2;    // rows in 32 KB / 16 KB
-    const int h = hot_rows_for(c, d);
-    if (h == 0) return false;
-    if (h == H32) launch_hot<G, H32>(c, weighted, x, cnt, agg, partial, d, stream, tail);
-    else launch_hot<G, H16>(c, weighted, x, cnt, agg, partial, d, stream, tail);
-    return true;
-  }
-  return false;
-}
-
 template <int G>
 void launch_level(const rgcn_csr* c, int level, bool weighted, const float* x, const float* cnt, float* agg,
                   float* partial, int d, hipStream_t stream, const rgcn_slab_job* tail = nullptr,
@@ -538,7 +342,6 @@ void launch_level(const rgcn_csr* c, int level, bool weighted, const float* x, c
   if (nitems == 0) return;
   const unsigned gy = (unsigned)ceil_div64(d, 4 * G);
   if (level == 0) {
-    if (gy == 1 && try_hot<G>(c, weighted, x, cnt, agg, partial, d, stream, tail, amax_out)) return;
     const unsigned gather_blocks = (unsigned)ceil_div64(nitems, kThreads / G);
     const rgcn_slab_job job = tail ? *tail : rgcn_slab_job{};
     dim3 grid(gather_blocks + (tail ? (unsigned)rgcn_slab_reduce_blocks(job) : 0u), gy);   // tail only with gy == 1
@@ -639,51 +442,6 @@ int rgcn_aggregate(const rgcn_graph* g, int transposed, const float* x, int64_t 
   if (!g) return RGCN_ERR_ARG;
   return aggregate_levels(g, transposed, 0, g->dir[transposed ? 1 : 0].num_levels, x, d, agg, workspace,
                           workspace_bytes, stream);
-}
-
-int rgcn_aggregate_prep(const rgcn_graph* g, int transposed, const float* x, int64_t d, float* agg, void* workspace,
-                        size_t workspace_bytes, int deferred, float* x_amax, float* zero_buffers, int zero_count, int count,
-                        const float* const* weights, const float* const* roots, const int64_t* R, const int64_t* d_in,
-                        const int64_t* d_out, void* const* packed, const size_t* packed_bytes, void* stream_) {
-  if (!g || !agg || !x || !(d == 64 || d == 128 || d == 256)) return RGCN_ERR_ARG;
-  const rgcn_csr* c = &g->dir[transposed ? 1 : 0];
-  if (!c->rowptr || c->weighted || c->num_items[0] <= 0) return RGCN_ERR_UNSUPPORTED;      // mean structures with work
-  if (deferred && !rgcn_aggregate_deferrable(g, transposed, d)) return RGCN_ERR_UNSUPPORTED;
-  if (c->num_partials > 0 && (!workspace || workspace_bytes < (size_t)c->num_partials * (size_t)d * sizeof(float)))
-    return RGCN_ERR_WORKSPACE;
-  rgcn_prep p;
-  const int rc = rgcn_prep_fill(x, c->n_other * d, x_amax, zero_buffers, zero_count, count, weights, roots, R, d_in, d_out,
-                                packed, packed_bytes, kThreads, &p);
-  if (rc != RGCN_OK) return rc;
-  hipStream_t stream = (hipStream_t)stream_;
-  const int prep_blocks = p.pack_blocks * p.layers + RGCN_AMAX_HEADS;
-  const int64_t nitems = c->num_items[0];
-  float* partial = (float*)workspace;
-  auto launch = [&](auto gtag) {
-    constexpr int G = decltype(gtag)::value;
-    const unsigned gather_blocks = (unsigned)ceil_div64(nitems, kThreads / G);
-    k_aggregate_prep<G><<<gather_blocks + (unsigned)prep_blocks, kThreads, 0, stream>>>(x, c->items[0], nitems, c->col, c->val,
-                                                                                      agg, partial, (int)d, c->head_col, p,
-                                                                                      prep_blocks);
-  };
-  if (d == 64) launch(std::integral_constant<int, 16>{});
-  else if (d == 128) launch(std::integral_constant<int, 32>{});
-  else launch(std::integral_constant<int, 64>{});
-  RGCN_HIP_TRY(hipGetLastError());
-  if (deferred) return RGCN_OK;
-  return aggregate_levels(g, transposed, 1, c->num_levels, x, d, agg, workspace, workspace_bytes, stream_);
-}
-
-int rgcn_aggregate_hot_rows(const rgcn_graph* g, int transposed, int64_t d) {
-  if (!g) return 0;
-  return hot_rows_for(&g->dir[transposed ? 1 : 0], d);
-}
-
-int rgcn_hot_rows_kb(int kb) {
-  const int before = hot_kb();
-  if (kb == 0 || kb == 16 || kb == 32) g_hot_kb = kb;
-  else if (kb == -1) g_hot_kb = -1;                  // back to RGCN_HOT_KB / the default; any other value: query only
-  return before;
 }
 
 int rgcn_aggregate_deferrable(const rgcn_graph* g, int transposed, int64_t d) {

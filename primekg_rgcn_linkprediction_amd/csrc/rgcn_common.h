@@ -73,20 +73,7 @@ struct rgcn_csr {
   // max over segments of sum of |weights| (weighted mode; 1 in mean mode): |agg row| <= weight_bound * max |x|.
   // The split-precision transforms scale the aggregate operand by this bound instead of scanning it.
   float weight_bound = 1.f;
-  // Hot rows (degree-skewed graphs): the RGCN_HOT_MAX rows of the gathered table that this structure's edges read
-  // most often, by descending count (hot_ids), and a copy of col / head_col in which an edge that reads hot row of
-  // rank s carries the id -2 - s instead (-1 stays "no edge").  A gather workgroup keeps the first H of them in LDS
-  // (H by row width) and serves those edges from there instead of from L2: on the PrimeKG-shaped graph the 64 most
-  // read rows are a third of all row reads.  hot_cover[k]: fraction of the edges that read one of the first
-  // RGCN_HOT_STEPS[k] hot rows; hot_count == 0 (and the pointers NULL) when the structure has no skew worth it.
-  int32_t* hot_ids = nullptr;       // [RGCN_HOT_MAX]
-  int32_t* col_hot = nullptr;       // [E]
-  int32_t* head_col_hot = nullptr;  // [num_items[0] * RGCN_HEAD]
-  int hot_count = 0;
-  float hot_cover[4] = {0.f, 0.f, 0.f, 0.f};
 };
-constexpr int RGCN_HOT_MAX = 128;
-constexpr int RGCN_HOT_STEPS[4] = {16, 32, 64, 128};
 
 struct rgcn_graph {
   int64_t E = 0, N = 0, R = 0;

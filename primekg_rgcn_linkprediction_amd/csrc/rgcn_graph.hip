@@ -209,9 +209,6 @@ void free_csr(rgcn_csr* c) {
   (void)hipFree(c->fin_ptr);
   (void)hipFree(c->head_col);
   (void)hipFree(c->head_w);
-  (void)hipFree(c->hot_ids);
-  (void)hipFree(c->col_hot);
-  (void)hipFree(c->head_col_hot);
   for (int l = 0; l < RGCN_MAX_LEVELS; ++l) (void)hipFree(c->items[l]);
   *c = rgcn_csr();
 }
@@ -296,86 +293,6 @@ __global__ void k_item_heads(const rgcn_item* __restrict__ items, int64_t nitems
   if (head_w) head_w[i] = ok ? w[e] : 0.f;
 }
 
-// ---- hot rows (see rgcn_csr::hot_ids) -------------------------------------------------------------------------
-__global__ void k_hot_count(const int32_t* __restrict__ col, int64_t E, uint32_t* __restrict__ counts) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < E) atomicAdd(&counts[col[e]], 1u);
-}
-__global__ void k_iota(uint32_t* __restrict__ ids, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) ids[i] = (uint32_t)i;
-}
-__global__ void k_hot_rank(const uint32_t* __restrict__ sorted_ids, int hot, int32_t* __restrict__ rank_of,
-                           int32_t* __restrict__ hot_ids) {
-  const int s = (int)threadIdx.x;
-  if (s < hot) {
-    rank_of[sorted_ids[s]] = s;
-    hot_ids[s] = (int32_t)sorted_ids[s];
-  }
-}
-__global__ void k_hot_encode(const int32_t* __restrict__ ids, int64_t n, const int32_t* __restrict__ rank_of,
-                             int32_t* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int32_t id = ids[i];
-  const int32_t rk = id >= 0 ? rank_of[id] : -1;
-  out[i] = rk >= 0 ? -2 - rk : id;
-}
-
-// Runs only while the hot-row gather is switched on (rgcn_hot_rows_kb() != 0 when the structure is bucketed: off by
-// default); the minimum coverage a structure needs is 10 % of its edges on its RGCN_HOT_MAX most read rows - a uniform
-// graph (C4) never gets there and keeps the plain gather.
-int find_hot_rows(rgcn_csr* c, int64_t E, hipStream_t stream) {
-  const bool enabled = rgcn_hot_rows_kb(-2) != 0;            // -2: query only
-  const int64_t n = c->n_other;
-  if (!enabled || E < 4096 || n < 4 * RGCN_HOT_MAX || n > (int64_t)1 << 30 || c->num_items[0] <= 0) return RGCN_OK;
-  struct Tmp {
-    uint32_t *counts = nullptr, *ids = nullptr, *scounts = nullptr, *sids = nullptr;
-    int32_t* rank_of = nullptr;
-    void* sort_tmp = nullptr;
-    ~Tmp() { (void)hipFree(counts); (void)hipFree(ids); (void)hipFree(scounts); (void)hipFree(sids); (void)hipFree(rank_of); (void)hipFree(sort_tmp); }
-  } t;
-  RGCN_HIP_TRY(hipMalloc((void**)&t.counts, n * sizeof(uint32_t)));
-  RGCN_HIP_TRY(hipMalloc((void**)&t.ids, n * sizeof(uint32_t)));
-  RGCN_HIP_TRY(hipMalloc((void**)&t.scounts, n * sizeof(uint32_t)));
-  RGCN_HIP_TRY(hipMalloc((void**)&t.sids, n * sizeof(uint32_t)));
-  RGCN_HIP_TRY(hipMemsetAsync(t.counts, 0, n * sizeof(uint32_t), stream));
-  k_hot_count<<<grid_for(E), kThreads, 0, stream>>>(c->col, E, t.counts);
-  k_iota<<<grid_for(n), kThreads, 0, stream>>>(t.ids, n);
-  size_t tmp_bytes = 0;
-  RGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, t.counts, t.scounts, t.ids, t.sids, (int)n, 0,
-                                                             32, stream));
-  RGCN_HIP_TRY(hipMalloc(&t.sort_tmp, tmp_bytes + 256));
-  // (a stable sort: rows of equal count keep ascending id order, so the hot set is a function of the structure alone)
-  RGCN_HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(t.sort_tmp, tmp_bytes, t.counts, t.scounts, t.ids, t.sids, (int)n, 0,
-                                                             32, stream));
-  uint32_t top[RGCN_HOT_MAX];
-  RGCN_HIP_TRY(hipMemcpyAsync(top, t.scounts, sizeof(top), hipMemcpyDeviceToHost, stream));
-  RGCN_HIP_TRY(hipStreamSynchronize(stream));
-  double run = 0.0;
-  for (int s = 0, k = 0; s < RGCN_HOT_MAX; ++s) {
-    run += top[s];
-    if (s + 1 == RGCN_HOT_STEPS[k]) c->hot_cover[k++] = (float)(run / (double)E);
-  }
-  if (c->hot_cover[3] < 0.10f) {
-    for (float& f : c->hot_cover) f = 0.f;
-    return RGCN_OK;
-  }
-  RGCN_HIP_TRY(hipMalloc((void**)&t.rank_of, n * sizeof(int32_t)));
-  RGCN_HIP_TRY(hipMemsetAsync(t.rank_of, 0xff, n * sizeof(int32_t), stream));              // -1 everywhere
-  RGCN_HIP_TRY(hipMalloc((void**)&c->hot_ids, RGCN_HOT_MAX * sizeof(int32_t)));
-  RGCN_HIP_TRY(hipMalloc((void**)&c->col_hot, E * sizeof(int32_t)));
-  const int64_t nh = c->num_items[0] * RGCN_HEAD;
-  RGCN_HIP_TRY(hipMalloc((void**)&c->head_col_hot, nh * sizeof(int32_t)));
-  k_hot_rank<<<1, RGCN_HOT_MAX, 0, stream>>>(t.sids, RGCN_HOT_MAX, t.rank_of, c->hot_ids);
-  k_hot_encode<<<grid_for(E), kThreads, 0, stream>>>(c->col, E, t.rank_of, c->col_hot);
-  k_hot_encode<<<grid_for(nh), kThreads, 0, stream>>>(c->head_col, nh, t.rank_of, c->head_col_hot);
-  RGCN_HIP_TRY(hipGetLastError());
-  RGCN_HIP_TRY(hipStreamSynchronize(stream));
-  c->hot_count = RGCN_HOT_MAX;
-  return RGCN_OK;
-}
-
 int plan_structure(rgcn_csr* c, int64_t R, hipStream_t stream) {
   const int64_t NR = c->n_key * R;
   std::vector<int32_t> rp((size_t)NR + 1);
@@ -412,7 +329,6 @@ int plan_structure(rgcn_csr* c, int64_t R, hipStream_t stream) {
                                                                    c->weighted ? c->val : nullptr, c->head_col,
                                                                    c->head_w);
     RGCN_HIP_TRY(hipGetLastError());
-    TRY_PLAN(find_hot_rows(c, (int64_t)rp[(size_t)NR], stream));
   }
   return RGCN_OK;
 }

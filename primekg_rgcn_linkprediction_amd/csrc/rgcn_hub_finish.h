@@ -3,7 +3,6 @@
 // transforms, which finish the hub rows of their own row tile themselves (rgcn_transform_split.hip) - so that both
 // give the same bits.
 #pragma once
-#include <hip/hip_fp16.h>
 #include "rgcn_common.h"
 
 #ifndef RGCN_REDUCE_UNROLL
@@ -17,32 +16,9 @@
 // + 4 G) of the row.  FINAL items: divided by cnt[dst] (mean structures) and written to agg row `dst`; others to
 // partial row `dst`.  Returns the lane's max |final value| (0 elsewhere).  Ends with every thread past its reads
 // of `red` only after a barrier at the START of the next call - callers that reuse `red` differently add their own.
-// PLANES (round 4): a FINAL row goes out as the gather's plane-writing mode would have written it - the four values of
-// a lane as fp16 hi / lo under `po.scale` into po.hi / po.lo (row-major, d halves per row) - instead of fp32 into agg.
-struct rgcn_plane_out {
-  __half* hi;
-  __half* lo;
-  float scale;
-};
-__device__ inline void rgcn_store_planes4(const rgcn_plane_out& po, size_t at, const float4 s) {
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  const float v[4] = {s.x * po.scale, s.y * po.scale, s.z * po.scale, s.w * po.scale};
-  h4 h, l;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const _Float16 hh = (_Float16)v[j];
-    h[j] = hh;
-    l[j] = (_Float16)(v[j] - (float)hh);
-  }
-  *reinterpret_cast<f2*>(po.hi + at) = __builtin_bit_cast(f2, h);
-  *reinterpret_cast<f2*>(po.lo + at) = __builtin_bit_cast(f2, l);
-}
-
-template <int G, bool PLANES = false>
+template <int G>
 __device__ inline float rgcn_reduce_item(const rgcn_item it, const float* __restrict__ cnt, float* __restrict__ agg,
-                                         float* partial, int d, int col0, float4* red,
-                                         const rgcn_plane_out po = rgcn_plane_out{}) {
+                                         float* partial, int d, int col0, float4* red) {
   constexpr int SLOTS = 256 / G;
   const int gl = (int)threadIdx.x % G, slot = (int)threadIdx.x / G;
   const int c4 = (gl + col0) * 4;
@@ -78,8 +54,7 @@ __device__ inline float rgcn_reduce_item(const rgcn_item it, const float* __rest
         const float c = cnt[it.dst];
         s.x /= c; s.y /= c; s.z /= c; s.w /= c;
       }
-      if (PLANES) rgcn_store_planes4(po, (size_t)it.dst * d + c4, s);
-      else *reinterpret_cast<float4*>(agg + (size_t)it.dst * d + c4) = s;
+      *reinterpret_cast<float4*>(agg + (size_t)it.dst * d + c4) = s;
       lmax = fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w)));
     } else {
       *reinterpret_cast<float4*>(partial + (size_t)it.dst * d + c4) = s;

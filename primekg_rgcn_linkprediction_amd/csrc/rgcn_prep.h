@@ -1,10 +1,10 @@
 // The first launch of a pass - max |x| of its input table, cleared amax buffers, the layers' split weight images -
-// as device bodies that more than one kernel can run: the stand-alone launches of rgcn_transform_split.hip
-// (k_absmax_multi, k_pack_split, k_absmax_pack: 1,024-thread workgroups) and, as extra workgroups at the front of its
-// grid, the first gather of a forward pass (rgcn_aggregate_prep, rgcn_aggregate.hip: 256-thread workgroups) - that
-// gather reads the table but needs neither its maximum nor the weights, so the 12 us latency chain of the stand-alone
-// launch runs beside it instead of before it.  Same values whatever the workgroup size (a maximum has no order; every
-// element is split by itself).
+// as device bodies templated on the workgroup size (k_absmax_multi, k_pack_split, k_absmax_pack of
+// rgcn_transform_split.hip run them with 1,024 threads).  Round 3 also ran them as 256-thread riders at the front of
+// conv1's gather (rgcn_aggregate_prep, in git history): bit-identical and 5 us per step SLOWER - each rider scans its
+// layer's weights for their maximum itself, 8 rounds of loads in 256 threads instead of 2 in 1,024, and outlasts the
+// gather it was meant to hide behind (profiles/r03_prep_rides.txt).  Same values whatever the workgroup size (a
+// maximum has no order; every element is split by itself).
 #pragma once
 #include "rgcn_split.h"
 

@@ -130,11 +130,6 @@ int rgcn_sequence_run(const rgcn_seq_call* calls, int num_calls, const rgcn_seq_
         rc = rgcn_layer_bwd_input_fused((const int32_t*)P(0), (const int32_t*)P(1), CF(2), (const uint32_t*)P(3), I(4), I(5),
                                         CF(6), CF(7), P(8), (int)I(9), CF(10), I(11), I(12), CF(13), F(14), MF(15), MF(16),
                                         P(17), F(18)); break;
-      case RGCN_FN_AGGREGATE_PREP: NEED(20);
-        rc = rgcn_aggregate_prep(G(0), (int)I(1), CF(2), I(3), MF(4), P(5), (size_t)I(6), (int)I(7), MF(8), MF(9), (int)I(10),
-                                 (int)I(11), (const float* const*)P(12), (const float* const*)P(13), (const int64_t*)P(14),
-                                 (const int64_t*)P(15), (const int64_t*)P(16), (void* const*)P(17), (const size_t*)P(18),
-                                 P(19)); break;
       default: return RGCN_ERR_UNSUPPORTED;
     }
 #undef P

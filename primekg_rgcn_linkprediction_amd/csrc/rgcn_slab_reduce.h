@@ -41,11 +41,9 @@ __device__ inline void rgcn_slab_reduce_block(const rgcn_slab_job& J, int64_t bl
       const float4 v = *reinterpret_cast<const float4*>(p + (size_t)i * stride);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-  } else if (J.grad_bias && q - nq < (N + 3) / 4) {            // tail outputs: bias partials (their own row count)
+  } else if (J.grad_bias && q - nq < (N + 3) / 4) {            // tail outputs: bias partials
     const int n = (int)(q - nq) * 4;
-    const int SB = J.bias_splits > 0 ? J.bias_splits : S;
-    const int b0 = (int)((int64_t)SB * grp / GROUPS), b1 = (int)((int64_t)SB * (grp + 1) / GROUPS);
-    for (int i = b0; i < b1; ++i) {
+    for (int i = s0; i < s1; ++i) {
       const float* b = J.bias_part + (size_t)i * N + n;
       acc.x += b[0];
       if (n + 1 < N) acc.y += b[1];

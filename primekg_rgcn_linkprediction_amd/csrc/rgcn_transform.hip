@@ -815,21 +815,11 @@ struct SplitPlan { int kc_tiles, n_tiles, splits, rows_per_split; };
 
 constexpr int TN_TKC = 64;          // kc columns per workgroup of k_gemm_tn_slab<1>
 
-int tn_blocks_override() {          // RGCN_TN_BLOCKS: workgroups per launch (A/B runs); 0 = automatic
-  static const int v = [] {
-    const char* e = getenv("RGCN_TN_BLOCKS");
-    const int x = e ? atoi(e) : 0;
-    return x > 0 ? x : 0;
-  }();
-  return v;
-}
-
 // Workgroups per launch.  Slab bytes (and the reduce that follows) scale with the count, so a
 // graph of C2's size gets one workgroup per CU (measured best); once every workgroup still has
 // >= 2,048 rows to stream, two per CU are worth their slabs: the second wave per SIMD covers
 // the per-tile barrier (C4 on one GPU: 2.5 -> 2.0 ms per launch).
 int tn_target_blocks(int64_t M, int tiles) {
-  if (tn_blocks_override()) return tn_blocks_override();
   return M / std::max(1, 512 / tiles) >= 2048 ? 512 : 256;
 }
 
@@ -847,38 +837,14 @@ SplitPlan plan_splits(int64_t M, int64_t Kc, int64_t N) {
   return p;
 }
 
-int tn_wave_groups() {                // wave groups per workgroup of the parameter-gradient GEMM; RGCN_TN_WG=1 for A/B runs
-  static const int v = [] {
-    const char* e = getenv("RGCN_TN_WG");
-    return (e && e[0] == '1') ? 1 : 2;
-  }();
-  return v;
-}
-
-bool force_plain_gemm() {             // RGCN_GEMM=plain: register-staged kernel for every shape (A/B runs)
-  static const bool v = [] {
-    const char* e = getenv("RGCN_GEMM");
-    return e && e[0] == 'p';
-  }();
-  return v;
-}
-
-bool use_tile_masks() {               // RGCN_TILE_MASK=0 disables the relation-occupancy skipping (A/B runs)
-  static const bool v = [] {
-    const char* e = getenv("RGCN_TILE_MASK");
-    return !(e && e[0] == '0');
-  }();
-  return v;
-}
 
 template <int BMODE, int EPI>
 void launch_nt(const float* A1, int K1, const float* A2, int K2, const float* W, const float* Rt, int dk,
                const float* bias, const float* mask, float* C, int M, int N, const uint32_t* tile_mask, int kseg,
                hipStream_t stream) {
-  const bool dma_ok = (K1 % BK == 0) && (K2 % BK == 0) && (K1 + K2 > 0) && (BMODE == B_KN || dk % BK == 0) &&
-                      !force_plain_gemm();
+  const bool dma_ok = (K1 % BK == 0) && (K2 % BK == 0) && (K1 + K2 > 0) && (BMODE == B_KN || dk % BK == 0);
   if (dma_ok) {
-    if (!use_tile_masks() || kseg <= 0 || kseg % BK != 0) tile_mask = nullptr;
+    if (kseg <= 0 || kseg % BK != 0) tile_mask = nullptr;
     if (N <= 64) {
       dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 64));
       k_gemm_nt_dma<1, BMODE, EPI><<<grid, kThreads, 0, stream>>>(A1, K1, A2, K2, W, Rt, dk, bias, mask, C, M, N,
@@ -1038,20 +1004,17 @@ int rgcn_transform_bwd_params_begin(const float* agg, const float* x, const floa
     return RGCN_OK;
   }
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
-  if (K1 % 64 == 0 && K2 % 64 == 0 && !force_plain_gemm())
+  if (K1 % 64 == 0 && K2 % 64 == 0)
   {
-    const uint32_t* tmask = (use_tile_masks() && d_in % 64 == 0) ? tile_mask : nullptr;
+    const uint32_t* tmask = (d_in % 64 == 0) ? tile_mask : nullptr;
     const bool one_per_cu = (int64_t)grid.x * grid.y <= 320;    // deeper ring when LDS need not hold two workgroups
     float* bp = grad_bias ? bias_part : nullptr;
-    if (tn_wave_groups() == 2 && one_per_cu)
+    if (one_per_cu)                             // (two wave groups per workgroup; one measured slower)
       k_gemm_tn_dma<2, 4><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
                                                              p.rows_per_split, slab, bp, tmask, (int)d_in);
-    else if (tn_wave_groups() == 2)
+    else
       k_gemm_tn_dma<2, 3><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
                                                              p.rows_per_split, slab, bp, tmask, (int)d_in);
-    else
-      k_gemm_tn_dma<1, 3><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,
-                                                         p.rows_per_split, slab, bp, tmask, (int)d_in);
   }
   else
     k_gemm_tn_slab<1><<<grid, kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles,

@@ -25,7 +25,6 @@
 // operand is split once per call by k_pack_split into two k-contiguous fp16 images Bh / Bl [n][K].
 #include <algorithm>
 #include <cstdlib>
-#include <type_traits>
 
 #include <hip/hip_fp16.h>
 
@@ -149,18 +148,8 @@ struct hub_fin {
   int d, tiles;
 };
 
-// A1P: the A1 operand arrives as planes (round 4): A1 / A1lo are its hi / lo fp16 images [M][K1] under the scale of amax1 *
-// a1_mul, written by the gather; its k-tiles are then staged exactly like B's (16 rows of 64 B per wave instruction)
-// and go to the MFMAs as they are - no vector ALU work in those tiles.  emit: the fp32 blocks that ARE split in the k
-// loop can leave their hi / lo values behind as planes (row stride = the block's width) for the parameter-gradient
-// GEMM, which then converts nothing (k_gemm_tn_planes): e1 for A1 (when !A1P), e2 for A2; written by the first wave
-// column only, rows < M.
-struct nt_emit {
-  __half *e1h, *e1l, *e2h, *e2l;
-};
-
-template <int WM, int WN, int TN, int EPI, bool LO, bool A1P = false>
-__global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __restrict__ A1, const __half* __restrict__ A1lo, int K1,
+template <int WM, int WN, int TN, int EPI, bool LO>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __restrict__ A1, int K1,
                                                             const float* __restrict__ A2, int K2,
                                                             const __half* __restrict__ Bh,
                                                             const __half* __restrict__ Bl,
@@ -170,14 +159,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
                                                             const float* __restrict__ mask, float* __restrict__ C,
                                                             int M, int N, const uint32_t* __restrict__ tile_mask,
                                                             int kseg, unsigned* __restrict__ amax_out,
-                                                            const hub_fin fin, float out_scale, const nt_emit emit) {
-  static_assert(!A1P || LO, "planes carry both parts");
+                                                            const hub_fin fin, float out_scale) {
   constexpr int WAVES = WM * WN;                 // WM wave rows (32 output rows each) x WN wave columns (32 TN columns each)
-#ifdef RGCN_PROBE_DEPTH3                          // tools/gemm_stamps: one-pass (16 KB) slots in a ring of four - 2 workgroups per CU as before, 3 tiles in flight
-  constexpr int BM = 32 * WM, BN = 32 * TN * WN, NBUF = (WM == 2 && LO) ? 3 : 4, D = NBUF - 1;
-#else
   constexpr int BM = 32 * WM, BN = 32 * TN * WN, NBUF = WM == 2 ? 3 : 4, D = NBUF - 1;   // D k-tiles in flight
-#endif
   constexpr int PARTS = LO ? 2 : 1;              // B images staged: hi (and lo)
   constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + PARTS * B_BYTES;
   constexpr int A_PW = BM / (8 * WAVES);         // A DMA instructions per wave and k-tile (8 rows of 128 B each)
@@ -219,17 +203,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
     if (je > jb) {
       float4* red = reinterpret_cast<float4*>(lds);
       float* agg = const_cast<float*>(A1);
-      // (planes: the finished row is written as the gather would have written it - hi / lo under the aggregate's scale)
-      rgcn_plane_out po{};
-      if (A1P) po = rgcn_plane_out{reinterpret_cast<__half*>(agg), const_cast<__half*>(A1lo), pow2f(scale_exponent(amax1_v))};
       for (int j = jb; j < je; ++j) {
         // two scratch areas in turn: the barrier inside item j + 1 is what separates item j's reads of its area
         // from item j + 2's writes to it - one barrier per item
         float4* scratch = red + ((j - jb) & 1) * 256;
         const rgcn_item it = fin.items[j];
-        if (fin.d == 64) rgcn_reduce_item<16, A1P>(it, fin.cnt, agg, fin.partial, 64, 0, scratch, po);
-        else if (fin.d == 128) rgcn_reduce_item<32, A1P>(it, fin.cnt, agg, fin.partial, 128, 0, scratch, po);
-        else rgcn_reduce_item<64, A1P>(it, fin.cnt, agg, fin.partial, 256, 0, scratch, po);
+        if (fin.d == 64) rgcn_reduce_item<16>(it, fin.cnt, agg, fin.partial, 64, 0, scratch);
+        else if (fin.d == 128) rgcn_reduce_item<32>(it, fin.cnt, agg, fin.partial, 128, 0, scratch);
+        else rgcn_reduce_item<64>(it, fin.cnt, agg, fin.partial, 256, 0, scratch);
       }
       __threadfence_block();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the rows are in L2 before this workgroup's DMAs ask for them
@@ -259,37 +240,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
     b_off[j] = (size_t)n * K + chunk * 8;                        // halves
   }
 
-  // A1 as planes: hi image [BM][32 halves] then lo image, 16 rows of 64 B per wave instruction, the chunk swizzle of B
-  constexpr int AP_PW = A_PW / 2;                                // per wave, k-tile and plane
-  static_assert(!A1P || (A_PW % 2 == 0 && AP_PW * 16 * WAVES == BM), "plane staging layout");
-  size_t ap_off[AP_PW > 0 ? AP_PW : 1];
-  if (A1P) {
-#pragma unroll
-    for (int j = 0; j < AP_PW; ++j) {
-      const int row = (wave * AP_PW + j) * 16 + (lane >> 2);
-      const int chunk = (lane & 3) ^ ((row >> 1) & 3);
-      ap_off[j] = (size_t)min(m0 + row, M - 1) * K1 + chunk * 8;   // halves
-    }
-  }
   auto stage = [&](int kt, int buf) {
     char* sA = lds + buf * BUF_BYTES;
     char* sBh = sA + A_BYTES;
     char* sBl = sBh + B_BYTES;
     const bool first = kt < K1;                                  // a k-tile lies in one A operand (K1 % 32 == 0)
-    if (A1P && first) {
-      const __half* a1h = reinterpret_cast<const __half*>(A1);
+    const float* abase = first ? A1 + kt : A2 + (kt - K1);
+    const int lda = first ? K1 : K2;
 #pragma unroll
-      for (int j = 0; j < AP_PW; ++j) {
-        glds16(a1h + kt + ap_off[j], sA + (wave * AP_PW + j) * 16 * BK * 2);
-        glds16(A1lo + kt + ap_off[j], sA + A_BYTES / 2 + (wave * AP_PW + j) * 16 * BK * 2);
-      }
-    } else {
-      const float* abase = first ? A1 + kt : A2 + (kt - K1);
-      const int lda = first ? K1 : K2;
-#pragma unroll
-      for (int j = 0; j < A_PW; ++j)
-        glds16(abase + ((size_t)a_m[j] * lda + a_c4[j]), sA + (wave * A_PW + j) * 8 * BK * 4);
-    }
+    for (int j = 0; j < A_PW; ++j)
+      glds16(abase + ((size_t)a_m[j] * lda + a_c4[j]), sA + (wave * A_PW + j) * 8 * BK * 4);
 #pragma unroll
     for (int j = 0; j < B_PW; ++j) {
       glds16(Bh + kt + b_off[j], sBh + (wave * B_PW + j) * 16 * BK * 2);
@@ -333,20 +293,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
     }
   }
 
-  unsigned ap_addr[2];                             // planes: the hi fragment of step s (lo: + A_BYTES / 2)
-#pragma unroll
-  for (int s = 0; s < 2; ++s) ap_addr[s] = (unsigned)(arow * BK * 2 + (((2 * s + lh) ^ ((arow >> 1) & 3)) << 4));
-  const int erow = m0 + arow;                      // the row this lane's A fragments belong to (emission)
-
   int t = 0;
   // one k-tile: wait, barrier, fragment reads, next DMA issue, split of A, MFMAs.  `sa`: the scale of the A
   // operand this tile lies in.  The k loop runs the A1 tiles, re-expresses the sums in A2's scale ONCE, then runs
   // the A2 tiles - with the rescale inside one loop hipcc turns it into a select and multiplies all accumulators
   // (and shuttles them between the register files) in EVERY iteration: 100 of 150 vector instructions per k-tile.
-  // `planes`: this tile's A operand is staged as hi / lo images (A1P tiles); em_h / em_l: where the split values of an
-  // fp32 tile go (row stride em_ld halves, column em_k0 + ...), or NULL
-  auto k_tile = [&](const float sa, auto planes_tag, __half* em_h, __half* em_l, int em_ld, int em_k0) {
-    constexpr bool PL = decltype(planes_tag)::value;
+  auto k_tile = [&](const float sa) {
     // k-tile ktq[0] has landed for this wave (all but the DMAs of the tiles staged behind it are done), then for
     // every wave; the barrier also says all waves are done reading the buffer the stage() below refills
     if (D == 3 && ktq[D - 1] < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
@@ -357,13 +309,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
     f32x4 fa[2][2], fh[2][TN], fl[2][TN];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {                // inline asm: hipcc would drain vmcnt(0) before a plain LDS read
-      if constexpr (PL) {
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s][0]) : "v"(ap_addr[s] + buf));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[s][1]) : "v"(ap_addr[s] + buf), "n"(A_BYTES / 2));
-      } else {
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s][0]) : "v"(a_addr[s][0] + buf));
-        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s][1]) : "v"(a_addr[s][1] + buf));
-      }
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s][0]) : "v"(a_addr[s][0] + buf));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(fa[s][1]) : "v"(a_addr[s][1] + buf));
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(fh[s][b]) : "v"(b_addr[b][s] + buf));
@@ -400,25 +347,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
       }
       // split the lane's 8 k of A: v = a * 2^ea; hi = fp16(v); lo = fp16(v - hi)
       half8 ah, al;
-      if constexpr (PL) {                          // the gather split these values: they go to the MFMAs as they are
-        ah = __builtin_bit_cast(half8, fa[s][0]);
-        al = __builtin_bit_cast(half8, fa[s][1]);
-      } else {
+      // (round 4 measured this split as FREE: with the aggregate delivered as ready fp16 hi / lo planes the k-tile takes
+      // the same ~1 us - profiles/r04_planes_probe.txt)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+      for (int q = 0; q < 2; ++q)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float v = fa[s][q][c] * sa;
-            const _Float16 h = (_Float16)v;
-            ah[4 * q + c] = h;
-            if (LO) al[4 * q + c] = (_Float16)(v - (float)h);
-          }
-        if (em_h && wn == 0 && erow < M) {         // the parameter-gradient GEMM reads these instead of splitting again
-          const size_t at = (size_t)erow * em_ld + em_k0 + 16 * s + 8 * lh;
-          *reinterpret_cast<f32x4*>(em_h + at) = __builtin_bit_cast(f32x4, ah);
-          if (LO) *reinterpret_cast<f32x4*>(em_l + at) = __builtin_bit_cast(f32x4, al);
+        for (int c = 0; c < 4; ++c) {
+          const float v = fa[s][q][c] * sa;
+          const _Float16 h = (_Float16)v;
+          ah[4 * q + c] = h;
+          if (LO) al[4 * q + c] = (_Float16)(v - (float)h);
         }
-      }
       // small terms first - per accumulator al*bh, ah*bl, ah*bh, as ever (the same bits) - issued pass by pass, so that
       // consecutive MFMAs write different accumulators and none waits for its predecessor's result
       if (LO) {
@@ -435,20 +374,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
     }
   };
   RGCN_STAMP(1);
-  while (ktq[0] < K1) {
-    const int kt = ktq[0];
-    k_tile(sa1, std::integral_constant<bool, A1P>{}, A1P ? nullptr : emit.e1h, emit.e1l, K1, kt);
-  }
+  while (ktq[0] < K1) k_tile(sa1);
   if (K2 > 0) {                                  // sums so far -> A2's scale (two exact power-of-two factors)
     const float down = pow2f(-ea1);
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][r] = acc[b][r] * down * sa2;
-    while (ktq[0] < K) {
-      const int kt = ktq[0];
-      k_tile(sa2, std::false_type{}, emit.e2h, emit.e2l, K2, kt - K1);
-    }
+    while (ktq[0] < K) k_tile(sa2);
   }
 
   RGCN_STAMP(2);
@@ -555,220 +488,15 @@ __global__ __launch_bounds__(kPackThreads) void k_absmax_pack(const absmax_multi
 
 // ---------------------------------------------------------------------------------------
 // slab[s][kc][n] = sum over the node rows of split s of [A1 | A2][m][kc] * G[m][n], split precision.
-// 128 kc x 128 n per 512-thread workgroup (eight waves, 4 kc x 2 n, a 32 x 64 block each), 32-row m-tiles
-// global -> LDS by LDS-DMA (fp32) through a ring of four buffers (three m-tiles = 96 KB in flight per CU:
-// this kernel streams both operands once and runs at the rate its bytes in flight allow), a split's tiles
-// placed on one XCD, relation-occupancy skipping of all-zero m-tiles.  Against the 64 kc tile of
-// k_gemm_tn_dma the G rows are re-read half as often (4 kc tiles at C2's K = 512, not 8).
-// The reduction index m is the slow index of both operands in memory, so a lane collects the 8 rows it
-// feeds to an MFMA with 8 ds_read_b32 (lanes along the contiguous dimension: conflict free) and splits
-// them in registers.  Every 64-column half of a kc tile lies in one A operand (K1 % 64 == 0), every wave's
-// 32 columns in one operand and one relation.  Slab values are unscaled here; their fixed-order sum is
-// k_slab_reduce.  The column sums of G (grad_bias partials) ride with the LAST kc tile (tile 0 without a
-// root), which therefore never skips an m-tile.
-// ---------------------------------------------------------------------------------------
-constexpr int TN_TKC = 128;
-template <bool LO>                               // false: one pass on the hi parts (configs[4], see k_gemm_nt_split)
-__global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __restrict__ A1, int K1,
-                                                                const float* __restrict__ A2, int K2,
-                                                                const float* __restrict__ G, int M, int N,
-                                                                int n_tiles, int rows_per_split,
-                                                                amax_ref amax1, float a1_mul, amax_ref amax2, amax_ref gmax,
-                                                                float* __restrict__ slab,
-                                                                float* __restrict__ bias_part,
-                                                                const uint32_t* __restrict__ tile_mask, int kseg) {
-  constexpr int TKC = TN_TKC, NBUF = 4, A_FLOATS = 32 * TKC, G_FLOATS = 32 * 128, BUF_FLOATS = A_FLOATS + G_FLOATS;
-  constexpr int NT = 2 * kThreads;
-  constexpr int A_PW = 2, G_PW = 2, P = A_PW + G_PW;            // LDS-DMA instructions per wave and m-tile (2 rows each)
-  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF_FLOATS];   // the ONLY LDS object (128 KB)
-  const int Kc = K1 + K2;
-  int bx = blockIdx.x, split = blockIdx.y;                     // a split's tiles on one XCD (see k_gemm_tn_dma)
-  {
-    const int gx = (int)gridDim.x, full = ((int)gridDim.y >> 3) << 3;
-    const int lin = blockIdx.y * gx + blockIdx.x;
-    if (lin < gx * full) {
-      const int q = lin >> 3;
-      bx = q % gx;
-      split = (q / gx) * 8 + (lin & 7);
-    }
-  }
-  const int kc_tile = bx / n_tiles, kc_tiles = (int)gridDim.x / n_tiles;
-  const int kc0 = kc_tile * TKC, n0 = (bx % n_tiles) * 128;
-  const int mbeg = split * rows_per_split;
-  const int mend = min(M, mbeg + rows_per_split);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wk = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, lh = lane >> 5;
-  const bool bias_block = (bias_part != nullptr) && (kc_tile == (K2 > 0 ? kc_tiles - 1 : 0));
-  const bool do_bias = bias_block && (tid < 128);
-  // m-tiles in which no row has ANY of this kc tile's relations are exact zeros in A1: skipped
-  unsigned rel_bits = 0u;
-  if (tile_mask != nullptr && !bias_block && kc0 + TKC <= K1)
-    for (int c = kc0; c < kc0 + TKC; c += kseg) rel_bits |= 1u << (c / kseg);
-  const bool sparse = rel_bits != 0u;
-  auto next_mt = [&](int mt) {
-    mt += 32;
-    while (sparse && mt < mend && !(tile_mask[mt >> 5] & rel_bits)) mt += 32;
-    return min(mt, mend + 31);
-  };
-
-  floatx16 acc[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-  float bsum = 0.f;
-
-  // A and G: 32 lanes per row (2 rows per wave instruction); this lane's 4 columns of the kc tile lie in one operand
-  const int d_row = lane >> 5, d_col = (lane & 31) * 4;
-  const int acol = min(kc0 + d_col, Kc - 4);                   // columns past Kc re-read valid ones; never stored
-  const bool a_first = acol < K1;
-  const float* a_src = a_first ? A1 + acol : A2 + (acol - K1);
-  const int lda = a_first ? K1 : K2;
-  const bool g_ok = n0 + d_col < N;
-
-  auto stage = [&](int mt, int buf) {
-    float* sA = lds + buf * BUF_FLOATS;
-    float* sG = sA + A_FLOATS;
-#pragma unroll
-    for (int j = 0; j < A_PW; ++j) {
-      const int r0 = (wave * A_PW + j) * 2;
-      const int m = min(mt + r0 + d_row, M - 1);               // tail rows are zeroed in LDS below
-      glds16(a_src + (size_t)m * lda, sA + r0 * TKC);
-    }
-#pragma unroll
-    for (int j = 0; j < G_PW; ++j) {
-      const int r0 = (wave * G_PW + j) * 2;
-      const int m = min(mt + r0 + d_row, M - 1);
-      if (g_ok) glds16(G + (size_t)m * N + n0 + d_col, sG + r0 * 128);
-    }
-  };
-
-  int mt_a = next_mt(mbeg - 32), mt_b = mt_a < mend ? next_mt(mt_a) : mend, mt_c = mt_b < mend ? next_mt(mt_b) : mend,
-      mt_d = mend;
-  if (mt_a < mend) stage(mt_a, 0);
-  if (mt_b < mend) stage(mt_b, 1);
-  if (mt_c < mend) stage(mt_c, 2);
-
-  // operand scales (behind the first DMA issue): this WAVE's 32 kc columns lie in ONE of the two A operands -
-  // the aggregate (scaled by the bound a1_mul * max |its table|, see k_gemm_nt_split) or x (its own maximum)
-  const bool w_first = kc0 + wk * 32 < K1 || !amax2.slots;
-  const float am = w_first ? amax_of(amax1, lane) * a1_mul : amax_of(amax2, lane);
-  const int ea = scale_exponent(am), eg = scale_exponent(amax_of(gmax, lane));
-  const float sa = pow2f(ea), sg = pow2f(eg);
-
-  // lane (li, lh) feeds rows 16 s + 8 lh + j (j = 0..7) of the m-tile to the MFMAs of 16-row step s
-  const unsigned a_addr = (unsigned)(8 * lh * TKC + wk * 32 + li) * 4u;
-  const unsigned g_addr = (unsigned)(A_FLOATS + 8 * lh * 128 + wn * 64 + li) * 4u;
-
-  for (int t = 0; mt_a < mend; ++t) {
-    const int mt = mt_a;
-    if (mt_c < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-    else if (mt_b < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    float* sA = lds + (t % NBUF) * BUF_FLOATS;
-    float* sG = sA + A_FLOATS;
-    if (mt + 32 > mend) {                      // ragged last tile: rows >= mend must contribute 0
-      for (int i = tid; i < 32 * TKC; i += NT)
-        if (mt + i / TKC >= mend) sA[i] = 0.f;
-      for (int i = tid; i < 32 * 128; i += NT)
-        if (mt + i / 128 >= mend) sG[i] = 0.f;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    const unsigned buf_bytes = (unsigned)((t % NBUF) * BUF_FLOATS) * 4u;
-    float fa[2][8], fg[2][2][8];               // [16-row step][..]
-    auto read_step = [&](int s) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const unsigned ao = (unsigned)((16 * s + j) * TKC * 4), go = (unsigned)((16 * s + j) * 128 * 4);
-        asm volatile("ds_read_b32 %0, %1" : "=v"(fa[s][j]) : "v"(a_addr + buf_bytes + ao));
-        asm volatile("ds_read_b32 %0, %1" : "=v"(fg[s][0][j]) : "v"(g_addr + buf_bytes + go));
-        asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(fg[s][1][j]) : "v"(g_addr + buf_bytes + go));
-      }
-    };
-    read_step(0);
-    mt_d = mt_c < mend ? next_mt(mt_c) : mend;   // the DMA issue covers the LDS latency of the reads above
-    if (mt_d < mend) stage(mt_d, (t + 3) % NBUF);
-    mt_a = mt_b;
-    mt_b = mt_c;
-    mt_c = mt_d;
-    if (do_bias) {                             // column sums of G, fp32, rows in order (as k_gemm_tn_dma)
-      const unsigned baddr = (unsigned)((sG - lds) + tid) * 4u;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        float v[16];
-#pragma unroll
-        for (int mm = 0; mm < 16; ++mm)
-          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v[mm]) : "v"(baddr + (unsigned)(half * 16 * 128 * 4)), "n"(mm * 128 * 4));
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                       "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]),
-                       "+v"(v[15]));
-#pragma unroll
-        for (int mm = 0; mm < 16; ++mm) bsum += v[mm];
-        asm volatile("" ::: "memory");
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (s == 0) read_step(1);                  // the next step's operands travel behind this step's conversion and MFMAs
-      asm volatile("" : "+v"(fa[s][0]), "+v"(fa[s][1]), "+v"(fa[s][2]), "+v"(fa[s][3]), "+v"(fa[s][4]), "+v"(fa[s][5]),
-                        "+v"(fa[s][6]), "+v"(fa[s][7]));
-      asm volatile("" : "+v"(fg[s][0][0]), "+v"(fg[s][0][1]), "+v"(fg[s][0][2]), "+v"(fg[s][0][3]), "+v"(fg[s][0][4]),
-                        "+v"(fg[s][0][5]), "+v"(fg[s][0][6]), "+v"(fg[s][0][7]));
-      asm volatile("" : "+v"(fg[s][1][0]), "+v"(fg[s][1][1]), "+v"(fg[s][1][2]), "+v"(fg[s][1][3]), "+v"(fg[s][1][4]),
-                        "+v"(fg[s][1][5]), "+v"(fg[s][1][6]), "+v"(fg[s][1][7]));
-      half8 ah, al, gh[2], gl[2];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = fa[s][j] * sa;
-        const _Float16 h = (_Float16)v;
-        ah[j] = h;
-        if (LO) al[j] = (_Float16)(v - (float)h);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const float u = fg[s][b][j] * sg;
-          const _Float16 hg = (_Float16)u;
-          gh[b][j] = hg;
-          if (LO) gl[b][j] = (_Float16)(u - (float)hg);
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        if (LO) {
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh[b], acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl[b], acc[b], 0, 0, 0);
-        }
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh[b], acc[b], 0, 0, 0);
-      }
-    }
-  }
-
-  const float ia = pow2f(-ea), ig = pow2f(-eg);
-  float* out = slab + (size_t)split * Kc * N;
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int nn = n0 + (wn * 2 + b) * 32 + li;
-    if (nn >= N) continue;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kc = kc0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (kc < Kc) out[(size_t)kc * N + nn] = acc[b][r] * ia * ig;
-    }
-  }
-  if (do_bias && n0 + tid < N) bias_part[(size_t)split * N + n0 + tid] = bsum;
-}
-
-// ---------------------------------------------------------------------------------------
-// The same slab GEMM with the operands split ONCE per workgroup (round 3; the default).
-// k_gemm_tn_split above has every wave collect its fragments with 48 ds_read_b32 per m-tile and split them in
-// registers - the A columns twice (two column waves share them), the G columns four times (four kc waves) -
-// 275 vector instructions per m-tile and wave against 12 MFMAs: the launch was bound by vector issue and LDS
-// reads (PMC, profiles/r02_pmc_counters.json: 5.6 M VALU instructions, MFMA pipes 11 % busy).  Here the fp32
+// 128 kc x 128 n per 512-thread workgroup (eight waves, 4 kc x 2 n, a 32 x 64 block each), 32-row m-tiles, a split's
+// tiles placed on one XCD, relation-occupancy skipping of all-zero m-tiles; every 64-column half of a kc tile lies in
+// one A operand (K1 % 64 == 0), every wave's 32 columns in one operand and one relation.  Slab values are unscaled
+// here; their fixed-order sum is k_slab_reduce.  The column sums of G (grad_bias partials) ride with the LAST kc tile
+// (tile 0 without a root), which therefore never skips an m-tile.
+// The operands are split ONCE per workgroup (round 3; round 2's kernel, k_gemm_tn_split in git history, had every wave
+// collect its fragments with 48 ds_read_b32 per m-tile and split them in registers - the A columns twice, the G
+// columns four times, 275 vector instructions per m-tile and wave against 12 MFMAs; PMC, profiles/r02_pmc_counters.json:
+// 5.6 M VALU instructions, MFMA pipes 11 % busy).  The fp32
 // m-tile still arrives by LDS-DMA (ring of THREE 32 KB slots: two tiles in flight), but the workgroup converts it
 // ONCE: thread (column pair, row group) reads its 2 x 8 values down the reduction index with eight ds_read_b64,
 // splits them (the same arithmetic, the same scale: the same fp16 bits) and writes them as 16-byte MFMA fragments -
@@ -780,6 +508,7 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_split(const float* __r
 // which the DMA of tile i + 3 then refills.  Same MFMA operands in the same order as the kernel above: same bits.
 // LDS: 3 x 32 KB + 2 x 32 KB = all 160 KB of the CU, one 512-thread workgroup per CU.
 // ---------------------------------------------------------------------------------------
+constexpr int TN_TKC = 128;
 template <bool LO>
 __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const float* __restrict__ A1, int K1,
                                                                const float* __restrict__ A2, int K2,
@@ -1027,281 +756,6 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------
-// Operands that ARRIVE split (round 4): fp16 hi / lo "planes".
-// A plane pair of a tensor T[M][K] under the scale 2^e: hi[m][k] = fp16(T * 2^e), lo[m][k] = fp16(T * 2^e - hi), both
-// row-major with K halves per row (K % 8 == 0) - the very two numbers the kernels above form in registers, stored once
-// by whoever holds T in registers anyway (the gather for an aggregate; an NT transform for the fp32 block it splits in
-// its k loop: x, h, g, gz) instead of being re-formed by every consumer.  Same bytes as fp32.
-//
-// k_split_planes: the stand-alone producer (callers that bring plain fp32 operands).
-// ---------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__global__ __launch_bounds__(kThreads) void k_split_planes(const float* __restrict__ src, int64_t n8, amax_ref amax,
-                                                           float mul, __half* __restrict__ hi, __half* __restrict__ lo) {
-  const float s = pow2f(scale_exponent(amax_of(amax, threadIdx.x & 63) * mul));
-  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n8; i += (int64_t)gridDim.x * kThreads) {
-    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    half8 h, l;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float u = v[j] * s;
-      const _Float16 hh = (_Float16)u;
-      h[j] = hh;
-      l[j] = (_Float16)(u - (float)hh);
-    }
-    reinterpret_cast<f32x4*>(hi)[i] = __builtin_bit_cast(f32x4, h);
-    if (lo) reinterpret_cast<f32x4*>(lo)[i] = __builtin_bit_cast(f32x4, l);
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// slab[s][kc][n] = sum over the node rows of split s of [A1 | A2][m][kc] * G[m][n], every operand given as planes.
-// Same tiling as k_gemm_tn_coop (128 kc x 128 n per 512-thread workgroup, 4 x 2 waves of 32 kc x 64 n, 32-row m-tiles,
-// a split's tiles on one XCD, relation-occupancy skipping) and the same MFMA operands in the same order - the same
-// bits - but nothing is converted: an m-tile's four images (A hi, A lo, G hi, G lo: 32 rows x 256 B each) arrive by
-// LDS-DMA, and because the reduction index m is the SLOW index of both operands a wave fetches its fragments - eight
-// consecutive m of one column - with the transposing LDS read of gfx950, ds_read_b64_tr_b16 (a 16-lane group reads a
-// 4-row x 16-column block and every lane receives one column of it): 24 of them per wave and m-tile, no vector ALU work
-// at all between the barrier and the 12 MFMAs.  The image is the guide's 256-byte-row layout for such reads
-// (16-byte chunk ch of row r at 256 r + 16 (ch ^ ((r & 3) << 2 | (r >> 2) & 3)): conflict free); LDS-DMA fills LDS
-// lane-linearly, so the swizzle is applied to the SOURCE chunk a lane fetches.  RING slots of 32 KB, RING - 1 tiles in
-// flight, one barrier per m-tile.  The column sums of G (grad_bias) are not formed here - there is no fp32 G in this
-// kernel; whoever produced G's planes held its fp32 values (rgcn_colsum_* partials).
-// ---------------------------------------------------------------------------------------
-template <bool LO, int RING>
-__global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_planes(
-    const __half* __restrict__ A1h, const __half* __restrict__ A1l, int K1, const __half* __restrict__ A2h,
-    const __half* __restrict__ A2l, int K2, const __half* __restrict__ Gh, const __half* __restrict__ Gl, int M, int N,
-    int n_tiles, int rows_per_split, amax_ref amax1, float a1_mul, amax_ref amax2, amax_ref gmax,
-    float* __restrict__ slab, const uint32_t* __restrict__ tile_mask, int kseg) {
-  constexpr int TKC = TN_TKC, D = RING - 1;
-  constexpr int PLANE = 32 * 256;                                // 8 KB: one image (32 rows x 128 halves)
-  constexpr int SLOT_BYTES = 4 * PLANE;                          // A hi, A lo, G hi, G lo
-  constexpr int P = 4;                                           // LDS-DMA instructions per wave and m-tile (4 rows each)
-  static_assert(RING >= 2 && RING <= 5 && TKC == 128, "ring / tile");
-  __shared__ __attribute__((aligned(16))) char lds[RING * SLOT_BYTES];   // the ONLY LDS object
-  const int Kc = K1 + K2;
-  int bx = blockIdx.x, split = blockIdx.y;                       // a split's tiles on one XCD (see k_gemm_tn_dma)
-  {
-    const int gx = (int)gridDim.x, full = ((int)gridDim.y >> 3) << 3;
-    const int lin = blockIdx.y * gx + blockIdx.x;
-    if (lin < gx * full) {
-      const int q = lin >> 3;
-      bx = q % gx;
-      split = (q / gx) * 8 + (lin & 7);
-    }
-  }
-  const int kc_tile = bx / n_tiles;
-  const int kc0 = kc_tile * TKC, n0 = (bx % n_tiles) * 128;
-  const int mbeg = split * rows_per_split;
-  const int mend = min(M, mbeg + rows_per_split);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wk = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, lh = lane >> 5;
-  RGCN_STAMP(0);
-  unsigned rel_bits = 0u;                                        // m-tiles without any of this kc tile's relations: skipped
-  if (tile_mask != nullptr && kc0 + TKC <= K1)
-    for (int c = kc0; c < kc0 + TKC; c += kseg) rel_bits |= 1u << (c / kseg);
-  const bool sparse = rel_bits != 0u;
-  auto next_mt = [&](int mt) {
-    mt += 32;
-    while (sparse && mt < mend && !(tile_mask[mt >> 5] & rel_bits)) mt += 32;
-    return min(mt, mend + 31);
-  };
-
-  floatx16 acc[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-
-  // LDS-DMA: waves 0,1 bring A hi, 2,3 A lo, 4,5 G hi, 6,7 G lo; a wave instruction is 4 rows x 256 B, instruction j
-  // of a wave covers rows 4 (4 (wave & 1) + j) .. + 3.  Lane -> (row, slot); it fetches source chunk slot ^ f(row).
-  const int sub = wave >> 1;
-  const bool is_lo = (sub & 1) != 0, is_g = sub >= 2;
-  const __half* src_base[P];
-  int src_ld[P];
-#pragma unroll
-  for (int j = 0; j < P; ++j) {
-    const int f = (((lane >> 4) & 3) << 2) | j;                  // row & 3 = lane >> 4, (row >> 2) & 3 = j
-    const int ch = (lane & 15) ^ f;
-    if (is_g) {
-      const int col = min(n0 + 8 * ch, N - 8);                   // columns past N re-read valid ones; never stored
-      src_base[j] = (is_lo ? Gl : Gh) + col;
-      src_ld[j] = N;
-    } else {
-      const int col = min(kc0 + 8 * ch, Kc - 8);
-      const bool first = col < K1;
-      src_base[j] = first ? (is_lo ? A1l : A1h) + col : (is_lo ? A2l : A2h) + (col - K1);
-      src_ld[j] = first ? K1 : K2;
-    }
-  }
-  const bool dma_on = LO || !is_lo;
-  auto stage = [&](int mt, int slot) {
-    char* dst = lds + slot * SLOT_BYTES + sub * PLANE + (wave & 1) * 4 * 1024;
-    if (dma_on) {
-#pragma unroll
-      for (int j = 0; j < P; ++j) {
-        const int m = min(mt + 4 * (4 * (wave & 1) + j) + (lane >> 4), M - 1);   // rows past mend are zeroed below
-        glds16(src_base[j] + (size_t)m * src_ld[j], dst + j * 1024);
-      }
-    }
-  };
-
-  int mtq[D];                                                    // the m-tile being multiplied and the D - 1 staged behind it
-  mtq[0] = next_mt(mbeg - 32);
-#pragma unroll
-  for (int j = 1; j < D; ++j) mtq[j] = mtq[j - 1] < mend ? next_mt(mtq[j - 1]) : mend;
-#pragma unroll
-  for (int j = 0; j < D; ++j)
-    if (mtq[j] < mend) stage(mtq[j], j);
-
-  // operand scales (behind the first DMA issue): only the epilogue needs them - the planes are already scaled
-  const float amax_a1 = amax_of(amax1, lane) * a1_mul;
-  const float amax_a2 = amax2.slots ? amax_of(amax2, lane) : amax_a1;
-  const int ea1 = scale_exponent(amax_a1), ea2 = scale_exponent(amax_a2), eg = scale_exponent(amax_of(gmax, lane));
-  const bool w_first = kc0 + wk * 32 < K1 || !amax2.slots;       // the multiplying wave's 32 kc columns
-  const int ea = w_first ? ea1 : ea2;
-
-  // transposed fragment reads: group g = lane >> 4 reads the 4-row x 16-column block of rows 16 s + 8 (g >> 1) + 4 t ..
-  // + 3, columns 16 (g & 1) .. + 15 of the wave's 32; lane 4 q + p of the group supplies row q, columns 4 p .. 4 p + 3
-  const int grp = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
-  unsigned a_rd[2], g_rd[2][2];
-#pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2) {
-    const int row = 8 * (grp >> 1) + 4 * t2 + q4;
-    const int f = (q4 << 2) | ((2 * (grp >> 1) + t2) & 3);       // of row + 16 s as well
-    const int ca = wk * 4 + 2 * (grp & 1) + (p4 >> 1);
-    a_rd[t2] = (unsigned)(256 * row + 16 * (ca ^ f) + 8 * (p4 & 1));
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int cg = wn * 8 + 4 * b + 2 * (grp & 1) + (p4 >> 1);
-      g_rd[t2][b] = (unsigned)(2 * PLANE + 256 * row + 16 * (cg ^ f) + 8 * (p4 & 1));
-    }
-  }
-
-  int t = 0;
-  RGCN_STAMP(1);
-  while (mtq[0] < mend) {
-    const int mt = mtq[0];
-    // tile mt has landed for this wave (all but the DMAs of the tiles staged behind it are done), then for every wave;
-    // the barrier also says all waves are done reading the slot the stage() below refills
-    if constexpr (D >= 4) { if (mtq[3] < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * P) : "memory"); else
-      if (mtq[2] < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory"); else
-      if (mtq[1] < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    else if constexpr (D == 3) { if (mtq[2] < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory"); else
-      if (mtq[1] < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    else if constexpr (D == 2) { if (mtq[1] < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const unsigned slot = (unsigned)((t % RING) * SLOT_BYTES);
-    if (mt + 32 > mend) {                          // ragged last tile: rows >= mend must contribute 0 (A is enough)
-      unsigned* z = reinterpret_cast<unsigned*>(lds + slot);
-      for (int i = tid; i < 2 * 32 * 64; i += 2 * kThreads)
-        if (mt + ((i >> 6) & 31) >= mend) z[i] = 0u;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    f32x2 ra[2][2][2], rg[2][2][2][2];             // [step][hi | lo][rows 0-3 | 4-7], [step][block][hi | lo][..]
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ra[s][0][t2]) : "v"(a_rd[t2] + slot), "n"(s * 4096));
-        if (LO) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ra[s][1][t2]) : "v"(a_rd[t2] + slot), "n"(s * 4096 + PLANE));
-      }
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-          asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(rg[s][b][0][t2]) : "v"(g_rd[t2][b] + slot), "n"(s * 4096));
-          if (LO) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(rg[s][b][1][t2]) : "v"(g_rd[t2][b] + slot), "n"(s * 4096 + PLANE));
-        }
-    }
-    const int mt_new = mtq[D - 1] < mend ? next_mt(mtq[D - 1]) : mend;   // the DMA issue covers the LDS latency of the reads above
-    if (mt_new < mend) stage(mt_new, (t + D) % RING);
-#pragma unroll
-    for (int j = 0; j + 1 < D; ++j) mtq[j] = mtq[j + 1];
-    mtq[D - 1] = mt_new;
-    ++t;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      // step 0 may start once its own reads are back (the last 6 (1 + LO) issued are step 1's); every fragment register is
-      // tied to the wait that covers it (tools/check_waitcnt.py)
-      constexpr int kStepReads = 6 * (LO ? 2 : 1);
-      if (LO) {
-        if (s == 0) asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(ra[0][0][0]), "+v"(ra[0][0][1]), "+v"(ra[0][1][0]), "+v"(ra[0][1][1]),
-                                 "+v"(rg[0][0][0][0]), "+v"(rg[0][0][0][1]), "+v"(rg[0][0][1][0]), "+v"(rg[0][0][1][1]),
-                                 "+v"(rg[0][1][0][0]), "+v"(rg[0][1][0][1]), "+v"(rg[0][1][1][0]), "+v"(rg[0][1][1][1]) : "n"(kStepReads));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[1][0][0]), "+v"(ra[1][0][1]), "+v"(ra[1][1][0]), "+v"(ra[1][1][1]),
-                          "+v"(rg[1][0][0][0]), "+v"(rg[1][0][0][1]), "+v"(rg[1][0][1][0]), "+v"(rg[1][0][1][1]),
-                          "+v"(rg[1][1][0][0]), "+v"(rg[1][1][0][1]), "+v"(rg[1][1][1][0]), "+v"(rg[1][1][1][1]));
-      } else {
-        if (s == 0) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(ra[0][0][0]), "+v"(ra[0][0][1]), "+v"(rg[0][0][0][0]), "+v"(rg[0][0][0][1]),
-                                 "+v"(rg[0][1][0][0]), "+v"(rg[0][1][0][1]) : "n"(kStepReads));
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[1][0][0]), "+v"(ra[1][0][1]), "+v"(rg[1][0][0][0]), "+v"(rg[1][0][0][1]),
-                          "+v"(rg[1][1][0][0]), "+v"(rg[1][1][0][1]));
-      }
-      auto frag = [](const f32x2 a, const f32x2 b) {
-        const f32x4 v = {a[0], a[1], b[0], b[1]};
-        return __builtin_bit_cast(half8, v);
-      };
-      const half8 ah = frag(ra[s][0][0], ra[s][0][1]);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {                // small terms first, as k_gemm_tn_coop
-        const half8 gh = frag(rg[s][b][0][0], rg[s][b][0][1]);
-        if (LO) {
-          const half8 al = frag(ra[s][1][0], ra[s][1][1]);
-          const half8 gl = frag(rg[s][b][1][0], rg[s][b][1][1]);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, gh, acc[b], 0, 0, 0);
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gl, acc[b], 0, 0, 0);
-        }
-        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, gh, acc[b], 0, 0, 0);
-      }
-    }
-  }
-
-  RGCN_STAMP(2);
-  const float ia = pow2f(-ea), ig = pow2f(-eg);
-  float* out = slab + (size_t)split * Kc * N;
-  if (kc0 + TKC <= Kc && n0 + 128 <= N) {
-    // whole tile inside the slab: through LDS, so that a lane stores 4 consecutive columns (see k_gemm_tn_coop)
-    __builtin_amdgcn_s_barrier();
-    float* tr = reinterpret_cast<float*>(lds) + wave * (32 * 64);
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + b * 32 + li] = acc[b][r];
-    const int trow = lane >> 4, tc4 = (lane & 15) * 4;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float4 a = *reinterpret_cast<const float4*>(tr + (q * 4 + trow) * 64 + tc4);
-      float4 v;
-      v.x = a.x * ia * ig; v.y = a.y * ia * ig; v.z = a.z * ia * ig; v.w = a.w * ia * ig;
-      *reinterpret_cast<float4*>(out + (size_t)(kc0 + wk * 32 + q * 4 + trow) * N + n0 + wn * 64 + tc4) = v;
-    }
-  } else {
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int nn = n0 + (wn * 2 + b) * 32 + li;
-      if (nn >= N) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kc = kc0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (kc < Kc) out[(size_t)kc * N + nn] = acc[b][r] * ia * ig;
-      }
-    }
-  }
-#ifdef RGCN_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-  RGCN_STAMP(3);
-}
-
-// ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
@@ -1365,14 +819,6 @@ int pack_weights(const float* weight, const float* root, int64_t R, int64_t d_in
   return RGCN_OK;
 }
 
-int nt_rows() {                       // RGCN_NT_ROWS=128: the 128-row tile for N > 64 (A/B runs; measured no faster at C2)
-  static const int v = [] {
-    const char* e = getenv("RGCN_NT_ROWS");
-    return (e && atoi(e) == 128) ? 128 : 64;
-  }();
-  return v;
-}
-
 // workspace of one NT call: the split weights (when the caller brings none) + partial maxima of an A
 // operand nobody left a maximum for
 size_t nt_workspace_bytes(int64_t R, int64_t d_in, int64_t d_out) {
@@ -1383,11 +829,7 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
                     const float* b_inv, const float* bias, const float* mask, int epi, float* C, int M, int N,
                     const uint32_t* tile_mask, int kseg, const float* a1_amax, float a1_mul, const float* a2_amax,
                     float* c_amax, float* scan_slots, bool half, hipStream_t stream, const hub_fin* hubs = nullptr,
-                    float out_scale = 1.f, const __half* a1_lo = nullptr, const nt_emit emit = nt_emit{}) {
-  // a1_lo != NULL: A1 is the hi plane of an aggregate that arrives split (the gather's plane mode), a1_lo its lo plane
-  const bool planes = a1_lo != nullptr;
-  if (planes && (half || !a1_amax || !K1 || (K1 & 7))) return RGCN_ERR_ARG;   // the planes' scale is amax * mul, never a scan
-  if ((emit.e1h && (planes || !emit.e1l)) || (emit.e2h && !emit.e2l)) return RGCN_ERR_ARG;
+                    float out_scale = 1.f) {
   const hub_fin fin = hubs ? *hubs : hub_fin{};
   if (fin.ptr && fin.d != 64 && fin.d != 128 && fin.d != 256) return RGCN_ERR_UNSUPPORTED;
   if (fin.ptr && (!a1_amax || fin.d != kseg)) return RGCN_ERR_ARG;   // an unfinished A1 cannot be scanned for its maximum
@@ -1407,15 +849,13 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
   if (!r1.slots) { r1 = r2; r2 = amax_ref{nullptr, 0}; a1_mul = 1.f; }   // the kernels read r1 unconditionally
   if (kseg <= 0 || kseg % BK != 0) tile_mask = nullptr;
   unsigned* amax_out = reinterpret_cast<unsigned*>(c_amax);
-#define RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, LO_, A1P_)                                                               \
-  k_gemm_nt_split<WM_, WN_, TN_, EPI_, LO_, A1P_><<<grid, 64 * WM_ * WN_, 0, stream>>>(                               \
-      A1, a1_lo, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, C, M, N, tile_mask, kseg, amax_out, fin,     \
-      out_scale, emit)
-#define RGCN_NT_SPLIT_W(WM_, WN_, TN_, EPI_)                     \
-  do {                                                           \
-    if (half) RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, false, false);  \
-    else if (planes) RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, true, true); \
-    else RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, true, false);        \
+#define RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, LO_)                                                                     \
+  k_gemm_nt_split<WM_, WN_, TN_, EPI_, LO_><<<grid, 64 * WM_ * WN_, 0, stream>>>(                                     \
+      A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, C, M, N, tile_mask, kseg, amax_out, fin, out_scale)
+#define RGCN_NT_SPLIT_W(WM_, WN_, TN_, EPI_)             \
+  do {                                                   \
+    if (half) RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, false); \
+    else RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, true);       \
   } while (0)
 #define RGCN_NT_SPLIT(WM_, TN_, EPI_) RGCN_NT_SPLIT_W(WM_, 2, TN_, EPI_)   /* two wave columns: see the note below */
   // (Round 3 also built WM x WN = 4 x 1 with TN = 4 - four waves of 32 rows x 128 columns, a 128 x 128 tile, one
@@ -1431,16 +871,11 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
     if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 1, EPI_RELU);
     else if (epi == EPI_MASK) RGCN_NT_SPLIT(2, 1, EPI_MASK);
     else RGCN_NT_SPLIT(2, 1, EPI_NONE);
-  } else if (nt_rows() == 64 || fin.ptr) {                      // (the 64-row kernel is the one that finishes hub rows)
+  } else {                       // (a 128-row tile, WM = 4, was measured no faster at C2: 15.8 against 15.2 us of main loop)
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 128));
     if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 2, EPI_RELU);
     else if (epi == EPI_MASK) RGCN_NT_SPLIT(2, 2, EPI_MASK);
     else RGCN_NT_SPLIT(2, 2, EPI_NONE);
-  } else {
-    dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)ceil_div64(N, 128));
-    if (epi == EPI_RELU) RGCN_NT_SPLIT(4, 2, EPI_RELU);
-    else if (epi == EPI_MASK) RGCN_NT_SPLIT(4, 2, EPI_MASK);
-    else RGCN_NT_SPLIT(4, 2, EPI_NONE);
   }
 #undef RGCN_NT_LAUNCH
 #undef RGCN_NT_SPLIT
@@ -1727,88 +1162,15 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
   const uint32_t* tmask = (d_in % 64 == 0) ? tile_mask : nullptr;
   float* bp = grad_bias ? bias_part : nullptr;
-  // RGCN_TN_KERNEL=split: round 2's kernel (every wave splits its own fragments) for A/B runs; same bits either way
-  static const bool coop = [] {
-    const char* e = getenv("RGCN_TN_KERNEL");
-    return !(e && e[0] == 's');
-  }();
 #define RGCN_TN_LAUNCH(KERNEL, LO_)                                                                              \
   KERNEL<LO_><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles, p.rows_per_split, \
                                                  r1, a1_mul, r2, rg, slab, bp, tmask, (int)d_in)
-  if (coop) {
-    if (half) RGCN_TN_LAUNCH(k_gemm_tn_coop, false);
-    else RGCN_TN_LAUNCH(k_gemm_tn_coop, true);
-  } else {
-    if (half) RGCN_TN_LAUNCH(k_gemm_tn_split, false);
-    else RGCN_TN_LAUNCH(k_gemm_tn_split, true);
-  }
+  if (half) RGCN_TN_LAUNCH(k_gemm_tn_coop, false);
+  else RGCN_TN_LAUNCH(k_gemm_tn_coop, true);
 #undef RGCN_TN_LAUNCH
   RGCN_HIP_TRY(hipGetLastError());
   job->slab = slab;
   job->bias_part = bias_part;
-  job->splits = p.splits;
-  job->K1 = K1;
-  job->Kc = Kc;
-  job->N = (int32_t)d_out;
-  job->grad_weight = grad_weight;
-  job->grad_root = grad_root;
-  job->grad_bias = grad_bias;
-  return RGCN_OK;
-}
-
-int rgcn_split_planes(const float* src, int64_t numel, const float* amax, float amax_mul, void* hi, void* lo,
-                      void* stream_) {
-  if (numel < 0 || (numel & 7) || !amax || !hi || !(amax_mul > 0.f)) return RGCN_ERR_ARG;
-  if (numel == 0) return RGCN_OK;
-  if (!src) return RGCN_ERR_ARG;
-  const int64_t n8 = numel / 8;
-  const unsigned blocks = (unsigned)std::min<int64_t>(2048, ceil_div64(n8, kThreads));
-  k_split_planes<<<blocks, kThreads, 0, (hipStream_t)stream_>>>(src, n8, amax_ref{amax, 0}, amax_mul, (__half*)hi, (__half*)lo);
-  RGCN_HIP_TRY(hipGetLastError());
-  return RGCN_OK;
-}
-
-int rgcn_transform_bwd_params_planes_begin(const void* agg_hi, const void* agg_lo, const void* x_hi, const void* x_lo,
-                                           const void* g_hi, const void* g_lo, const uint32_t* tile_mask, int64_t N,
-                                           int64_t R, int64_t d_in, int64_t d_out, const float* agg_amax,
-                                           float agg_amax_mul, const float* x_amax, const float* g_amax, int half,
-                                           float* grad_weight, float* grad_root, float* grad_bias,
-                                           const float* bias_part, int bias_splits, void* workspace,
-                                           size_t workspace_bytes, void* stream_, rgcn_slab_job* job) {
-  if (!job) return RGCN_ERR_ARG;
-  *job = rgcn_slab_job{};
-  if (bad_dims(N, R, d_in, d_out) || !grad_weight) return RGCN_ERR_ARG;
-  if (N > 0 && (!agg_hi || !g_hi || !agg_amax || !g_amax || (!half && (!agg_lo || !g_lo)))) return RGCN_ERR_ARG;
-  if (N > 0 && grad_root && (!x_hi || !x_amax || (!half && !x_lo))) return RGCN_ERR_ARG;
-  if (grad_bias && N > 0 && (!bias_part || bias_splits < 1)) return RGCN_ERR_ARG;   // no fp32 g in this kernel: partials come from its producer
-  if ((d_in % 64) || (d_out % 8)) return RGCN_ERR_UNSUPPORTED; // a 64-column kc tile lies in one operand / relation; 16-byte chunks
-  if (N > INT32_MAX / 2 || (R + 1) * d_in > (1 << 24) || d_out > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
-  if (!workspace || workspace_bytes < tn_workspace_bytes(N, R, d_in, d_out)) return RGCN_ERR_WORKSPACE;
-  hipStream_t stream = (hipStream_t)stream_;
-  const int K1 = (int)(R * d_in), K2 = grad_root ? (int)d_in : 0, Kc = K1 + K2;
-  TnPlan p = tn_plan(N, (R + 1) * d_in, d_out);
-  p.kc_tiles = (int)ceil_div64(Kc, TN_TKC);
-  float* slab = (float*)workspace;
-  if (N == 0) {
-    RGCN_HIP_TRY(hipMemsetAsync(grad_weight, 0, (size_t)K1 * d_out * sizeof(float), stream));
-    if (grad_root) RGCN_HIP_TRY(hipMemsetAsync(grad_root, 0, (size_t)d_in * d_out * sizeof(float), stream));
-    if (grad_bias) RGCN_HIP_TRY(hipMemsetAsync(grad_bias, 0, (size_t)d_out * sizeof(float), stream));
-    return RGCN_OK;
-  }
-  const amax_ref r1{agg_amax, 0}, r2 = K2 ? amax_ref{x_amax, 0} : amax_ref{nullptr, 0}, rg{g_amax, 0};
-  const float a1_mul = agg_amax_mul > 0.f ? agg_amax_mul : 1.f;
-  dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
-#define RGCN_TNP_LAUNCH(LO_)                                                                                          \
-  k_gemm_tn_planes<LO_, 3><<<grid, 2 * kThreads, 0, stream>>>(                                                         \
-      (const __half*)agg_hi, (const __half*)agg_lo, K1, (const __half*)x_hi, (const __half*)x_lo, K2, (const __half*)g_hi, \
-      (const __half*)g_lo, (int)N, (int)d_out, p.n_tiles, p.rows_per_split, r1, a1_mul, r2, rg, slab, tile_mask, (int)d_in)
-  if (half) RGCN_TNP_LAUNCH(false);
-  else RGCN_TNP_LAUNCH(true);
-#undef RGCN_TNP_LAUNCH
-  RGCN_HIP_TRY(hipGetLastError());
-  job->slab = slab;
-  job->bias_part = bias_part;
-  job->bias_splits = grad_bias ? bias_splits : 0;
   job->splits = p.splits;
   job->K1 = K1;
   job->Kc = Kc;

@@ -188,6 +188,74 @@ class NodePartition:
         part._finish(*cls._interior_first(rank_of, slot_of, edge_index.cpu(), part.cap))
         return part
 
+    CLUSTER_MAX_NODES = 200_000    # `clustered` walks the nodes in Python: PrimeKG-sized graphs, not C4
+
+    @classmethod
+    def clustered(cls, edge_index: Tensor, num_nodes: int, world: int, balance: float = 1.04,
+                  heavy_share: float = 0.7) -> "NodePartition":
+        """A locality-aware assignment for degree-skewed graphs (PrimeKG: a few hub genes, a long tail of nodes with
+        one or two neighbours), so that the interior-first overlap of the "pull" scheme has rows to work with: under
+        the degree-balanced deal a row is interior only if ALL its neighbours happened to land on its rank - a handful
+        of rows at P = 8 - although most nodes have so few neighbours that they could simply sit WITH them.
+
+        1. the heaviest nodes - those that together hold `heavy_share` of the edge endpoints - are dealt by the exact
+           longest-processing-time heap of `_deal` (they are what balances the edge load);
+        2. every other node, heaviest first (its heavier neighbours are placed by then), goes to the rank that already
+           holds most of its neighbours, among the ranks with a free row slot whose edge load stays under `balance` x
+           the mean; ties and neighbourless nodes go to the least-loaded such rank.
+
+        Same capacity (ceil(N / world) rows per rank) and slot conventions as the deal, so everything downstream -
+        halo plans, shards, results - is unchanged: only WHICH rows a rank owns differs (results in fp32 arithmetic
+        are bit-identical to any other assignment's: no output row is a cross-rank sum)."""
+        import numpy as np
+        if num_nodes > cls.CLUSTER_MAX_NODES:
+            raise ValueError(f"clustered() walks the nodes one by one: {num_nodes} > {cls.CLUSTER_MAX_NODES}; use the deal")
+        ei = edge_index.cpu()
+        src, dst = ei[0].numpy(), ei[1].numpy()
+        n = num_nodes
+        deg = np.bincount(src, minlength=n) + np.bincount(dst, minlength=n)
+        cap = (n + world - 1) // world
+        # undirected neighbour lists (CSR), duplicates kept: a neighbour reached by more edges pulls harder
+        a = np.concatenate([src, dst])
+        b = np.concatenate([dst, src])
+        order = np.argsort(a, kind="stable")
+        nbr = b[order]
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(a, minlength=n), out=ptr[1:])
+        by_deg = np.argsort(-deg, kind="stable")
+        total = float(deg.sum())
+        cum = np.cumsum(deg[by_deg])
+        heavy = int(np.searchsorted(cum, heavy_share * total)) + 1 if total > 0 else 0
+        heavy = min(n, max(heavy, world))
+        rank_of = np.full(n, -1, dtype=np.int64)
+        load = np.zeros(world, dtype=np.float64)
+        fill = np.zeros(world, dtype=np.int64)
+        heap = [(0.0, k) for k in range(world)]
+        for v in by_deg[:heavy].tolist():                                # step 1: exact LPT over the heavy head
+            ld, k = heapq.heappop(heap)
+            rank_of[v] = k
+            fill[k] += 1
+            load[k] = ld + deg[v]
+            if fill[k] < cap:
+                heapq.heappush(heap, (load[k], k))
+        limit = balance * total / world
+        for v in by_deg[heavy:].tolist():                                # step 2: join the neighbours
+            open_ = fill < cap
+            ok = open_ & (load + deg[v] <= limit)
+            if not ok.any():
+                ok = open_
+            votes = np.zeros(world, dtype=np.int64)
+            rk = rank_of[nbr[ptr[v]:ptr[v + 1]]]
+            rk = rk[rk >= 0]
+            if rk.size:
+                votes = np.bincount(rk, minlength=world)
+            score = np.where(ok, votes.astype(np.float64) - 1e-9 * load, -np.inf)   # most neighbours; then least loaded
+            k = int(np.argmax(score))
+            rank_of[v] = k
+            fill[k] += 1
+            load[k] += deg[v]
+        return cls.from_assignment(torch.from_numpy(rank_of), ei, world)
+
     @staticmethod
     def _interior_first(rank_of: Tensor, slot_of: Tensor, ei: Tensor, cap: int):
         """re-number each rank's slots so that its interior rows (no edge of theirs, in either direction, crosses
@@ -205,10 +273,12 @@ class NodePartition:
         return rank_of, new_slot, ~boundary
 
     @classmethod
-    def shared(cls, edge_index: Tensor, num_nodes: int, group=None, device=None) -> "NodePartition":
+    def shared(cls, edge_index: Tensor, num_nodes: int, group=None, device=None, method: str = "deal") -> "NodePartition":
+        """``method``: "deal" (degree-balanced), "clustered" (locality-aware, PrimeKG-sized graphs) or "auto"
+        (clustered up to CLUSTER_MAX_NODES nodes on a skewed graph, else the deal)"""
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         if rank == 0:
-            part = cls(edge_index, num_nodes, world)
+            part = cls.build(edge_index, num_nodes, world, method)
             payload = torch.stack([part.rank_of, part.slot_of, part.interior.long()])
         else:
             part = cls.__new__(cls)
@@ -222,6 +292,21 @@ class NodePartition:
         if rank != 0:
             part._finish(payload[0].clone(), payload[1].clone(), payload[2].bool())
         return part
+
+    @classmethod
+    def build(cls, edge_index: Tensor, num_nodes: int, world: int, method: str = "deal") -> "NodePartition":
+        if method not in ("deal", "clustered", "auto"):
+            raise ValueError(f"partition method must be 'deal', 'clustered' or 'auto', got {method!r}")
+        if method == "auto":
+            ei = edge_index.cpu()
+            deg = torch.bincount(ei[0], minlength=num_nodes) + torch.bincount(ei[1], minlength=num_nodes)
+            # clustering pays where most nodes have a handful of neighbours (they can sit with them); a uniform
+            # random graph (C4: every node ~80 neighbours on all ranks) has no interior rows under any assignment
+            light = float((deg <= 8).float().mean()) if num_nodes else 0.0
+            method = "clustered" if (world > 1 and num_nodes <= cls.CLUSTER_MAX_NODES and light >= 0.15) else "deal"
+        if method == "clustered":
+            return cls.clustered(edge_index, num_nodes, world)
+        return cls(edge_index, num_nodes, world)
 
     def _finish(self, rank_of: Tensor, slot_of: Tensor, interior: Tensor) -> None:
         self.rank_of, self.slot_of, self.interior = rank_of, slot_of, interior
@@ -398,7 +483,7 @@ class RankShard:
         w_out = (1.0 / cnt[dst[m_out] * r + et[m_out]]).to(torch.float32)
         n_int = self.num_interior
         if split is None:
-            split = os.environ.get("RGCN_DIST_SPLIT", "1") == "1"
+            split = True
         # interior / boundary halves (pull): worth two launches each only when both halves are real
         self.split = bool(split and scheme == "pull" and part.world > 1 and n_int >= self.MIN_SPLIT_ROWS
                           and self.cap - n_int >= self.MIN_SPLIT_ROWS)
@@ -550,7 +635,7 @@ def _zero_pad_rows(g: Tensor, num_own: int) -> Tensor:
     """the slots past a rank's last node are padding: whatever arrives there must not reach a parameter gradient"""
     if num_own >= g.size(0):
         return g.contiguous()
-    g = g.clone()
+    g = g.contiguous().clone()                  # (clone() alone keeps a transposed layout)
     g[num_own:] = 0
     return g
 
@@ -652,6 +737,29 @@ def _backward_layer(agg, x, g, weight, root, relu_mask, shard, backend, group, h
     return red, gx
 
 
+def _encoder2_fwd(x, w1, root1, b1, w2, root2, b2, shard: RankShard, backend, group):
+    """conv1 -> ReLU -> conv2 on this rank's rows -> (out, what the backward needs)"""
+    x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
+    h, agg1 = _layer_fwd(x, w1, root1, b1, True, shard, backend, group)
+    out, agg2 = _layer_fwd(h, w2, root2, b2, False, shard, backend, group)
+    return out, (x, agg1, h, agg2, w1, root1, w2, root2)
+
+
+def _encoder2_bwd(saved, flags, g, shard: RankShard, backend, group, need_x: bool):
+    x, agg1, h, agg2, w1, root1, w2, root2 = saved
+    has_root1, has_b1, has_root2, has_b2 = flags
+    g = _zero_pad_rows(g, shard.num_own)
+    # per layer: halo exchange of the gradient rows, then the parameter-gradient GEMM + its all-reduce behind it,
+    # then the input gradient (ReLU backward in its epilogue)
+    red2, gz = _backward_layer(agg2, h, g, w2, root2, h, shard, backend, group, has_root2, has_b2)
+    red1, gx = _backward_layer(agg1, x, gz, w1, root1, None, shard, backend, group, has_root1, has_b1, need_x=need_x)
+    _wait(red2)
+    _wait(red1)
+    gw2, groot2, gb2 = _unflatten(red2[1], red2[2], has_root2, has_b2)
+    gw1, groot1, gb1 = _unflatten(red1[1], red1[2], has_root1, has_b1)
+    return gx, gw1, groot1, gb1, gw2, groot2, gb2
+
+
 class _PartitionedEncoder2Function(torch.autograd.Function):
     """conv1 -> ReLU -> conv2 on this rank's rows as ONE autograd node (cf. conv._Encoder2Function):
     four exchanges per step, ReLU and its backward in the GEMM epilogues, parameter-gradient all-reduces
@@ -659,30 +767,16 @@ class _PartitionedEncoder2Function(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, root1, b1, w2, root2, b2, shard: RankShard, backend, group):
-        x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
-        h, agg1 = _layer_fwd(x, w1, root1, b1, True, shard, backend, group)
-        out, agg2 = _layer_fwd(h, w2, root2, b2, False, shard, backend, group)
+        out, saved = _encoder2_fwd(x, w1, root1, b1, w2, root2, b2, shard, backend, group)
         ctx.shard, ctx.backend, ctx.group = shard, backend, group
         ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
-        ctx.save_for_backward(x, agg1, h, agg2, w1, root1, w2, root2)
+        ctx.save_for_backward(*saved)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, agg1, h, agg2, w1, root1, w2, root2 = ctx.saved_tensors
-        shard, backend, group = ctx.shard, ctx.backend, ctx.group
-        has_root1, has_b1, has_root2, has_b2 = ctx.flags
-        g = _zero_pad_rows(g, shard.num_own)
-        # per layer: halo exchange of the gradient rows, then the parameter-gradient GEMM + its all-reduce behind it,
-        # then the input gradient (ReLU backward in its epilogue)
-        red2, gz = _backward_layer(agg2, h, g, w2, root2, h, shard, backend, group, has_root2, has_b2)
-        red1, gx = _backward_layer(agg1, x, gz, w1, root1, None, shard, backend, group, has_root1, has_b1,
-                                   need_x=ctx.needs_input_grad[0])
-        _wait(red2)
-        _wait(red1)
-        gw2, groot2, gb2 = _unflatten(red2[1], red2[2], has_root2, has_b2)
-        gw1, groot1, gb1 = _unflatten(red1[1], red1[2], has_root1, has_b1)
-        return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None, None
+        grads = _encoder2_bwd(ctx.saved_tensors, ctx.flags, g, ctx.shard, ctx.backend, ctx.group, ctx.needs_input_grad[0])
+        return grads + (None, None, None)
 
 
 class _PartitionedConvFunction(torch.autograd.Function):
@@ -724,10 +818,13 @@ class PartitionedEncoder:
 
     def __init__(self, edge_index: Tensor, edge_type: Tensor, num_nodes: int, num_relations: int,
                  emb_full: Tensor, convs: Sequence[torch.nn.Module], device, backend=None, group=None,
-                 scheme: Optional[str] = None, assignment: Optional[Tensor] = None, split: Optional[bool] = None):
-        """``assignment`` (int64 [N], optional): node -> rank from a locality-aware partitioner, identical on every
-        rank (default: the degree-balanced deal, computed on rank 0 and broadcast); ``split``: interior / boundary
-        overlap of the "pull" scheme (default on where a rank has >= 32 rows of each kind; RGCN_DIST_SPLIT=0)."""
+                 scheme: Optional[str] = None, assignment: Optional[Tensor] = None, split: Optional[bool] = None,
+                 partition: str = "auto"):
+        """``assignment`` (int64 [N], optional): node -> rank from a partitioner of the caller's, identical on every
+        rank; else ``partition``: "auto" (default: the locality-aware ``NodePartition.clustered`` on degree-skewed
+        graphs of PrimeKG's size, the degree-balanced deal otherwise), "clustered" or "deal" - computed on rank 0
+        and broadcast; ``split``: interior / boundary overlap of the "pull" scheme (default on where a rank has >= 32
+        rows of each kind)."""
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.group = group
@@ -736,7 +833,7 @@ class PartitionedEncoder:
         if assignment is not None:
             self.part = NodePartition.from_assignment(assignment, edge_index, self.world)
         else:
-            self.part = NodePartition.shared(edge_index, num_nodes, group, device)
+            self.part = NodePartition.shared(edge_index, num_nodes, group, device, method=partition)
         self.shard = RankShard(self.part, edge_index, edge_type, num_relations, self.rank, device,
                                self.backend, self.scheme, split=split)
         self.emb = self.part.shard_rows(emb_full, self.rank).to(device).requires_grad_(True)
@@ -770,8 +867,23 @@ class PartitionedEncoder:
         return partitioned_conv(h, c2.effective_weight(), c2.root, c2.bias, self.shard, self.backend,
                                 self.group)
 
-    def step(self, cot_own: Tensor) -> Tensor:
-        """forward + backward with the given cotangent rows; grads land in ``.grad``."""
+    def step(self, cot_own: Tensor, explicit: bool = True) -> Tensor:
+        """forward + backward with the given cotangent rows; grads land in ``.grad``.  ``explicit`` (default): the two
+        halves are called directly, without the autograd engine - at N > 1 a rank's kernels shrink with 1 / N while the
+        host cost of a step does not, and the engine's hop to its backward thread is ~100 us of it
+        (``tools/host_profile.py``); plain-weight layers only (a basis-decomposed layer takes the autograd route)."""
+        c1, c2 = self.convs
+        if explicit and c1.num_bases is None and c2.num_bases is None:
+            with torch.no_grad():
+                flags = (c1.root is not None, c1.bias is not None, c2.root is not None, c2.bias is not None)
+                out, saved = _encoder2_fwd(self.emb, c1.weight, c1.root, c1.bias, c2.weight, c2.root, c2.bias, self.shard,
+                                           self.backend, self.group)
+                grads = _encoder2_bwd(saved, flags, cot_own, self.shard, self.backend, self.group, True)
+            targets = (self.emb, c1.weight, c1.root, c1.bias, c2.weight, c2.root, c2.bias)
+            for p, gr in zip(targets, grads):
+                if p is not None:
+                    p.grad = gr
+            return out
         out = self.forward()
         for p in self.params:
             p.grad = None

@@ -516,10 +516,6 @@ class BucketedGraph:
             cache[key] = bool(_L().rgcn_aggregate_deferrable(handle, int(transposed), int(d)))
         return cache[key]
 
-    def hot_rows(self, transposed: bool, d: int) -> int:
-        """rows of the gathered table a gather of d-wide rows keeps in LDS (``rgcn_aggregate_hot_rows``; 0: plain)"""
-        return int(_lib.load().rgcn_aggregate_hot_rows(self.handle, int(transposed and not self.bipartite), int(d)))
-
     def weight_bound(self, transposed: bool) -> float:
         """``|aggregate(x) row| <= weight_bound * max |x|``: 1 for the mean structure, the largest
         per-segment sum of edge weights for a weighted one (memoised; fixed for the life of the handle)"""
@@ -1008,54 +1004,6 @@ def aggregate_deferred(graph: BucketedGraph, x: torch.Tensor, transposed: bool =
 # 1: the pass's first launch rides in conv1's gather (rgcn_aggregate_prep).  OFF by default: measured on the MI355X the
 # step gets 5 us SLOWER (0.286 against 0.281 ms, profiles/r03_prep_rides.txt) - in 256-thread workgroups the riders' scan
 # of the weights takes 8 rounds of loads instead of 2 and outlasts the gather it was meant to hide behind.
-PREP_RIDES = os.environ.get("RGCN_PREP_RIDES", "0") == "1"
-
-
-def aggregate_with_prep(graph: BucketedGraph, x: torch.Tensor, x_amax: torch.Tensor, clear: Optional[torch.Tensor],
-                        layers, deferred: bool = True):
-    """The first gather of a forward pass with the pass's first launch riding in its grid (``rgcn_aggregate_prep``):
-    ``absmax_and_split(x, x_amax, clear, layers)`` and ``aggregate[_deferred](graph, x)`` as ONE launch ->
-    ``(agg, hubs | None, [SplitWeights, ...])``, or None where the combination does not apply (the caller then issues
-    the two launches): measurement mode, a weighted / fp16 / wide structure, a layer the split kernels do not tile,
-    weights too large for the merged launch."""
-    d = x.size(1) if x.dim() == 2 else 0
-    if (not PREP_RIDES or GATHER_EVENTS is not None or GEMM_PRECISION != "split" or x.dtype != torch.float32
-            or d not in (64, 128, 256) or graph.weighted_shard or x.size(0) != graph.num_other_nodes or graph.num_edges == 0
-            or not layers or len(layers) > 4):
-        return None
-    for weight, root in layers:
-        if weight.dim() != 3 or weight.size(1) % 32 or weight.size(2) % 32:
-            return None
-        if weight.numel() + (root.numel() if root is not None else 0) > _MERGED_PACK_MAX:
-            return None
-    _need_gpu("x", x, torch.float32)
-    _check_amax("x_amax", x_amax, x.device)
-    defer = bool(deferred and graph.num_levels(False) == 2 and graph.deferrable(False, d))
-    count = 0
-    if clear is not None:
-        _need_gpu("clear", clear, torch.float32)
-        count = clear.numel() // AMAX_FLOATS
-    lib = _L()
-    n = len(layers)
-    with _on(x.device):
-        out = _empty(graph.num_nodes, graph.num_relations * d, dtype=torch.float32, device=x.device)
-        nbytes = graph.workspace_bytes(False, d)
-        ws = _workspace(nbytes, x.device)
-        sizes = [_query("rgcn_weights_split_bytes", *w.shape) for w, _ in layers]
-        bufs = [_empty(sz, dtype=torch.uint8, device=x.device) for sz in sizes]
-        arr, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
-        cast = lambda a: ctypes.cast(a, ctypes.c_void_p)                                   # noqa: E731
-        rc = lib.rgcn_aggregate_prep(
-            graph.handle, 0, _ptr(x), d, _ptr(out), _ptr(ws), nbytes, int(defer), _ptr(x_amax), _ptr(clear), count, n,
-            cast(arr(*[_ptr(w) for w, _ in layers])), cast(arr(*[_ptr(r) for _, r in layers])),
-            cast(i64(*[w.size(0) for w, _ in layers])), cast(i64(*[w.size(1) for w, _ in layers])),
-            cast(i64(*[w.size(2) for w, _ in layers])), cast(arr(*[_ptr(b) for b in bufs])),
-            cast((ctypes.c_size_t * n)(*sizes)), _stream())
-    _lib.check(rc, "rgcn_aggregate_prep")
-    packs = [SplitWeights(b, w, r) for b, (w, r) in zip(bufs, layers)]
-    return out, (DeferredHubs(graph, False, ws) if defer else None), packs
-
-
 def _hub_args(hubs: Optional[DeferredHubs], n: int, r: int):
     if hubs is None:
         return None, 0, None
@@ -1663,10 +1611,10 @@ _SEQ_STREAM_POS = {"rgcn_absmax": 5, "rgcn_absmax_multi": 6, "rgcn_absmax_pack":
                    "rgcn_aggregate": 7, "rgcn_aggregate_and_reduce": 8, "rgcn_aggregate_amax": 9, "rgcn_aggregate_deferred": 8,
                    "rgcn_transform_fwd_split": 20, "rgcn_transform_bwd_input_split": 19, "rgcn_transform_first_split": 12,
                    "rgcn_transform_bwd_params_split_begin": 18, "rgcn_slab_reduce": 1, "rgcn_layer_fwd_fused": 17,
-                   "rgcn_layer_bwd_input_fused": 17, "rgcn_aggregate_prep": 19}
-_SEQ_PURE = ("rgcn_aggregate_hot_rows", "rgcn_graph_tile_mask", "rgcn_graph_num_levels", "rgcn_graph_weight_bound", "rgcn_aggregate_deferrable",
+                   "rgcn_layer_bwd_input_fused": 17}
+_SEQ_PURE = ("rgcn_graph_tile_mask", "rgcn_graph_num_levels", "rgcn_graph_weight_bound", "rgcn_aggregate_deferrable",
              "rgcn_graph_num_edges", "rgcn_graph_num_nodes", "rgcn_graph_num_relations", "rgcn_abi_version", "rgcn_strerror")
-REGIONS = os.environ.get("RGCN_NATIVE_STEP", "1") == "1"      # 0: always through the wrappers (A/B runs, debugging)
+REGIONS = True      # False: always through the wrappers (tests, tools/host_profile.py)
 
 
 def guard_torch_op(what: str) -> None:
@@ -1835,7 +1783,38 @@ class _Recorder:
 
 
 class _Plan:
-    def __init__(self, rec: _Recorder, outputs):
+    def __init__(self, rec: _Recorder, outputs, want=()):
+        # Outputs the caller LOOKS AT (`want`) and that are whole allocations of the pass get a tensor of their own at
+        # replay time, addressed through one more base pointer: an arena view handed out of an autograd Function would
+        # refuse in-place ops on it ("a view ... is being modified inplace"), would keep the whole arena (aggregates,
+        # workspaces, split images) alive for as long as the caller holds it, and `torch.save` would write all of it.
+        self.external = []                                   # (arena offset, nbytes, shape, dtype) per such output
+        ext_of = {}
+        n_in = len(rec.inputs)
+        spans = {off: nb for off, nb in zip(rec.offsets, rec.sizes)}
+        outputs = list(outputs)
+        for i in sorted(want):
+            spec = outputs[i] if i < len(outputs) else None
+            if spec is None or spec[0] != "arena":
+                continue
+            off, shape, dtype = spec[1], spec[2], spec[3]
+            n = 1
+            for d in shape:
+                n *= d
+            nbytes = n * torch.empty((), dtype=dtype).element_size()
+            if nbytes and spans.get(off) == nbytes:
+                if off not in ext_of:
+                    ext_of[off] = len(self.external)
+                    self.external.append((off, nbytes, shape, dtype))
+                outputs[i] = ("external", ext_of[off])
+
+        def rebase(kind, index, value):
+            if kind == _lib.SEQ_BASE and index == 0:
+                for e, (off, nbytes, _, _) in enumerate(self.external):
+                    if off <= value < off + nbytes:
+                        return (kind, 1 + n_in + e, value - off)
+            return (kind, index, value)
+
         flat, calls = [], []
         tails = []                                           # array entries live behind the calls' own arguments
         for fn, descs in rec.calls:
@@ -1852,7 +1831,7 @@ class _Plan:
                 start = len(flat) + len(tails)
                 tails.extend(entries)
                 slot[:] = [_lib.SEQ_ARRAY, start, len(entries)]
-        allargs = [tuple(a) for a in flat] + [tuple(t) for t in tails]
+        allargs = [rebase(*a) for a in flat] + [rebase(*t) for t in tails]
         self.num_calls, self.num_args = len(calls), len(allargs)
         self.calls = (_lib.SeqCall * max(1, len(calls)))(*[_lib.SeqCall(fn, n, first) for fn, n, first in calls])
         args = (_lib.SeqArg * max(1, len(allargs)))()
@@ -1882,20 +1861,28 @@ class _Plan:
                     return False
                 continue
             dtype, shape, index = sig
-            if isinstance(t, Lazy):
-                if t.dtype is not dtype or t.shape != shape:
+            if isinstance(t, Lazy):                          # (an arena view is dense by construction)
+                if t.dtype is not dtype or t.shape != shape or t.arena.get_device() != index:
                     return False
-            elif t.dtype is not dtype or t.shape != shape or t.get_device() != index:
-                return False
+            elif t.dtype is not dtype or t.shape != shape or t.get_device() != index or not t.is_contiguous():
+                return False                                 # (a strided input would be read as dense through its data_ptr)
         return True
 
-    def run(self, inputs, want, zero=False):
-        """-> list of outputs: tensors for the positions in `want`, Lazy for the rest"""
+    def run(self, inputs, want, fill=None):
+        """-> list of outputs: tensors for the positions in `want`, Lazy for the rest.  `fill`: a byte value the arena
+        and the external outputs are filled with first (the acceptance replays of Region.run); None = torch.empty"""
         lib = _lib.load()
         with _on(self.device):
-            arena = (torch.zeros if zero else torch.empty)(self.arena_bytes, dtype=torch.uint8, device=self.device)
-            nb = len(inputs) + 1
-            bases = (ctypes.c_void_p * nb)(arena.data_ptr(), *[t.data_ptr() if t is not None else None for t in inputs])
+            if fill is None:
+                arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=self.device)
+                ext = [torch.empty(shape, dtype=dtype, device=self.device) for _, _, shape, dtype in self.external]
+            else:
+                arena = torch.full((self.arena_bytes,), fill, dtype=torch.uint8, device=self.device)
+                ext = [torch.full((nbytes,), fill, dtype=torch.uint8, device=self.device).view(dtype).view(shape)
+                       for _, nbytes, shape, dtype in self.external]
+            nb = len(inputs) + 1 + len(ext)
+            bases = (ctypes.c_void_p * nb)(arena.data_ptr(), *[t.data_ptr() if t is not None else None for t in inputs],
+                                           *[t.data_ptr() for t in ext])
             rc = lib.rgcn_sequence_run(self.calls, self.num_calls, self.args, self.num_args, bases, nb, _stream())
         _lib.check(rc, "rgcn_sequence_run")
         outs = []
@@ -1905,6 +1892,8 @@ class _Plan:
                 outs.append(None)
             elif spec[0] == "input":
                 outs.append(inputs[spec[1]])
+            elif spec[0] == "external":
+                outs.append(ext[spec[1]])
             else:
                 lz = Lazy(arena, spec[1], spec[2], spec[3], alias)
                 outs.append(lz.tensor() if i in want else lz)
@@ -1931,7 +1920,11 @@ class Region:
         state = store.get(full_key)
         if isinstance(state, _Plan):
             if state.matches(tensors):
-                return state.run(tensors, want)
+                try:
+                    return state.run(tensors, want)
+                except torch.cuda.OutOfMemoryError:          # the arena lays a pass's temporaries side by side: a step that
+                    store[full_key] = self.DISABLED          # fits through the wrappers (which free as they go) keeps running
+                    return self._eager(tensors, static)
             return self._eager(tensors, static)              # (the wrappers say what is wrong with these inputs)
         if state == self.DISABLED or torch.cuda.is_current_stream_capturing():
             return self._eager(tensors, static)
@@ -1957,7 +1950,11 @@ class Region:
             store[full_key] = ("sizes", rec.sizes)
             return list(outs)
         # third run: every allocation in one arena, every call noted; then the native replay must reproduce it
-        rec = _Recorder(dev, sizes=state[1], inputs=tensors)
+        try:
+            rec = _Recorder(dev, sizes=state[1], inputs=tensors)
+        except torch.cuda.OutOfMemoryError:
+            store[full_key] = self.DISABLED
+            return self._eager(tensors, static)
         _REC = rec
         try:
             outs = list(self.fn(*tensors, **static))
@@ -1983,14 +1980,33 @@ class Region:
         if rec.cursor != len(rec.sizes) or len(rec.jobs) > 8:
             store[full_key] = self.DISABLED
             return outs
-        plan = _Plan(rec, specs)
+        plan = _Plan(rec, specs, want)
+        # Acceptance: the noted list, issued natively, must reproduce the recorded results bit for bit - replayed TWICE,
+        # into memory filled with 0x00 (what the recording ran in: bytes no launch writes compare equal) and with 0xFF
+        # (what a production replay may meet: torch.empty).  A byte of an output that differs between the two replays
+        # must be one NO launch defines (0x00 in the one, 0xFF in the other: the unused entries of an amax buffer, the
+        # alignment gaps of the split images); anything else means a launch READS memory it expects cleared, which the
+        # zero-filled check alone would have passed and torch.empty would break.
+        def as_bytes(t):
+            return t.contiguous().view(-1).view(torch.uint8)
         try:
-            again = plan.run(tensors, want=set(range(len(specs))), zero=True)
-            same = all((a is None and b is None) or (a is b) or torch.equal(a, b) for a, b in zip(outs, again))
+            everything = set(range(len(specs)))
+            zeros = plan.run(tensors, want=everything, fill=0)
+            ones = plan.run(tensors, want=everything, fill=255)
+            same = True
+            for a, z, f in zip(outs, zeros, ones):
+                if a is None or a is z:
+                    same = same and (z is None or a is z)
+                    continue
+                za, fa = as_bytes(z), as_bytes(f)
+                undefined = za != fa
+                same = same and torch.equal(a, z) and bool(((za == 0) & (fa == 255))[undefined].all())
         except (RuntimeError, ValueError, IndexError):
             same = False
         store[full_key] = plan if same else self.DISABLED
-        return outs
+        # this run's results sit in the recorder's arena: what the caller looks at leaves it as a tensor of its own, like
+        # the outputs of every later (replayed) and earlier (eager) step - no view of a shared buffer is handed out
+        return [o.clone() if (i in want and specs[i] is not None and specs[i][0] == "arena") else o for i, o in enumerate(outs)]
 
     def _eager(self, tensors, static):
         return list(self.fn(*[materialize(t) for t in tensors], **static))

@@ -423,9 +423,38 @@ def test_partition_is_balanced_and_consistent():
     assert torch.equal(part.unshard_rows(gathered), full)
 
 
+def test_clustered_partition_keeps_neighbourhoods_together():
+    """``NodePartition.clustered``: on the PrimeKG-shaped graph most rows are interior only by
+    accident under the degree-balanced deal; placing the light nodes WITH their neighbours nearly doubles the interior
+    rows of every rank and cuts fewer edges, at the same row capacity and edge balance - so the interior-first
+    overlap of the "pull" scheme has rows to work with.  A uniform random graph has none to find: "auto" keeps the deal."""
+    ei, et, n, r = synth.primekg_like(seed=42)
+    deg_in = torch.bincount(ei[1], minlength=n).float()
+    for world in (2, 8):
+        deal = rdist.NodePartition(ei, n, world)
+        part = rdist.NodePartition.clustered(ei, n, world)
+        assert part.cap == deal.cap and int(part.counts.max()) <= part.cap and int(part.counts.sum()) == n
+        assert torch.unique(part.pid).numel() == n
+        per_rank = torch.zeros(world).index_add_(0, part.rank_of, deg_in)
+        assert per_rank.max() / per_rank.mean() <= 1.05
+        assert int(part.num_interior.sum()) >= 1.4 * int(deal.num_interior.sum()), (world, part.num_interior, deal.num_interior)
+        assert int(part.num_interior.min()) >= 1.4 * int(deal.num_interior.min())       # on EVERY rank, not one lucky one
+        cut = lambda p: float((p.rank_of[ei[0]] != p.rank_of[ei[1]]).float().mean())    # noqa: E731
+        assert cut(part) < cut(deal) - 0.05
+        # interior means what RankShard relies on: no edge of an interior row, either direction, crosses ranks
+        inner = part.interior
+        assert not ((part.rank_of[ei[0]] != part.rank_of[ei[1]]) & (inner[ei[0]] | inner[ei[1]])).any()
+    auto = rdist.NodePartition.build(ei, n, 8, "auto")
+    assert torch.equal(auto.rank_of, rdist.NodePartition.clustered(ei, n, 8).rank_of)        # deterministic, and chosen
+    ue, _, un, _ = synth.uniform_graph(20000, 400000, 4, seed=1)
+    assert torch.equal(rdist.NodePartition.build(ue, un, 8, "auto").rank_of, rdist.NodePartition(ue, un, 8).rank_of)
+    with pytest.raises(ValueError):
+        rdist.NodePartition.build(ei, n, 8, "metis")
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_hip_shards_match_single_gpu_bitwise(world, monkeypatch):
+@pytest.mark.parametrize("world,method", [(2, "deal"), (4, "deal"), (8, "deal"), (8, "clustered")])
+def test_hip_shards_match_single_gpu_bitwise(world, method, monkeypatch):
     """Each rank's bipartite structures on the real kernels; the all-gathers are emulated by
     concatenating the ranks' rows.  Activations and input grads must equal the 1-GPU path
     bit for bit; parameter grads (summed over ranks) to 1e-5.  (fp32 arithmetic: the split-precision
@@ -447,7 +476,7 @@ def test_hip_shards_match_single_gpu_bitwise(world, monkeypatch):
     gw1, groot1, gbias1 = ops.transform_bwd_params(agg1, x.to(dev), g.to(dev), r)
     # P ranks
     backend = rdist.HipBackend()
-    part = rdist.NodePartition(ei, n, world)
+    part = rdist.NodePartition.build(ei, n, world, method)      # (clustered: another owner for most rows, the same bits)
     xd, gd = x.to(dev), g.to(dev)
     outs, gxs, gw, groot, gbias = [], [], 0, 0, 0
     for k in range(world):
@@ -466,6 +495,110 @@ def test_hip_shards_match_single_gpu_bitwise(world, monkeypatch):
     assert torch.equal(part.unshard_rows(torch.cat(gxs)), gx1)
     for got, want in ((gw, gw1), (groot, groot1), (gbias, gbias1)):
         assert ((got - want).abs().max() / want.abs().max()).item() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+def test_config_c4_node_partitioned_over_8_ranks_at_full_size(precision, monkeypatch):
+    """BASELINE configs[3] as it is WRITTEN: 500,000 nodes / 20,000,000 edge columns / 16 relations, 64 -> 128,
+    node-partitioned across 8 ranks.  One GPU builds each rank's shard in turn (partition, halo plans, both bucketed
+    shard structures of its ~2.5 M edges - the previous one freed), runs the layer forward, the input gradient and the
+    parameter gradients on it with the halo exchange emulated from the full tensors, and compares with the
+    single-GPU run of the whole graph: >= 64 sampled output and grad_x rows per rank (bit for bit in fp32 arithmetic,
+    where a rank's result cannot depend on which rows it holds; 1e-5 of the largest entry in split precision, where
+    every rank scales by the maximum of ITS rows) and the parameter gradients summed over the ranks at 1e-5.  Edge
+    balance <= 1.05; halo rows / bytes per rank and the peak memory go to gpurun_out/r04_c4_shards.txt."""
+    import json
+    dev = need_gpu()
+    if torch.cuda.get_device_properties(dev).total_memory < 60 * 2 ** 30:
+        pytest.skip("needs ~40 GB of device memory")
+    monkeypatch.setattr(ops, "GEMM_PRECISION", precision)
+    world, d_in, d_out = 8, 64, 128
+    ei, et, n, r = synth.uniform_graph(500_000, 20_000_000, 16, seed=42)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(n, d_in, generator=gen).to(dev)
+    g = (torch.randn(n, d_out, generator=gen) * 1e-3).to(dev)
+    torch.manual_seed(3)
+    conv = RGCNConv(d_in, d_out, r).to(dev)
+    conv.bias.data.uniform_(-0.1, 0.1)
+    w, root, bias = conv.weight.detach(), conv.root.detach(), conv.bias.detach()
+    eid, etd = ei.to(dev), et.to(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    # ---- the whole graph on the one GPU (separate kernels: the same entry points the shards take)
+    graph = ops.BucketedGraph(eid, etd, n, r)
+    amax_x = (ops.absmax(x),) * 2 if precision == "split" else None
+    agg1 = ops.aggregate(graph, x)
+    out1 = ops.transform_fwd(agg1, x, w, root, bias, amax=amax_x)
+    gw1, groot1, gbias1 = ops.transform_bwd_params(agg1, x, g, r, graph=graph)
+    del agg1
+    amax_g = (ops.absmax(g),) * 2 if precision == "split" else None
+    gagg1 = ops.aggregate(graph, g, transposed=True)
+    gx1 = ops.transform_bwd_input(gagg1, g, w, root, amax=amax_g, amax_mul=graph.weight_bound(True))
+    del gagg1
+    graph.destroy()
+    torch.cuda.synchronize()
+    peak_single = torch.cuda.max_memory_allocated(dev)
+    # ---- 8 ranks, one after the other
+    backend = rdist.HipBackend()
+    part = rdist.NodePartition(ei, n, world)
+    deg = torch.bincount(ei[1], minlength=n).float()
+    per_rank_edges = torch.zeros(world).index_add_(0, part.rank_of, deg)
+    balance = float(per_rank_edges.max() / per_rank_edges.mean())
+    assert balance <= 1.05, balance
+    report = {"config": "C4 500000 / 20000000 / 16, 64 -> 128, P = 8 (degree-balanced deal), one GPU, shards in turn",
+              "precision": precision, "edge_balance_max_over_mean": balance, "cap_rows": part.cap, "ranks": []}
+    gw, groot, gbias = 0, 0, 0
+    pick = torch.Generator().manual_seed(11)
+    worst_out = worst_gx = 0.0
+    for k in range(world):
+        torch.cuda.reset_peak_memory_stats(dev)
+        shard = rdist.RankShard(part, eid, etd, r, k, dev, backend)
+        nodes = part.nodes_of(k).to(dev)
+        x_own, g_own = x.new_zeros(part.cap, d_in), g.new_zeros(part.cap, d_out)
+        x_own[: nodes.numel()], g_own[: nodes.numel()] = x[nodes], g[nodes]
+        x_tbl = shard.halo_in.emulate(x_own, x)          # [own rows | the rows the halo exchange would deliver]
+        g_tbl = shard.halo_out.emulate(g_own, g)
+        agg = backend.aggregate(shard.g_in, x_tbl)
+        out = backend.transform_fwd(agg, x_own, w, root, bias, False, shard.g_in, table=x_tbl)
+        gagg = backend.aggregate(shard.g_out, g_tbl)
+        gx = backend.transform_bwd_input(gagg, g_own, w, root, None, shard.g_out, table=g_tbl)
+        del gagg
+        a, b, c = backend.transform_bwd_params(agg, x_own, g_own, r, True, True, shard.g_in)
+        gw, groot, gbias = gw + a, groot + b, gbias + c
+        rows = torch.randperm(nodes.numel(), generator=pick)[:96].to(dev)          # >= 64 sampled rows of this rank
+        for got, want, tag in ((out, out1, "out"), (gx, gx1, "gx")):
+            gr, wr = got[rows], want[nodes[rows]]
+            if precision == "fp32":
+                assert torch.equal(gr, wr), (k, tag)
+            else:
+                err = float((gr - wr).abs().max() / want.abs().max())
+                assert err <= 1e-5, (k, tag, err)
+                if tag == "out":
+                    worst_out = max(worst_out, err)
+                else:
+                    worst_gx = max(worst_gx, err)
+        torch.cuda.synchronize()
+        report["ranks"].append({
+            "rank": k, "own_rows": shard.num_own, "interior_rows": shard.num_interior,
+            "in_edges": shard.num_in_edges, "out_edges": shard.num_out_edges,
+            "halo_rows_forward": shard.halo_in.num_halo, "halo_rows_backward": shard.halo_out.num_halo,
+            "halo_bytes_forward_layer1": shard.halo_in.num_halo * d_in * 4,
+            "halo_bytes_backward_layer1": shard.halo_out.num_halo * d_out * 4,
+            "send_rows_forward": shard.halo_in.num_send,
+            "peak_device_bytes": int(torch.cuda.max_memory_allocated(dev))})
+        del shard, agg, out, gx, x_tbl, g_tbl, x_own, g_own
+        ops.clear_graph_cache()
+    for got, want in ((gw, gw1), (groot, groot1), (gbias, gbias1)):
+        assert ((got - want).abs().max() / want.abs().max()).item() < 1e-5
+    report["single_gpu_peak_device_bytes"] = int(peak_single)
+    report["worst_sampled_row_error_vs_single_gpu"] = {"out": worst_out, "grad_x": worst_gx}
+    try:
+        root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root_dir, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root_dir, "gpurun_out", f"r04_c4_shards_{precision}.txt"), "w") as f:
+            f.write(json.dumps(report, indent=1) + "\n")
+    except OSError:
+        pass
 
 
 @pytest.mark.gpu

@@ -224,7 +224,7 @@ def test_fp16_gather_training_reaches_the_same_auc(tmp_path):
     # run is one epoch on the synthetic PrimeKG-shaped graph - a +-0.005 agreement test between the two arithmetics.
     try:
         import json, os
-        log_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r03.json")
+        log_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_r04.json")
         os.makedirs(os.path.dirname(log_path), exist_ok=True)
         log = json.load(open(log_path)) if os.path.exists(log_path) else {}
         log["C5_auc_one_epoch_synthetic"] = {"auc_roc_fp32_run": float(aucs[0]), "auc_roc_fp16_run": float(aucs[1]),

@@ -18,7 +18,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from primekg_rgcn_linkprediction_amd import RGCNConv, ops, rgcn_encoder2, synth  # noqa: E402
+from primekg_rgcn_linkprediction_amd import RGCNConv, ops, rgcn_encoder2, rgcn_encoder2_step, synth  # noqa: E402
 
 dev = torch.device("cuda:0")
 
@@ -33,6 +33,13 @@ def make(ei, et, n, r):
     def step():
         out = rgcn_encoder2(emb, eid, etd, convs[0], convs[1])
         out.backward(cot)
+
+    def explicit():                                  # the same two passes without the autograd engine (round 4)
+        for p in params:
+            p.grad = None
+        rgcn_encoder2_step(emb, eid, etd, convs[0], convs[1], cot)
+    params = [emb] + [p for c in convs for p in c.parameters()]
+    step.explicit = explicit
     return step
 
 
@@ -58,6 +65,10 @@ for native in (True, False):
     issue, total = per_step(small, 2000)
     print(f"{label}: 1k-node graph (host-bound) {total * 1e6:.0f} us per step = host cost of an eager encoder step")
 ops.REGIONS = True
+issue, total = per_step(big.explicit, 200)
+print(f"explicit step (rgcn_encoder2_step: both passes, no autograd engine): C2 {issue * 1e6:.0f} us per step issued, {total * 1e6:.0f} us with the final sync")
+issue, total = per_step(small.explicit, 2000)
+print(f"explicit step (rgcn_encoder2_step: both passes, no autograd engine): 1k-node graph (host-bound) {total * 1e6:.0f} us per step")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(2000):

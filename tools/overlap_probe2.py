@@ -2,7 +2,7 @@
 stream) run BESIDE the transposed gather that does not depend on it (bound by indexed L2 reads, 4 KB of LDS per
 workgroup)?  C2's graph and shapes; each variant captured as a HIP graph of `reps` repetitions and replayed.
 
-    python tools/overlap_probe2.py          ->  us per (TN + gather) pair: one stream / two streams, both launch orders
+    (needs the plane entry points of commit e229a4a)  python tools/overlap_probe2.py          ->  us per (TN + gather) pair: one stream / two streams, both launch orders
 """
 import ctypes
 import sys

@@ -2,7 +2,7 @@
 // that split in their loops - same data, C2's shapes.  Checks that the plane kernels return the SAME BITS (slabs of the
 // parameter-gradient GEMM, outputs of the NT transform, the planes an NT transform emits against k_split_planes) and
 // times both (events, 20 launches each).
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/planes_probe.hip -o tools/planes_probe && tools/planes_probe
+// (builds against the kernels of commit e229a4a, where k_gemm_tn_planes / the A1P NT variant / k_split_planes live; results: profiles/r04_planes_probe.txt)
 #include "../primekg_rgcn_linkprediction_amd/csrc/rgcn_transform_split.hip"
 
 #include <cstdio>
