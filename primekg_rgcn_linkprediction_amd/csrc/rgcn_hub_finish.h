@@ -10,7 +10,7 @@
 #endif
 
 #if defined(__HIPCC__)
-// Called by ALL threads of a workgroup of 256 or more; the first 256 do the work, the others only meet the barrier.  Rows [it.begin, it.end) of `partial` (contiguous, d floats each) ->
+// Called by all 256 threads of a workgroup.  Rows [it.begin, it.end) of `partial` (contiguous, d floats each) ->
 // one row: slot s of SLOTS = 256 / G sums rows begin + s, begin + s + SLOTS, ... in order (RGCN_REDUCE_UNROLL loads
 // in flight); the slots are then added in slot order through LDS (`red`: 256 float4).  Columns [4 * col0, 4 * col0
 // + 4 G) of the row.  FINAL items: divided by cnt[dst] (mean structures) and written to agg row `dst`; others to
@@ -22,8 +22,7 @@ __device__ inline float rgcn_reduce_item(const rgcn_item it, const float* __rest
   constexpr int SLOTS = 256 / G;
   const int gl = (int)threadIdx.x % G, slot = (int)threadIdx.x / G;
   const int c4 = (gl + col0) * 4;
-  const bool worker = threadIdx.x < 256;
-  const bool live = worker && c4 < d;
+  const bool live = c4 < d;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) {
     for (int r0 = it.begin + slot; r0 < it.end; r0 += SLOTS * RGCN_REDUCE_UNROLL) {
@@ -40,7 +39,7 @@ __device__ inline float rgcn_reduce_item(const rgcn_item it, const float* __rest
       }
     }
   }
-  if (worker) red[threadIdx.x] = acc;
+  red[threadIdx.x] = acc;
   __syncthreads();
   float lmax = 0.f;
   if (slot == 0 && live) {

@@ -148,49 +148,30 @@ struct hub_fin {
   int d, tiles;
 };
 
-// (the arguments of one NT launch: the stand-alone kernel takes them as they are, the paired backward launch -
-// k_bwd_pair below - carries them beside a parameter-gradient job's)
-struct nt_args {
-  const float* A1; int K1; const float* A2; int K2;
-  const __half* Bh; const __half* Bl; const float* b_inv_scale;
-  amax_ref amax1; float a1_mul; amax_ref amax2;
-  const float* bias; const float* mask; float* C; int M, N;
-  const uint32_t* tile_mask; int kseg; unsigned* amax_out; hub_fin fin; float out_scale;
-};
-template <int WM, int WN, int TN, bool LO, int NB = (WM == 2 ? 3 : 4)>
-constexpr int nt_lds_bytes() {
-  return NB * (32 * WM * BK * 4 + (LO ? 2 : 1) * 32 * TN * WN * BK * 2);
-}
-
-// workgroup (bid_x, bid_y) of the launch; `lds`: nt_lds_bytes<WM, WN, TN, LO>() bytes, 16-byte aligned, the ONLY LDS it uses
-template <int WM, int WN, int TN, int EPI, bool LO, int NB = (WM == 2 ? 3 : 4)>
-__device__ inline void nt_block(const nt_args& a, char* lds, const int bid_x, const int bid_y) {
-  const float* __restrict__ A1 = a.A1;
-  const float* __restrict__ A2 = a.A2;
-  const __half* __restrict__ Bh = a.Bh;
-  const __half* __restrict__ Bl = a.Bl;
-  const float* __restrict__ b_inv_scale = a.b_inv_scale;
-  const float* __restrict__ bias = a.bias;
-  const float* __restrict__ mask = a.mask;
-  float* __restrict__ C = a.C;
-  const uint32_t* __restrict__ tile_mask = a.tile_mask;
-  unsigned* __restrict__ amax_out = a.amax_out;
-  const int K1 = a.K1, K2 = a.K2, M = a.M, N = a.N, kseg = a.kseg;
-  const amax_ref amax1 = a.amax1, amax2 = a.amax2;
-  const float a1_mul = a.a1_mul, out_scale = a.out_scale;
-  const hub_fin fin = a.fin;
+template <int WM, int WN, int TN, int EPI, bool LO>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __restrict__ A1, int K1,
+                                                            const float* __restrict__ A2, int K2,
+                                                            const __half* __restrict__ Bh,
+                                                            const __half* __restrict__ Bl,
+                                                            const float* __restrict__ b_inv_scale,
+                                                            amax_ref amax1, float a1_mul, amax_ref amax2,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ mask, float* __restrict__ C,
+                                                            int M, int N, const uint32_t* __restrict__ tile_mask,
+                                                            int kseg, unsigned* __restrict__ amax_out,
+                                                            const hub_fin fin, float out_scale) {
   constexpr int WAVES = WM * WN;                 // WM wave rows (32 output rows each) x WN wave columns (32 TN columns each)
-  constexpr int BM = 32 * WM, BN = 32 * TN * WN, NBUF = NB, D = NBUF - 1;   // D k-tiles in flight
+  constexpr int BM = 32 * WM, BN = 32 * TN * WN, NBUF = WM == 2 ? 3 : 4, D = NBUF - 1;   // D k-tiles in flight
   constexpr int PARTS = LO ? 2 : 1;              // B images staged: hi (and lo)
   constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 2, BUF_BYTES = A_BYTES + PARTS * B_BYTES;
   constexpr int A_PW = BM / (8 * WAVES);         // A DMA instructions per wave and k-tile (8 rows of 128 B each)
   constexpr int B_PW = BN / (16 * WAVES);        // B DMA instructions per wave, k-tile and part (16 rows of 64 B each)
   constexpr int P = A_PW + PARTS * B_PW;
   static_assert(A_PW >= 1 && B_PW >= 1 && A_PW * 8 * WAVES == BM && B_PW * 16 * WAVES == BN, "tile / wave layout");
-  static_assert(NBUF * BUF_BYTES == nt_lds_bytes<WM, WN, TN, LO, NB>(), "LDS size");
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * BUF_BYTES];   // the ONLY LDS object
 
   const int K = K1 + K2;
-  const int m0 = bid_x * BM, n0 = bid_y * BN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -215,7 +196,7 @@ __device__ inline void nt_block(const nt_args& a, char* lds, const int bid_x, co
   // Hub rows of this workgroup's row tiles whose partial rows the gather left unsummed: summed here, by the whole
   // workgroup, exactly as k_reduce_partials would (same function), written to A1 and only then read back by the
   // DMAs below.  Workgroups of other column blocks of the same rows write the same values.
-  if (WAVES >= 4 && fin.ptr) {                  // (rgcn_reduce_item: 256 threads sum, a larger workgroup's others only meet the barriers)
+  if (WAVES == 4 && fin.ptr) {                   // (rgcn_reduce_item is written for 256 threads)
     const int t32 = m0 >> 5;
     const int jb = __builtin_amdgcn_readfirstlane(fin.ptr[min(t32, fin.tiles)]);
     const int je = __builtin_amdgcn_readfirstlane(fin.ptr[min(t32 + WM, fin.tiles)]);
@@ -320,13 +301,9 @@ __device__ inline void nt_block(const nt_args& a, char* lds, const int bid_x, co
   auto k_tile = [&](const float sa) {
     // k-tile ktq[0] has landed for this wave (all but the DMAs of the tiles staged behind it are done), then for
     // every wave; the barrier also says all waves are done reading the buffer the stage() below refills
-    if constexpr (D == 1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if (D == 3 && ktq[D - 1] < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-      else if (ktq[D > 1 ? 1 : 0] < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (D == 3 && ktq[D - 1] < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
+    else if (ktq[1] < K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const unsigned buf = (unsigned)((t % NBUF) * BUF_BYTES);
     f32x4 fa[2][2], fh[2][TN], fl[2][TN];
@@ -477,12 +454,6 @@ __device__ inline void nt_block(const nt_args& a, char* lds, const int bid_x, co
   RGCN_STAMP(3);
 }
 
-template <int WM, int WN, int TN, int EPI, bool LO, int NB = (WM == 2 ? 3 : 4)>
-__global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const nt_args a) {
-  __shared__ __attribute__((aligned(16))) char lds[nt_lds_bytes<WM, WN, TN, LO, NB>()];   // the ONLY LDS object
-  nt_block<WM, WN, TN, EPI, LO, NB>(a, lds, (int)blockIdx.x, (int)blockIdx.y);
-}
-
 // max |x| of up to kPrepTensors tensors, each into its own amax buffer, in ONE launch - no atomics and no prior
 // clearing: workgroup b of RGCN_AMAX_HEADS writes its partial maximum of every tensor to head b of that
 // tensor's buffer; it also ZEROES head b of `zero_count` further amax buffers that start at `zero` (the buffers
@@ -538,42 +509,33 @@ __global__ __launch_bounds__(kPackThreads) void k_absmax_pack(const absmax_multi
 // LDS: 3 x 32 KB + 2 x 32 KB = all 160 KB of the CU, one 512-thread workgroup per CU.
 // ---------------------------------------------------------------------------------------
 constexpr int TN_TKC = 128;
-struct tn_args {
-  const float* A1; int K1; const float* A2; int K2; const float* G; int M, N, n_tiles, rows_per_split;
-  amax_ref amax1; float a1_mul; amax_ref amax2, gmax;
-  float* slab; float* bias_part; const uint32_t* tile_mask; int kseg;
-};
-constexpr int TN_LDS_BYTES = 3 * (32 * TN_TKC + 32 * 128) * 4 + 2 * 4 * (4 * 128 * 16);   // ring + plane buffers: 160 KB
-
-// workgroup `lin` of a gx x gy grid (lin = y * gx + x); `lds`: TN_LDS_BYTES bytes, the ONLY LDS it uses
 template <bool LO>
-__device__ inline void tn_block(const tn_args& a, char* lds, const int lin, const int gx, const int gy) {
-  const float* __restrict__ A1 = a.A1;
-  const float* __restrict__ A2 = a.A2;
-  const float* __restrict__ G = a.G;
-  float* __restrict__ slab = a.slab;
-  float* __restrict__ bias_part = a.bias_part;
-  const uint32_t* __restrict__ tile_mask = a.tile_mask;
-  const int K1 = a.K1, K2 = a.K2, M = a.M, N = a.N, n_tiles = a.n_tiles, rows_per_split = a.rows_per_split, kseg = a.kseg;
-  const amax_ref amax1 = a.amax1, amax2 = a.amax2, gmax = a.gmax;
-  const float a1_mul = a.a1_mul;
+__global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const float* __restrict__ A1, int K1,
+                                                               const float* __restrict__ A2, int K2,
+                                                               const float* __restrict__ G, int M, int N,
+                                                               int n_tiles, int rows_per_split,
+                                                               amax_ref amax1, float a1_mul, amax_ref amax2, amax_ref gmax,
+                                                               float* __restrict__ slab,
+                                                               float* __restrict__ bias_part,
+                                                               const uint32_t* __restrict__ tile_mask, int kseg) {
   constexpr int TKC = TN_TKC, RING = 3, A_FLOATS = 32 * TKC, G_FLOATS = 32 * 128;
   constexpr int SLOT_BYTES = (A_FLOATS + G_FLOATS) * 4;          // 32 KB: one fp32 m-tile of both operands
   constexpr int PLANE = 4 * 128 * 16;                            // 8 KB: one fp16 image of one operand's m-tile
   constexpr int PBUF_BYTES = 4 * PLANE;                          // A hi, A lo, G hi, G lo
   constexpr int A_PW = 2, G_PW = 2, P = A_PW + G_PW;             // LDS-DMA instructions per wave and m-tile (2 rows each)
-  static_assert(RING * SLOT_BYTES + 2 * PBUF_BYTES == TN_LDS_BYTES, "LDS size");
+  __shared__ __attribute__((aligned(16))) char lds[RING * SLOT_BYTES + 2 * PBUF_BYTES];   // the ONLY LDS object (160 KB)
   const int Kc = K1 + K2;
-  int bx = lin % gx, split = lin / gx;                           // a split's tiles on one XCD (see k_gemm_tn_dma)
+  int bx = blockIdx.x, split = blockIdx.y;                       // a split's tiles on one XCD (see k_gemm_tn_dma)
   {
-    const int full = (gy >> 3) << 3;
+    const int gx = (int)gridDim.x, full = ((int)gridDim.y >> 3) << 3;
+    const int lin = blockIdx.y * gx + blockIdx.x;
     if (lin < gx * full) {
       const int q = lin >> 3;
       bx = q % gx;
       split = (q / gx) * 8 + (lin & 7);
     }
   }
-  const int kc_tile = bx / n_tiles, kc_tiles = gx / n_tiles;
+  const int kc_tile = bx / n_tiles, kc_tiles = (int)gridDim.x / n_tiles;
   const int kc0 = kc_tile * TKC, n0 = (bx % n_tiles) * 128;
   const int mbeg = split * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
@@ -793,37 +755,6 @@ __device__ inline void tn_block(const tn_args& a, char* lds, const int lin, cons
   RGCN_STAMP(3);
 }
 
-template <bool LO>
-__global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const tn_args a) {
-  __shared__ __attribute__((aligned(16))) char lds[TN_LDS_BYTES];   // the ONLY LDS object (160 KB)
-  tn_block<LO>(a, lds, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.x, (int)gridDim.y);
-}
-
-// ---------------------------------------------------------------------------------------
-// One layer's backward GEMMs in ONE launch (round 4).  The parameter-gradient slab GEMM (TN) and the NT transform
-// that follows it - the input-gradient GEMM of the same layer, or the transform-first half of it - read the same
-// cotangent and do not depend on each other, yet as two launches each pays its own boundary, dispatch ramp, cold
-// first touch and drain behind its slowest workgroup (8 - 12 us of a 17 - 32 us launch: profiles/r03_stamps.txt).
-// Here the grid is the TN workgroups (the longer ones: first) followed by the NT workgroups, all 512 threads and one
-// per CU (the TN body owns all 160 KB of LDS; the NT body takes its 128-row form, 8 waves, ring of four): a CU
-// that finishes a TN workgroup starts an NT one at once.  Each workgroup runs the body of its stand-alone kernel
-// unchanged - the same bits.  Two streams were measured SLOWER than back to back (rounds 3 and 4): this is one
-// queue, no graph branches.
-// ---------------------------------------------------------------------------------------
-template <int TN_COLS, int EPI, bool LO>
-__global__ __launch_bounds__(2 * kThreads) void k_bwd_pair(const tn_args t, const int tn_gx, const int tn_gy, const nt_args n,
-                                                           const int nt_gx) {
-  constexpr int LDS = TN_LDS_BYTES > nt_lds_bytes<4, 2, TN_COLS, LO>() ? TN_LDS_BYTES : nt_lds_bytes<4, 2, TN_COLS, LO>();
-  __shared__ __attribute__((aligned(16))) char lds[LDS];            // the ONLY LDS object
-  const int b = (int)blockIdx.x, tn_blocks = tn_gx * tn_gy;
-  if (b < tn_blocks) {
-    tn_block<LO>(t, lds, b, tn_gx, tn_gy);
-  } else {
-    const int q = b - tn_blocks;
-    nt_block<4, 2, TN_COLS, EPI, LO>(n, lds, q % nt_gx, q / nt_gx);
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -893,13 +824,12 @@ int pack_weights(const float* weight, const float* root, int64_t R, int64_t d_in
 size_t nt_workspace_bytes(int64_t R, int64_t d_in, int64_t d_out) {
   return packed_bytes(R, d_in, d_out) + 2 * kMaxSlots * sizeof(float);
 }
-size_t nt_workspace_bytes_for(int64_t R, int64_t d_in, int64_t d_out) { return nt_workspace_bytes(R, d_in, d_out); }
 
 int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __half* Bh, const __half* Bl,
                     const float* b_inv, const float* bias, const float* mask, int epi, float* C, int M, int N,
                     const uint32_t* tile_mask, int kseg, const float* a1_amax, float a1_mul, const float* a2_amax,
                     float* c_amax, float* scan_slots, bool half, hipStream_t stream, const hub_fin* hubs = nullptr,
-                    float out_scale = 1.f, nt_args* args_out = nullptr) {
+                    float out_scale = 1.f) {
   const hub_fin fin = hubs ? *hubs : hub_fin{};
   if (fin.ptr && fin.d != 64 && fin.d != 128 && fin.d != 256) return RGCN_ERR_UNSUPPORTED;
   if (fin.ptr && (!a1_amax || fin.d != kseg)) return RGCN_ERR_ARG;   // an unfinished A1 cannot be scanned for its maximum
@@ -919,12 +849,9 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
   if (!r1.slots) { r1 = r2; r2 = amax_ref{nullptr, 0}; a1_mul = 1.f; }   // the kernels read r1 unconditionally
   if (kseg <= 0 || kseg % BK != 0) tile_mask = nullptr;
   unsigned* amax_out = reinterpret_cast<unsigned*>(c_amax);
-  const nt_args na{A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, C, M, N, tile_mask, kseg, amax_out, fin, out_scale};
-  if (args_out) {                                // the caller launches (k_bwd_pair): hand back what the kernel would get
-    *args_out = na;
-    return RGCN_OK;
-  }
-#define RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, LO_) k_gemm_nt_split<WM_, WN_, TN_, EPI_, LO_><<<grid, 64 * WM_ * WN_, 0, stream>>>(na)
+#define RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, LO_)                                                                     \
+  k_gemm_nt_split<WM_, WN_, TN_, EPI_, LO_><<<grid, 64 * WM_ * WN_, 0, stream>>>(                                     \
+      A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, C, M, N, tile_mask, kseg, amax_out, fin, out_scale)
 #define RGCN_NT_SPLIT_W(WM_, WN_, TN_, EPI_)             \
   do {                                                   \
     if (half) RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, false); \
@@ -944,11 +871,6 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
     if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 1, EPI_RELU);
     else if (epi == EPI_MASK) RGCN_NT_SPLIT(2, 1, EPI_MASK);
     else RGCN_NT_SPLIT(2, 1, EPI_NONE);
-  } else if (!half && getenv("RGCN_NT_RING2")) {   // EXPERIMENT (round 4): ring of two, 48 KB, three workgroups per CU
-    dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 128));
-    if (epi == EPI_RELU) k_gemm_nt_split<2, 2, 2, EPI_RELU, true, 2><<<grid, 256, 0, stream>>>(na);
-    else if (epi == EPI_MASK) k_gemm_nt_split<2, 2, 2, EPI_MASK, true, 2><<<grid, 256, 0, stream>>>(na);
-    else k_gemm_nt_split<2, 2, 2, EPI_NONE, true, 2><<<grid, 256, 0, stream>>>(na);
   } else {                       // (a 128-row tile, WM = 4, was measured no faster at C2: 15.8 against 15.2 us of main loop)
     dim3 grid((unsigned)ceil_div64(M, 64), (unsigned)ceil_div64(N, 128));
     if (epi == EPI_RELU) RGCN_NT_SPLIT(2, 2, EPI_RELU);
@@ -984,11 +906,6 @@ bool bad_dims(int64_t n, int64_t r, int64_t di, int64_t dout) {
 }
 
 struct TnPlan { int kc_tiles, n_tiles, splits, rows_per_split; };
-struct tn_pair { tn_args args; int gx, gy; };      // a parameter-gradient job that the caller launches (k_bwd_pair)
-int params_begin(const float* agg, const float* x, const float* g, const uint32_t* tile_mask, int64_t N, int64_t R,
-                 int64_t d_in, int64_t d_out, const float* agg_amax, float agg_amax_mul, const float* x_amax,
-                 const float* g_amax, int half, float* grad_weight, float* grad_root, float* grad_bias, void* workspace,
-                 size_t workspace_bytes, void* stream_, rgcn_slab_job* job, tn_pair* pair_out);
 
 // one workgroup per CU (the 128 KB ring leaves no room for a second): as many row splits as that gives
 TnPlan tn_plan(int64_t M, int64_t Kc, int64_t N) {
@@ -1211,18 +1128,6 @@ int rgcn_transform_bwd_params_split_begin(const float* agg, const float* x, cons
                                           float* grad_root,
                                           float* grad_bias, void* workspace, size_t workspace_bytes, void* stream_,
                                           rgcn_slab_job* job) {
-  return params_begin(agg, x, g, tile_mask, N, R, d_in, d_out, agg_amax, agg_amax_mul, x_amax, g_amax, half, grad_weight,
-                      grad_root, grad_bias, workspace, workspace_bytes, stream_, job, nullptr);
-}
-
-}  // extern "C"
-
-namespace {
-
-int params_begin(const float* agg, const float* x, const float* g, const uint32_t* tile_mask, int64_t N, int64_t R,
-                 int64_t d_in, int64_t d_out, const float* agg_amax, float agg_amax_mul, const float* x_amax,
-                 const float* g_amax, int half, float* grad_weight, float* grad_root, float* grad_bias, void* workspace,
-                 size_t workspace_bytes, void* stream_, rgcn_slab_job* job, tn_pair* pair_out) {
   if (!job) return RGCN_ERR_ARG;
   *job = rgcn_slab_job{};
   if (bad_dims(N, R, d_in, d_out) || !grad_weight) return RGCN_ERR_ARG;
@@ -1257,16 +1162,13 @@ int params_begin(const float* agg, const float* x, const float* g, const uint32_
   dim3 grid((unsigned)(p.kc_tiles * p.n_tiles), (unsigned)p.splits);
   const uint32_t* tmask = (d_in % 64 == 0) ? tile_mask : nullptr;
   float* bp = grad_bias ? bias_part : nullptr;
-  const tn_args ta{agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles, p.rows_per_split, r1, a1_mul, r2, rg, slab, bp, tmask, (int)d_in};
-  if (pair_out) {                                // the caller launches this job together with an NT transform (k_bwd_pair)
-    pair_out->args = ta;
-    pair_out->gx = (int)grid.x;
-    pair_out->gy = (int)grid.y;
-  } else {
-    if (half) k_gemm_tn_coop<false><<<grid, 2 * kThreads, 0, stream>>>(ta);
-    else k_gemm_tn_coop<true><<<grid, 2 * kThreads, 0, stream>>>(ta);
-    RGCN_HIP_TRY(hipGetLastError());
-  }
+#define RGCN_TN_LAUNCH(KERNEL, LO_)                                                                              \
+  KERNEL<LO_><<<grid, 2 * kThreads, 0, stream>>>(agg, K1, x, K2, g, (int)N, (int)d_out, p.n_tiles, p.rows_per_split, \
+                                                 r1, a1_mul, r2, rg, slab, bp, tmask, (int)d_in)
+  if (half) RGCN_TN_LAUNCH(k_gemm_tn_coop, false);
+  else RGCN_TN_LAUNCH(k_gemm_tn_coop, true);
+#undef RGCN_TN_LAUNCH
+  RGCN_HIP_TRY(hipGetLastError());
   job->slab = slab;
   job->bias_part = bias_part;
   job->splits = p.splits;
@@ -1276,69 +1178,6 @@ int params_begin(const float* agg, const float* x, const float* g, const uint32_
   job->grad_weight = grad_weight;
   job->grad_root = grad_root;
   job->grad_bias = grad_bias;
-  return RGCN_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-int rgcn_layer_bwd_pair_split_supported(int64_t R, int64_t d_in, int64_t d_out, int transform_first) {
-  if (R <= 0 || d_in <= 0 || d_out <= 0 || (d_in % 64) || (d_out % 32)) return 0;
-  const int64_t cols = transform_first ? (R + 1) * d_in : d_in;                  // columns of the NT half's output
-  return cols % 128 == 0 ? 1 : 0;                                                // the 128-column, 128-row NT tile
-}
-
-int rgcn_layer_bwd_pair_split(const float* agg, const float* x, const float* g, const float* gagg, const float* weight,
-                              const float* root, const void* packed, const float* relu_mask,
-                              const uint32_t* tile_mask, const uint32_t* tile_mask_t, int64_t N, int64_t R,
-                              int64_t d_in, int64_t d_out, const float* x_amax, float agg_amax_mul, const float* g_amax,
-                              float gagg_amax_mul, int half, float* grad_weight, float* grad_root, float* grad_bias,
-                              float* out, float* out_amax, void* params_workspace, size_t params_workspace_bytes,
-                              void* nt_workspace, size_t nt_workspace_bytes, void* stream_, rgcn_slab_job* job,
-                              const rgcn_graph* hub_graph, int hub_transposed, float* hub_partial, float out_scale) {
-  const int transform_first = gagg == nullptr;
-  if (bad_dims(N, R, d_in, d_out) || !out || !packed || !x_amax || !g_amax || !(out_scale > 0.f)) return RGCN_ERR_ARG;
-  if (!rgcn_layer_bwd_pair_split_supported(R, d_in, d_out, transform_first)) return RGCN_ERR_UNSUPPORTED;
-  if (N == 0) return RGCN_ERR_UNSUPPORTED;                                       // (callers take the separate launches)
-  if (transform_first && (relu_mask || hub_graph)) return RGCN_ERR_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
-  tn_pair tp{};
-  int rc = params_begin(agg, x, g, tile_mask, N, R, d_in, d_out, x_amax, agg_amax_mul, x_amax, g_amax, half, grad_weight,
-                        grad_root, grad_bias, params_workspace, params_workspace_bytes, stream_, job, &tp);
-  if (rc != RGCN_OK) return rc;
-  const PackedWeights v = packed_view(const_cast<void*>(packed), R, d_in, d_out);
-  nt_args na{};
-  int M = (int)N, cols;
-  if (transform_first) {                                                          // T = g * [W_r^T | root^T]
-    cols = (int)((R + (root ? 1 : 0)) * d_in);
-    if (!nt_workspace || nt_workspace_bytes < 2 * kMaxSlots * sizeof(float)) return RGCN_ERR_WORKSPACE;
-    rc = launch_nt_split(g, (int)d_out, nullptr, 0, v.Bh_n, v.Bl_n, v.inv_scale, nullptr, nullptr, EPI_NONE, out, M, cols,
-                         nullptr, 0, g_amax, 1.f, nullptr, out_amax, (float*)nt_workspace, half != 0, stream, nullptr, 1.f, &na);
-  } else {                                                                        // grad_x = [gagg | g] * [W_r^T ; root^T]
-    cols = (int)d_in;
-    if (!nt_workspace || nt_workspace_bytes < nt_workspace_bytes_for(R, d_in, d_out)) return RGCN_ERR_WORKSPACE;
-    float* scan = (float*)((char*)nt_workspace + packed_bytes(R, d_in, d_out));
-    hub_fin fin;
-    const int hrc = make_hub_fin(hub_graph, hub_transposed, hub_partial, N, R, d_out, &fin);
-    if (hrc < 0) return hrc;
-    rc = launch_nt_split(gagg, (int)(R * d_out), g, root ? (int)d_out : 0, v.Bh_b, v.Bl_b, v.inv_scale, nullptr, relu_mask,
-                         relu_mask ? EPI_MASK : EPI_NONE, out, M, cols, tile_mask_t, (int)d_out, g_amax, gagg_amax_mul, g_amax,
-                         out_amax, scan, half != 0, stream, hrc ? &fin : nullptr, out_scale, &na);
-  }
-  if (rc != RGCN_OK) return rc;
-  const int nt_gx = (int)ceil_div64(M, 128), nt_gy = (int)ceil_div64(cols, 128);
-  const unsigned blocks = (unsigned)(tp.gx * tp.gy + nt_gx * nt_gy);
-#define RGCN_PAIR(EPI_, LO_) k_bwd_pair<2, EPI_, LO_><<<blocks, 2 * kThreads, 0, stream>>>(tp.args, tp.gx, tp.gy, na, nt_gx)
-  if (relu_mask && !transform_first) {
-    if (half) RGCN_PAIR(EPI_MASK, false);
-    else RGCN_PAIR(EPI_MASK, true);
-  } else {
-    if (half) RGCN_PAIR(EPI_NONE, false);
-    else RGCN_PAIR(EPI_NONE, true);
-  }
-#undef RGCN_PAIR
-  RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
 

@@ -1,7 +1,7 @@
 // Round 4 probe: one layer's two backward GEMMs - the parameter-gradient slab GEMM (TN) and the NT transform beside it
 // (input gradient, or its transform-first half) - as ONE launch (k_bwd_pair) against the two launches, C2's shapes,
 // synthetic data.  Checks that outputs and slabs are the same bits and times both (events, 20 repetitions).
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/pair_probe.hip -o tools/pair_probe && tools/pair_probe
+// (builds against the kernels of the commit "Pair-launch and ring-of-2 experiments": k_bwd_pair / rgcn_layer_bwd_pair_split; results: profiles/r04_planes_probe.txt)
 #include "../primekg_rgcn_linkprediction_amd/csrc/rgcn_transform_split.hip"
 
 #include <cstdio>
