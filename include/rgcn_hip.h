@@ -291,7 +291,10 @@ int rgcn_weights_split_pack(const float* weight, const float* root, int64_t num_
 int rgcn_weights_split_pack_multi(int count, const float* const* weights, const float* const* roots,
                                   const int64_t* num_relations, const int64_t* d_in, const int64_t* d_out,
                                   const float* const* w_amax, const float* const* r_amax, void* const* packed,
-                                  const size_t* packed_bytes, void* stream);
+                                  const size_t* packed_bytes, float* zero_buffers, int zero_count, void* stream);
+/* zero_buffers / zero_count (round 4): `zero_count` contiguous amax buffers whose heads this launch clears on the
+ * side, as rgcn_absmax does - so that it can BE the first launch of a pass whose operand maxima all come from the
+ * optimizer (rgcn_adam_clip_step's amax_out): no scan of the input table, none of the weights. */
 /* The first launch of a forward pass, as ONE launch: max |x| of the pass's input table into x_amax (zero_buffers /
  * zero_count as in rgcn_absmax) AND the split weights of up to 4 layers (as rgcn_weights_split_pack_multi without
  * given maxima: the kernel scans the weights itself).  Array arguments: HOST arrays of `count` entries. */
@@ -478,13 +481,18 @@ int rgcn_sample_batch(const int64_t* edge_index, const int64_t* edge_type, int64
  * params / grads / exp_avg / exp_avg_sq / steps: HOST arrays of `num_tensors` DEVICE pointers (the
  * pointers travel in the launch arguments, so a captured HIP graph keeps working on them); steps[t]:
  * DEVICE float[1], torch's per-tensor step count, bumped by one per call on the device.
- * total_norm: DEVICE float[1] or NULL.  workspace: rgcn_adam_workspace_bytes(num_tensors, numels). */
+ * total_norm: DEVICE float[1] or NULL.  workspace: rgcn_adam_workspace_bytes(num_tensors, numels).
+ * amax_out (round 4; HOST array of `num_tensors` DEVICE amax buffers, entries or the array itself may be NULL): the
+ * update leaves max |params[t]| AFTER the step in amax_out[t] (the heads it publishes into are cleared by the first
+ * launch; every other entry must be zero and stays so) - the optimizer is the only writer of the embedding table and
+ * of the layers' weights, so the next step's split-precision transforms take their operand scales from here instead
+ * of scanning 8 MB + the weights at the head of their latency chain (rgcn_weights_split_pack_multi with maxima). */
 size_t rgcn_adam_workspace_bytes(int num_tensors, const int64_t* numels);
 int rgcn_adam_clip_step(int num_tensors, float* const* params, const float* const* grads,
                         float* const* exp_avg, float* const* exp_avg_sq, float* const* steps,
                         const int64_t* numels, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int adamw, float max_norm, float* total_norm,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        float* const* amax_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Tail ranking for evaluation (LinkPredictor.score_all_tails rgcn.py:215-243 +
  * compute_ranking_metrics evaluate.py:260-276, without materialising the [B, N] score matrix

@@ -95,7 +95,7 @@ PROTOTYPES = {
     "rgcn_absmax": (c_int, [_P, _I64, _P, _P, c_int, _P]),
     "rgcn_absmax_multi": (c_int, [c_int, _P, _P, _P, _P, c_int, _P]),
     "rgcn_absmax_pack": (c_int, [_P, _I64, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "rgcn_weights_split_pack_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "rgcn_weights_split_pack_multi": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     "rgcn_weights_split_bytes": (c_size_t, [_I64, _I64, _I64]),
     "rgcn_weights_split_pack": (c_int, [_P, _P, _I64, _I64, _I64, _P, c_size_t, _P]),
     "rgcn_transform_split_workspace_bytes": (c_size_t, [_I64, _I64, _I64]),
@@ -129,7 +129,7 @@ PROTOTYPES = {
     "distmult_bwd": (c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, c_size_t, c_int, _P]),
     "rgcn_adam_workspace_bytes": (c_size_t, [c_int, _P]),
     "rgcn_adam_clip_step": (c_int, [c_int, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float, c_float, c_int,
-                                    c_float, _P, _P, c_size_t, _P]),
+                                    c_float, _P, _P, _P, c_size_t, _P]),
     "rgcn_sample_batch": (c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "distmult_bce_fwd": (c_int, [_P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _I64, _I64, _P, _P, _P]),
     "distmult_bce_bwd": (c_int, [_P, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I64, _I64, _P, _P, _P, _P,

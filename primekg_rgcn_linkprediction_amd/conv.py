@@ -69,24 +69,33 @@ class _Scales:
     slot - and, in a forward pass, splits the layers' weights.  In fp32 mode nothing is allocated and every
     slot is None."""
 
-    def __init__(self, t: Tensor, slots: int = 2, layers=()):
+    def __init__(self, t: Tensor, slots: int = 2, layers=(), given=None):
         """``layers``: ``[(weight, root | None), ...]`` of the pass (forward passes): their split images are made
-        by the SAME first launch - ``self.packed[i]`` (None for widths the split kernels do not tile)."""
-        self._buf, self._next, self.first = None, 1, None
+        by the SAME first launch - ``self.packed[i]`` (None for widths the split kernels do not tile).
+        ``given`` = ``(amax of t, [(amax of weight, amax of root | None), ...])``: every maximum is already known
+        (``ops.amax_hint``: the optimizer left them) - the first launch then scans nothing, it splits the weights
+        under the given maxima and clears the pass's own slots."""
+        self._own, self._next, self.first = None, 0, None
         self.packed = [None] * len(layers)
         if ops.GEMM_PRECISION == "split":
-            self._buf = ops._empty(slots, ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
-            self.first = self._buf[0]
+            if given is not None:
+                self.first = given[0]
+                if slots > 1:
+                    self._own = ops._empty(slots - 1, ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
+                self.packed = ops.split_weights_many(list(layers), amax=list(given[1]), clear=self._own)
+                return
+            buf = ops._empty(slots, ops.AMAX_FLOATS, dtype=torch.float32, device=t.device)
+            self.first, self._own = buf[0], buf[1:slots]
             if layers:
-                self.packed = ops.absmax_and_split(t, self.first, self._buf[1:slots], list(layers))
+                self.packed = ops.absmax_and_split(t, self.first, self._own, list(layers))
             else:
-                ops.absmax(t, self.first, self._buf[1:slots])
+                ops.absmax(t, self.first, self._own)
 
     def slot(self) -> Optional[Tensor]:
-        if self._buf is None:
+        if self._own is None:
             return None
         self._next += 1
-        return self._buf[self._next - 1]
+        return self._own[self._next - 1]
 
 
 import os as _os
@@ -197,13 +206,13 @@ def _packs(bufs, layers):
 
 
 def _conv_forward(x, weight, root, bias, *, graph, relu, gather_dtype, half):
-    """one layer's training forward as a pass -> (out, agg, amax buffer of x | None, split images | None)"""
+    """one layer's training forward as a pass -> (out, agg, amax of x | None, split images | None)"""
     scales = _Scales(x, slots=1, layers=[(weight, root)])            # ONE launch: max |x| and the split weights
     x_amax = scales.first            # also the bound of agg: a mean of rows cannot exceed the table's maximum
     packed = scales.packed[0]                                         # once, for forward and backward
     agg, out = _layer_train_forward(graph, x, gather_dtype, weight, root, bias, relu, half, x_amax, None,
                                     packed)                           # rows A3 + A4, A6 (+ fused ReLU)
-    return out, agg, scales._buf, (packed.buf if packed is not None else None)
+    return out, agg, x_amax, (packed.buf if packed is not None else None)
 
 
 def _conv_backward(x, agg, weight, root, x_amax, pkbuf, g, *, graph, has_root, has_bias, need_x, need_p, prec):
@@ -249,13 +258,9 @@ class _RGCNConvFunction(torch.autograd.Function):
         ctx.bwd_precision = "half" if (half and half_backward and ops.GEMM_PRECISION == "split") else None
         key = (tuple(x.shape), tuple(weight.shape), root is not None, bias is not None, gather_dtype, bool(relu),
                _policy_key())
-        out, agg, amax, pkbuf = _R_CONV_FORWARD.run(graph, key, (x, weight, root_c, bias_c),
-                                                    dict(graph=graph, relu=relu, gather_dtype=gather_dtype, half=half),
-                                                    want={0})
-        x_amax = None
-        if amax is not None:                          # row 0 of the amax allocation, as a tensor or as an arena offset
-            x_amax = (ops.Lazy(amax.arena, amax.offset, (ops.AMAX_FLOATS,), torch.float32) if isinstance(amax, ops.Lazy)
-                      else amax[0])
+        out, agg, x_amax, pkbuf = _R_CONV_FORWARD.run(graph, key, (x, weight, root_c, bias_c),
+                                                      dict(graph=graph, relu=relu, gather_dtype=gather_dtype, half=half),
+                                                      want={0})
         ctx.graph, ctx.relu, ctx.key = graph, relu, key
         ctx.has_root, ctx.has_bias = root is not None, bias is not None
         ctx.save_for_backward(x, weight, root_c)             # the node's inputs (autograd checks their versions)
@@ -279,14 +284,16 @@ class _RGCNConvFunction(torch.autograd.Function):
         return gx, gw, groot, gbias, None, None, None, None
 
 
-def _enc2_layer1(x, w1, root1, b1, w2, root2, *, graph, gather_dtype, half):
+def _enc2_layer1(x, w1, root1, b1, w2, root2, xa=None, w1a=None, r1a=None, w2a=None, r2a=None, *, graph, gather_dtype, half):
     """first launch of the pass (max |x|, cleared amax slots, both layers' split weights) + conv1 with its ReLU
-    -> (h, agg1, amax buffers [x | h], split images of conv1, of conv2)"""
-    scales = _Scales(x, layers=[(w1, root1), (w2, root2)])
+    -> (h, agg1, amax of x, amax slot of h, split images of conv1, of conv2).  xa ... r2a: the maxima of x, w1, root1,
+    w2, root2 where the optimizer left them (ops.amax_hint): the first launch then scans nothing."""
+    given = (xa, [(w1a, r1a), (w2a, r2a)]) if xa is not None else None
+    scales = _Scales(x, layers=[(w1, root1), (w2, root2)], given=given)
     x_amax, h_amax = scales.first, scales.slot()
     pk1, pk2 = scales.packed                                      # once, for forward and backward
     agg1, h = _layer_train_forward(graph, x, gather_dtype, w1, root1, b1, True, half, x_amax, h_amax, pk1)
-    return h, agg1, scales._buf, (pk1.buf if pk1 is not None else None), (pk2.buf if pk2 is not None else None)
+    return h, agg1, x_amax, h_amax, (pk1.buf if pk1 is not None else None), (pk2.buf if pk2 is not None else None)
 
 
 def _enc2_layer2(h, w2, root2, b2, h_amax, pk2buf, *, graph, gather_dtype, half):
@@ -295,12 +302,13 @@ def _enc2_layer2(h, w2, root2, b2, h_amax, pk2buf, *, graph, gather_dtype, half)
     return out, agg2
 
 
-def _enc2_forward(x, w1, root1, b1, w2, root2, b2, *, graph, gather_dtype, half):
-    """both layers (no dropout between them) as one pass -> (out, h, agg1, agg2, amax buffers, images 1, images 2)"""
-    h, agg1, amax, pk1buf, pk2buf = _enc2_layer1(x, w1, root1, b1, w2, root2, graph=graph, gather_dtype=gather_dtype, half=half)
-    out, agg2 = _enc2_layer2(h, w2, root2, b2, amax[1] if amax is not None else None, pk2buf, graph=graph,
-                             gather_dtype=gather_dtype, half=half)
-    return out, h, agg1, agg2, amax, pk1buf, pk2buf
+def _enc2_forward(x, w1, root1, b1, w2, root2, b2, xa=None, w1a=None, r1a=None, w2a=None, r2a=None, *, graph, gather_dtype,
+                  half):
+    """both layers (no dropout between them) as one pass -> (out, h, agg1, agg2, amax of x, of h, images 1, images 2)"""
+    h, agg1, x_amax, h_amax, pk1buf, pk2buf = _enc2_layer1(x, w1, root1, b1, w2, root2, xa, w1a, r1a, w2a, r2a, graph=graph,
+                                                           gather_dtype=gather_dtype, half=half)
+    out, agg2 = _enc2_layer2(h, w2, root2, b2, h_amax, pk2buf, graph=graph, gather_dtype=gather_dtype, half=half)
+    return out, h, agg1, agg2, x_amax, h_amax, pk1buf, pk2buf
 
 
 def _enc2_backward(x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax, pk1buf, pk2buf, g, *, graph, flags, p,
@@ -368,7 +376,7 @@ class _Encoder2Function(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, root1, b1, w2, root2, b2, graph, gather_dtype=None, p: float = 0.0,
-                half_backward: bool = False):
+                half_backward: bool = False, hints=None):
         x, w1, w2 = x.contiguous(), w1.contiguous(), w2.contiguous()
         root1 = root1.contiguous() if root1 is not None else None
         root2 = root2.contiguous() if root2 is not None else None
@@ -379,28 +387,22 @@ class _Encoder2Function(torch.autograd.Function):
         # per-tensor power-of-two scales = loss scaling per tensor, fp32 accumulate); the gradient gathers stay fp32
         ctx.bwd_precision = "half" if (half and half_backward and ops.GEMM_PRECISION == "split") else None
         static = dict(graph=graph, gather_dtype=gather_dtype, half=half)
+        hinted = hints is not None and ops.GEMM_PRECISION == "split"
+        hint_list = list(hints) if hinted else []     # maxima of x, w1, root1, w2, root2 left by the optimizer
         key = (tuple(x.shape), tuple(w1.shape), tuple(w2.shape), root1 is not None, b1 is not None, root2 is not None,
-               b2 is not None, gather_dtype, _policy_key())
+               b2 is not None, gather_dtype, hinted, _policy_key())
         # A dense tensor's maximum is left behind by the launch that produces it (the first launch of the pass
-        # for x, the epilogue of conv1's transform for h); an aggregate is scaled by the bound its table's
-        # maximum gives (a mean of rows cannot exceed it), so the gathers publish nothing.
+        # for x - or the optimizer step that wrote x -, the epilogue of conv1's transform for h); an aggregate is scaled
+        # by the bound its table's maximum gives (a mean of rows cannot exceed it), so the gathers publish nothing.
         if p > 0:
-            h, agg1, amax, pk1buf, pk2buf = _R_LAYER1.run(graph, key, (x, w1, root1, b1, w2, root2), static, want={0, 2})
+            h, agg1, x_amax, h_amax, pk1buf, pk2buf = _R_LAYER1.run(graph, key, [x, w1, root1, b1, w2, root2] + hint_list,
+                                                                    static, want={0, 3})
             h = torch.native_dropout(h, p, True)[0]
-            h_amax = amax[1] * (1.0 / (1.0 - p)) if amax is not None else None      # kept units are scaled up
-            x_amax = amax[0] if amax is not None else None
+            h_amax = ops.materialize(h_amax) * (1.0 / (1.0 - p)) if h_amax is not None else None   # kept units are scaled up
             out, agg2 = _R_LAYER2.run(graph, key, (h, w2, root2, b2, h_amax, pk2buf), static, want={0})
         else:
-            out, h, agg1, agg2, amax, pk1buf, pk2buf = _R_FORWARD.run(graph, key, (x, w1, root1, b1, w2, root2, b2),
-                                                                     static, want={0})
-            x_amax = h_amax = None
-            if amax is not None:                      # rows 0 / 1 of the amax allocation, as tensors or as arena offsets
-                if isinstance(amax, ops.Lazy):
-                    row = ops.AMAX_FLOATS * 4
-                    x_amax = ops.Lazy(amax.arena, amax.offset, (ops.AMAX_FLOATS,), torch.float32)
-                    h_amax = ops.Lazy(amax.arena, amax.offset + row, (ops.AMAX_FLOATS,), torch.float32)
-                else:
-                    x_amax, h_amax = amax[0], amax[1]
+            out, h, agg1, agg2, x_amax, h_amax, pk1buf, pk2buf = _R_FORWARD.run(
+                graph, key, [x, w1, root1, b1, w2, root2, b2] + hint_list, static, want={0})
         ctx.graph, ctx.p, ctx.key = graph, p, key
         ctx.flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
         ctx.save_for_backward(x, w1, root1, w2, root2)           # the node's inputs (autograd checks their versions)
@@ -418,7 +420,7 @@ class _Encoder2Function(torch.autograd.Function):
                                 (x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax, pk1buf, pk2buf, g), static,
                                 want={0, 1, 2, 3, 4, 5, 6})
         gx, gw1, groot1, gb1, gw2, groot2, gb2 = grads
-        return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None, None, None
+        return gx, gw1, groot1, gb1, gw2, groot2, gb2, None, None, None, None, None
 
 
 # No-grad encoder (``DrugDiseaseModel.get_embeddings / predict / predict_all_tails``, ``Trainer.validate``,
@@ -526,6 +528,17 @@ def rgcn_conv(x: Tensor, edge_index: Tensor, edge_type: Tensor, weight: Tensor,
     return _RGCNConvFunction.apply(x, weight, root, bias, graph, activation == "relu", gather_dtype, half_backward)
 
 
+def _encoder_hints(x: Tensor, conv1: "RGCNConv", conv2: "RGCNConv"):
+    """the operand maxima the optimizer left (``ops.amax_hint``) for x, conv1.weight / root, conv2.weight / root - all
+    of them or None (plain weights with a root, fp32 table, split precision)"""
+    if ops.GEMM_PRECISION != "split" or conv1.num_bases is not None or conv2.num_bases is not None:
+        return None
+    if conv1.root is None or conv2.root is None or conv1.gather_dtype not in (None, torch.float32):
+        return None
+    hints = tuple(ops.amax_hint(t) for t in (x, conv1.weight, conv1.root, conv2.weight, conv2.root))
+    return hints if all(h is not None for h in hints) else None
+
+
 def rgcn_encoder2(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: "RGCNConv",
                   conv2: "RGCNConv", dropout_p: float = 0.0) -> Tensor:
     """``conv2(dropout(relu(conv1(x)), dropout_p))`` through the fused two-layer autograd node
@@ -540,7 +553,8 @@ def rgcn_encoder2(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: "RGCN
                              conv2.root, conv2.bias, conv1.gather_dtype)       # nothing to differentiate, no dropout
     return _Encoder2Function.apply(x, conv1.effective_weight(), conv1.root, conv1.bias,
                                    conv2.effective_weight(), conv2.root, conv2.bias, graph,
-                                   conv1.gather_dtype, float(dropout_p), conv1.half_backward)
+                                   conv1.gather_dtype, float(dropout_p), conv1.half_backward,
+                                   _encoder_hints(x, conv1, conv2))
 
 
 def _accumulate(param: Optional[Tensor], grad: Optional[Tensor]) -> None:
@@ -576,17 +590,12 @@ def rgcn_encoder2_step(x: Tensor, edge_index: Tensor, edge_type: Tensor, conv1: 
     prec = "half" if (half and conv1.half_backward and ops.GEMM_PRECISION == "split") else None
     key = (tuple(x.shape), tuple(w1.shape), tuple(w2.shape), root1 is not None, b1 is not None, root2 is not None,
            b2 is not None, gather_dtype, _policy_key())
-    out, h, agg1, agg2, amax, pk1buf, pk2buf = _R_FORWARD.run(graph, key, (x, w1, root1, b1, w2, root2, b2),
-                                                             dict(graph=graph, gather_dtype=gather_dtype, half=half),
-                                                             want={0})
-    x_amax = h_amax = None
-    if amax is not None:
-        if isinstance(amax, ops.Lazy):
-            row = ops.AMAX_FLOATS * 4
-            x_amax = ops.Lazy(amax.arena, amax.offset, (ops.AMAX_FLOATS,), torch.float32)
-            h_amax = ops.Lazy(amax.arena, amax.offset + row, (ops.AMAX_FLOATS,), torch.float32)
-        else:
-            x_amax, h_amax = amax[0], amax[1]
+    hints = None if (basis1 or basis2) else _encoder_hints(x, conv1, conv2)
+    hinted = hints is not None
+    key = key[:-1] + (hinted, key[-1])
+    out, h, agg1, agg2, x_amax, h_amax, pk1buf, pk2buf = _R_FORWARD.run(
+        graph, key, [x, w1, root1, b1, w2, root2, b2] + (list(hints) if hinted else []),
+        dict(graph=graph, gather_dtype=gather_dtype, half=half), want={0})
     need_x = bool(need_input_grad)
     flags = (root1 is not None, b1 is not None, root2 is not None, b2 is not None)
     static = dict(graph=graph, flags=flags, p=0.0, prec=prec, need_x=need_x)

@@ -25,6 +25,7 @@ struct AdamList {
   float* m[kMaxTensors];
   float* v[kMaxTensors];
   float* step[kMaxTensors];
+  float* amax[kMaxTensors];                      // amax buffer that receives max |p| after the update, or NULL
   int64_t n[kMaxTensors];
   int first_block[kMaxTensors + 1];              // slices of tensor t: [first_block[t], first_block[t+1])
   int count;
@@ -59,6 +60,9 @@ __global__ __launch_bounds__(kThreads) void k_sumsq(const AdamList L, float* __r
   if (blockIdx.x == 0 && (int)threadIdx.x < L.count) L.step[threadIdx.x][0] += 1.f;   // `step += 1` per tensor
   const int t = tensor_of_block(L, blockIdx.x);
   const float* g = L.g[t];
+  // the head of the tensor's amax buffer that this slice's update (next launch) will publish into: cleared here
+  if (L.amax[t] && threadIdx.x == 0)
+    L.amax[t][((blockIdx.x - L.first_block[t]) & (RGCN_AMAX_HEADS - 1)) * RGCN_AMAX_HEAD_STRIDE] = 0.f;
   const int64_t lo = (int64_t)(blockIdx.x - L.first_block[t]) * kSlice;
   const int64_t hi = lo + kSlice < L.n[t] ? lo + kSlice : L.n[t];
   float s = 0.f;
@@ -108,6 +112,7 @@ __global__ __launch_bounds__(kThreads) void k_adam_update(const AdamList L, cons
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
     pp -= step_size * (mm / denom);
   };
+  float pmax = 0.f;
   if (hi - lo == kSlice && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) {
     // the same arithmetic per element, every load of the slice in flight before the first use
     float4* p4 = reinterpret_cast<float4*>(p + lo);
@@ -128,15 +133,25 @@ __global__ __launch_bounds__(kThreads) void k_adam_update(const AdamList L, cons
       update(pp[q].z, mm[q].z, vv[q].z, gg[q].z);
       update(pp[q].w, mm[q].w, vv[q].w, gg[q].w);
       p4[i] = pp[q]; m4[i] = mm[q]; v4[i] = vv[q];
+      pmax = fmaxf(pmax, fmaxf(fmaxf(fabsf(pp[q].x), fabsf(pp[q].y)), fmaxf(fabsf(pp[q].z), fabsf(pp[q].w))));
     }
-    return;
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+      float pp = p[i], mm = m[i], vv = v[i];
+      update(pp, mm, vv, g[i]);
+      p[i] = pp;
+      m[i] = mm;
+      v[i] = vv;
+      pmax = fmaxf(pmax, fabsf(pp));
+    }
   }
-  for (int64_t i = lo + threadIdx.x; i < hi; i += kThreads) {
-    float pp = p[i], mm = m[i], vv = v[i];
-    update(pp, mm, vv, g[i]);
-    p[i] = pp;
-    m[i] = mm;
-    v[i] = vv;
+  // max |p| of what this step wrote, for the NEXT step's split-precision transforms (the embedding table is their
+  // input, W and root their weights): the scan that would find it again is the head of that step's latency chain.
+  // Integer max on the bit pattern of a non-negative float: order-free, so the value is deterministic.
+  if (L.amax[t]) {
+    const unsigned m_wave = __ockl_wfred_max_u32(__float_as_uint(pmax));
+    if ((threadIdx.x & 63) == 0 && m_wave)
+      atomicMax(reinterpret_cast<unsigned*>(L.amax[t]) + ((blockIdx.x - L.first_block[t]) & (RGCN_AMAX_HEADS - 1)) * RGCN_AMAX_HEAD_STRIDE, m_wave);
   }
 }
 
@@ -154,7 +169,7 @@ size_t rgcn_adam_workspace_bytes(int num_tensors, const int64_t* numels) {
 int rgcn_adam_clip_step(int num_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, float* const* steps, const int64_t* numels, float lr, float beta1,
                         float beta2, float eps, float weight_decay, int adamw, float max_norm, float* total_norm,
-                        void* workspace, size_t workspace_bytes, void* stream_) {
+                        float* const* amax_out, void* workspace, size_t workspace_bytes, void* stream_) {
   if (num_tensors < 0 || num_tensors > kMaxTensors) return num_tensors < 0 ? RGCN_ERR_ARG : RGCN_ERR_UNSUPPORTED;
   if (num_tensors == 0) return RGCN_OK;
   if (!params || !grads || !exp_avg || !exp_avg_sq || !steps || !numels) return RGCN_ERR_ARG;
@@ -166,6 +181,7 @@ int rgcn_adam_clip_step(int num_tensors, float* const* params, const float* cons
     if (numels[t] < 0 || !steps[t] || (numels[t] > 0 && (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t])))
       return RGCN_ERR_ARG;
     L.p[t] = params[t]; L.g[t] = grads[t]; L.m[t] = exp_avg[t]; L.v[t] = exp_avg_sq[t]; L.step[t] = steps[t];
+    L.amax[t] = amax_out ? amax_out[t] : nullptr;
     L.n[t] = numels[t];
     L.first_block[t] = blocks;
     const int64_t nb = std::max<int64_t>(1, ceil_div64(numels[t], kSlice));

@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int kMaxArgs = 32, kMaxJobs = 8, kMaxArrayEntries = 8, kMaxArrays = 8;
+constexpr int kMaxArgs = 32, kMaxJobs = 8, kMaxArrayEntries = 8, kMaxArrays = 12;   // (rgcn_weights_split_pack_multi: nine host arrays)
 
 struct Resolved {
   uint64_t v[kMaxArgs];
@@ -93,11 +93,11 @@ int rgcn_sequence_run(const rgcn_seq_call* calls, int num_calls, const rgcn_seq_
         rc = rgcn_absmax_pack(CF(0), I(1), MF(2), MF(3), (int)I(4), (int)I(5), (const float* const*)P(6),
                               (const float* const*)P(7), (const int64_t*)P(8), (const int64_t*)P(9), (const int64_t*)P(10),
                               (void* const*)P(11), (const size_t*)P(12), P(13)); break;
-      case RGCN_FN_WEIGHTS_SPLIT_PACK_MULTI: NEED(11);
+      case RGCN_FN_WEIGHTS_SPLIT_PACK_MULTI: NEED(13);
         rc = rgcn_weights_split_pack_multi((int)I(0), (const float* const*)P(1), (const float* const*)P(2),
                                            (const int64_t*)P(3), (const int64_t*)P(4), (const int64_t*)P(5),
                                            (const float* const*)P(6), (const float* const*)P(7), (void* const*)P(8),
-                                           (const size_t*)P(9), P(10)); break;
+                                           (const size_t*)P(9), MF(10), (int)I(11), P(12)); break;
       case RGCN_FN_AGGREGATE: NEED(8);
         rc = rgcn_aggregate(G(0), (int)I(1), CF(2), I(3), MF(4), P(5), (size_t)I(6), P(7)); break;
       case RGCN_FN_AGGREGATE_AND_REDUCE: NEED(9);

@@ -120,8 +120,12 @@ __device__ inline void pack_body(const pack_job& J, float* red, int nblocks, int
   rgcn_pack_body<kPackThreads>(J, red, nblocks, bid);
 }
 
-__global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ) {
+__global__ __launch_bounds__(kPackThreads) void k_pack_split(const pack_jobs JJ, float* __restrict__ zero, int zero_count) {
   __shared__ float red[kPackThreads / 64];
+  // (on the side: the heads of `zero_count` amax buffers the coming pass publishes into, as rgcn_absmax clears them)
+  if (blockIdx.y == 0 && (int)threadIdx.x < zero_count)
+    for (int h = (int)blockIdx.x; h < RGCN_AMAX_HEADS; h += (int)gridDim.x)
+      zero[(size_t)threadIdx.x * RGCN_AMAX_FLOATS + h * RGCN_AMAX_HEAD_STRIDE] = 0.f;
   pack_body(JJ.j[blockIdx.y], red, (int)gridDim.x, (int)blockIdx.x);   // one layer per grid row
 }
 
@@ -814,7 +818,7 @@ int pack_weights(const float* weight, const float* root, int64_t R, int64_t d_in
   JJ.j[0] = make_pack_job(weight, root, R, d_in, d_out, packed, nullptr, nullptr);
   const int64_t total = (R + (root ? 1 : 0)) * d_in * d_out;
   dim3 grid((unsigned)std::min<int64_t>(64, ceil_div64(total, kPackThreads)), 1);
-  k_pack_split<<<grid, kPackThreads, 0, stream>>>(JJ);
+  k_pack_split<<<grid, kPackThreads, 0, stream>>>(JJ, nullptr, 0);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }
@@ -1017,9 +1021,10 @@ int rgcn_weights_split_pack(const float* weight, const float* root, int64_t R, i
 int rgcn_weights_split_pack_multi(int count, const float* const* weights, const float* const* roots,
                                   const int64_t* R, const int64_t* d_in, const int64_t* d_out,
                                   const float* const* w_amax, const float* const* r_amax, void* const* packed,
-                                  const size_t* packed_bytes_, void* stream_) {
+                                  const size_t* packed_bytes_, float* zero_buffers, int zero_count, void* stream_) {
   if (count < 1 || count > kPackJobs || !weights || !roots || !R || !d_in || !d_out || !packed || !packed_bytes_)
     return RGCN_ERR_ARG;
+  if (zero_count < 0 || zero_count > kPackThreads || (zero_count > 0 && !zero_buffers)) return RGCN_ERR_ARG;
   pack_jobs JJ{};
   int64_t most = 0;
   for (int l = 0; l < count; ++l) {
@@ -1031,7 +1036,7 @@ int rgcn_weights_split_pack_multi(int count, const float* const* weights, const 
     most = std::max<int64_t>(most, (R[l] + (roots[l] ? 1 : 0)) * d_in[l] * d_out[l]);
   }
   dim3 grid((unsigned)std::min<int64_t>(64, ceil_div64(most, kPackThreads)), (unsigned)count);
-  k_pack_split<<<grid, kPackThreads, 0, (hipStream_t)stream_>>>(JJ);
+  k_pack_split<<<grid, kPackThreads, 0, (hipStream_t)stream_>>>(JJ, zero_buffers, zero_count);
   RGCN_HIP_TRY(hipGetLastError());
   return RGCN_OK;
 }

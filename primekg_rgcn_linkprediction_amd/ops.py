@@ -134,6 +134,33 @@ def _check_amax(name: str, t: Optional[torch.Tensor], device) -> None:
         raise ValueError(f"{name} must be an amax buffer ({AMAX_FLOATS} floats) on {device}")
 
 
+# Operand maxima that somebody else already knows (round 4): the optimizer is the only writer of the embedding table and
+# of the layers' weights, and ``adam_clip_step(amax_out=)`` leaves max |param| of what it just wrote in an amax buffer.
+# ``set_amax_hint(param, buffer)`` says so; ``amax_hint(param)`` returns the buffer while the tensor has not been
+# modified through torch since (``_version``) - the encoder's first launch then only splits the weights under the
+# given maxima instead of scanning the 8 MB table and the weights at the head of the step's latency chain.
+_AMAX_HINTS = {}
+
+
+def set_amax_hint(t: torch.Tensor, buf: Optional[torch.Tensor]) -> None:
+    import weakref
+    if buf is None:
+        _AMAX_HINTS.pop(id(t), None)
+        return
+    _check_amax("buf", buf, t.device)
+    key = id(t)
+    _AMAX_HINTS[key] = (weakref.ref(t, lambda _, k=key: _AMAX_HINTS.pop(k, None)), buf, t._version)
+
+
+def amax_hint(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    h = _AMAX_HINTS.get(id(t))
+    if h is None or h[0]() is not t or h[2] != t._version or not t.is_contiguous() or t.dtype != torch.float32:
+        return None
+    return h[1]
+
+
 def absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None, clear: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``max |x|`` as an amax buffer (``rgcn_absmax``; ``amax_value`` reads it): the operand scale of the
     split-precision transforms for a tensor no kernel of this library produced (the embedding table,
@@ -203,10 +230,12 @@ def split_weights(weight: torch.Tensor, root: Optional[torch.Tensor]) -> Optiona
     return split_weights_many([(weight, root)])[0]
 
 
-def split_weights_many(layers, amax=None):
+def split_weights_many(layers, amax=None, clear: Optional[torch.Tensor] = None):
     """``[(weight, root | None), ...]`` (up to 4 layers) -> ``[SplitWeights | None, ...]`` in ONE launch
     (``rgcn_weights_split_pack_multi``).  ``amax``: per layer ``(weight_amax, root_amax)`` buffers when the
-    pass's first launch (``absmax_many``) already left the weights' maxima; otherwise the kernel scans them."""
+    pass's first launch (``absmax_many``) - or the optimizer (``adam_clip_step(amax_out=)``) - already left the
+    weights' maxima; otherwise the kernel scans them.  ``clear``: amax buffers whose heads the launch clears on the
+    side (it can then be the first launch of a pass)."""
     if not layers or len(layers) > 4:
         raise ValueError("1..4 layers")
     todo, out = [], [None] * len(layers)
@@ -221,7 +250,16 @@ def split_weights_many(layers, amax=None):
                 raise ValueError(f"root must be [{d_in}, {d_out}]")
         if GEMM_PRECISION != "fp32" and d_in % 32 == 0 and d_out % 32 == 0:
             todo.append(i)
+    count = 0
+    if clear is not None:
+        _need_gpu("clear", clear, torch.float32)
+        if clear.numel() % AMAX_FLOATS:
+            raise ValueError("clear must hold whole amax buffers")
+        count = clear.numel() // AMAX_FLOATS
     if not todo:
+        if count:
+            guard_torch_op("clearing amax buffers without a launch to carry it")
+            clear.zero_()
         return out
     lib = _L()
     dev = layers[todo[0]][0].device
@@ -243,7 +281,7 @@ def split_weights_many(layers, amax=None):
             n, cast(arr(*[_ptr(layers[i][0]) for i in todo])), cast(arr(*[_ptr(layers[i][1]) for i in todo])),
             cast(i64(*[layers[i][0].size(0) for i in todo])), cast(i64(*[layers[i][0].size(1) for i in todo])),
             cast(i64(*[layers[i][0].size(2) for i in todo])), wam, ram, cast(arr(*[_ptr(b) for b in bufs])),
-            cast((ctypes.c_size_t * n)(*sizes)), _stream())
+            cast((ctypes.c_size_t * n)(*sizes)), _ptr(clear) if count else None, count, _stream())
     _lib.check(rc, "rgcn_weights_split_pack_multi")
     for i, b in zip(todo, bufs):
         out[i] = SplitWeights(b, layers[i][0], layers[i][1])
@@ -1334,12 +1372,14 @@ def segment_sum(rows: torch.Tensor, idx: torch.Tensor, num_rows: int) -> torch.T
 
 def adam_clip_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr: float, beta1: float, beta2: float, eps: float,
                    weight_decay: float = 0.0, adamw: bool = False, max_norm: float = 0.0,
-                   total_norm: Optional[torch.Tensor] = None) -> None:
+                   total_norm: Optional[torch.Tensor] = None, amax_out=None) -> None:
     """``clip_grad_norm_(params, max_norm)`` (``max_norm <= 0``: no clipping) followed by one
     ``torch.optim.Adam`` / ``AdamW`` step, in two launches (``rgcn_adam_clip_step``).  All lists
     are parallel, fp32, contiguous CUDA tensors; ``steps[t]`` is the one-element device step count of
     tensor t (bumped here).  Parameters and moments are updated in place; gradients are left as
-    they are (the clipped values are used, not stored)."""
+    they are (the clipped values are used, not stored).  ``amax_out``: per tensor an amax buffer (or None) that
+    receives ``max |param|`` after the update (its written heads are cleared by the first launch; allocate it with
+    ``amax_buffer``) - the scales the next step's transforms would otherwise scan for."""
     n = len(params)
     if not (len(grads) == len(exp_avgs) == len(exp_avg_sqs) == len(steps) == n):
         raise ValueError("params, grads, exp_avgs, exp_avg_sqs and steps must be equally long")
@@ -1357,6 +1397,13 @@ def adam_clip_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr: float, beta1
     dev = params[0].device
     arr = ctypes.c_void_p * n
     numels = (ctypes.c_int64 * n)(*[p.numel() for p in params])
+    amax_arr = None
+    if amax_out is not None:
+        if len(amax_out) != n:
+            raise ValueError("amax_out must be as long as params")
+        for a in amax_out:
+            _check_amax("amax_out", a, dev)
+        amax_arr = ctypes.cast(arr(*[_ptr(a) for a in amax_out]), ctypes.c_void_p)
     with _on(dev):
         nbytes = lib.rgcn_adam_workspace_bytes(n, ctypes.cast(numels, ctypes.c_void_p))
         ws = _workspace(nbytes, dev)
@@ -1367,7 +1414,7 @@ def adam_clip_step(params, grads, exp_avgs, exp_avg_sqs, steps, lr: float, beta1
             ctypes.cast(arr(*[_ptr(t) for t in exp_avg_sqs]), ctypes.c_void_p),
             ctypes.cast(arr(*[_ptr(t) for t in steps]), ctypes.c_void_p), ctypes.cast(numels, ctypes.c_void_p),
             float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(adamw), float(max_norm),
-            _ptr(total_norm), _ptr(ws), nbytes, _stream())
+            _ptr(total_norm), amax_arr, _ptr(ws), nbytes, _stream())
     _lib.check(rc, "rgcn_adam_clip_step")
 
 
@@ -1607,7 +1654,7 @@ class _NotRecordable(Exception):
 
 
 _SEQ_INDEX = {name: i for i, name in enumerate(_lib.SEQ_FUNCTIONS)}
-_SEQ_STREAM_POS = {"rgcn_absmax": 5, "rgcn_absmax_multi": 6, "rgcn_absmax_pack": 13, "rgcn_weights_split_pack_multi": 10,
+_SEQ_STREAM_POS = {"rgcn_absmax": 5, "rgcn_absmax_multi": 6, "rgcn_absmax_pack": 13, "rgcn_weights_split_pack_multi": 12,
                    "rgcn_aggregate": 7, "rgcn_aggregate_and_reduce": 8, "rgcn_aggregate_amax": 9, "rgcn_aggregate_deferred": 8,
                    "rgcn_transform_fwd_split": 20, "rgcn_transform_bwd_input_split": 19, "rgcn_transform_first_split": 12,
                    "rgcn_transform_bwd_params_split_begin": 18, "rgcn_slab_reduce": 1, "rgcn_layer_fwd_fused": 17,
@@ -1845,6 +1892,16 @@ class _Plan:
         self.arena_bytes, self.device = rec.arena_bytes, rec.device
         self.outputs = outputs                               # per output: ("arena", off, shape, dtype) | ("input", k) | None
         self.num_jobs = len(rec.jobs)
+        # external outputs under 256 KB each (bias / root / weight gradients) are views of one slab of their own - one
+        # allocation instead of six; the large ones (layer outputs, the input gradient) stay single tensors
+        self._small_off, self._small_bytes = [], 0
+        for _, nbytes, _, _ in self.external:
+            if nbytes <= (256 << 10):
+                self._small_off.append(self._small_bytes)
+                self._small_bytes += (nbytes + 255) // 256 * 256
+            else:
+                self._small_off.append(None)
+        self._small = sum(o is not None for o in self._small_off) >= 2
         # what the recorded addresses stand for: a later call whose inputs differ in type, shape or place must not be
         # replayed (the wrappers would have refused it; the native list would read the wrong bytes)
         self.signature = rec.input_signature
@@ -1857,15 +1914,15 @@ class _Plan:
             return False
         for t, sig in zip(inputs, sigs):
             if t is None or sig is None:
-                if t is not None or sig is not None:
+                if t is not sig:                             # (both None, or a mismatch)
                     return False
                 continue
-            dtype, shape, index = sig
-            if isinstance(t, Lazy):                          # (an arena view is dense by construction)
-                if t.dtype is not dtype or t.shape != shape or t.arena.get_device() != index:
+            if type(t) is Lazy:                              # (an arena view is dense by construction)
+                if t.dtype is not sig[0] or t.shape != sig[1] or t.arena.get_device() != sig[2]:
                     return False
-            elif t.dtype is not dtype or t.shape != shape or t.get_device() != index or not t.is_contiguous():
-                return False                                 # (a strided input would be read as dense through its data_ptr)
+            elif (t.dtype is not sig[0] or t.shape != sig[1] or t.get_device() != sig[2]
+                  or not t.is_contiguous()):                 # (a strided input would be read as dense through its data_ptr)
+                return False
         return True
 
     def run(self, inputs, want, fill=None):
@@ -1875,7 +1932,13 @@ class _Plan:
         with _on(self.device):
             if fill is None:
                 arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=self.device)
-                ext = [torch.empty(shape, dtype=dtype, device=self.device) for _, _, shape, dtype in self.external]
+                if self._small:                              # the small ones (parameter gradients) share ONE allocation
+                    slab = torch.empty(self._small_bytes, dtype=torch.uint8, device=self.device)
+                    ext = [slab[o: o + nb].view(dtype).view(shape) if o is not None else
+                           torch.empty(shape, dtype=dtype, device=self.device)
+                           for o, (_, nb, shape, dtype) in zip(self._small_off, self.external)]
+                else:
+                    ext = [torch.empty(shape, dtype=dtype, device=self.device) for _, _, shape, dtype in self.external]
             else:
                 arena = torch.full((self.arena_bytes,), fill, dtype=torch.uint8, device=self.device)
                 ext = [torch.full((nbytes,), fill, dtype=torch.uint8, device=self.device).view(dtype).view(shape)

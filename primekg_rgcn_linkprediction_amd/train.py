@@ -198,10 +198,29 @@ class Trainer:
                 state[p]["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state[p]["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         beta1, beta2 = group["betas"]
+        # The update also leaves max |p| of every matrix it writes (the embedding table, W, root) in an amax buffer of
+        # the trainer's: the optimizer is their only writer, so the NEXT step's encoder takes its operand scales from
+        # there (ops.amax_hint) and its first launch splits the weights without scanning 8 MB + the weights first.
+        amax = [self._amax_of(p) for p in params]
         ops.adam_clip_step([p.data for p in params], [p.grad for p in params], [state[p]["exp_avg"] for p in params],
                            [state[p]["exp_avg_sq"] for p in params], [state[p]["step"] for p in params],
                            group["lr"], beta1, beta2, group["eps"], group["weight_decay"],
-                           adamw=isinstance(self.optimizer, torch.optim.AdamW), max_norm=self.args.grad_clip)
+                           adamw=isinstance(self.optimizer, torch.optim.AdamW), max_norm=self.args.grad_clip,
+                           amax_out=amax)
+        for p, a in zip(params, amax):
+            if a is not None:
+                ops.set_amax_hint(p, a)              # valid until the tensor is modified through torch (p._version)
+
+    def _amax_of(self, p):
+        """the amax buffer the fused update publishes max |p| into (matrices only; zeroed once, kept for the run)"""
+        if p.dim() < 2 or p.dtype != torch.float32:
+            return None
+        store = self.__dict__.setdefault("_param_amax", {})
+        buf = store.get(id(p))
+        if buf is None:
+            from . import ops
+            buf = store[id(p)] = ops.amax_buffer(p.device)[0]
+        return buf
 
     def _capture_step(self, batch: int) -> None:
         """Record ``_step`` on the batch at ``self._cursor`` (``order``, ``cursor``, the RNG

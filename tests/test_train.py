@@ -160,6 +160,60 @@ def test_training_steps_are_bitwise_reproducible(tmp_path, hip_graph):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hip_graph", [False, True])
+def test_optimizer_emitted_maxima_change_no_bit(tmp_path, hip_graph, monkeypatch):
+    """the fused clip + Adam step leaves max |p| of the embedding table and of every W / root it
+    writes in an amax buffer (``adam_clip_step(amax_out=)``), and the next step's encoder takes its operand scales
+    from there (``ops.amax_hint``): its first launch splits the weights under GIVEN maxima and scans nothing.  The
+    emitted value is exactly ``max |p|``; seven training steps with the hints give the bits of seven without them;
+    a parameter modified through torch loses its hint."""
+    from primekg_rgcn_linkprediction_amd import ops
+    dev = need_gpu()
+    # (a) what the update emits is the maximum a scan finds
+    torch.manual_seed(3)
+    params = [torch.randn(3001, 64, device=dev) * 0.1, torch.randn(3, 64, 128, device=dev) * 0.2, torch.randn(64, 128, device=dev)]
+    grads = [torch.randn_like(p) for p in params]
+    ms, vs = [torch.zeros_like(p) for p in params], [torch.zeros_like(p) for p in params]
+    steps = [torch.zeros((), device=dev) for _ in params]
+    bufs = [ops.amax_buffer(dev)[0] for _ in params]
+    for _ in range(3):
+        ops.adam_clip_step(params, grads, ms, vs, steps, 0.05, 0.9, 0.999, 1e-8, max_norm=1.0, amax_out=bufs)
+        for p, b in zip(params, bufs):
+            assert torch.equal(ops.amax_value(b), p.abs().max())
+    # (b) the trainer with and without the hints
+    tr, va, full, _ = T.synthetic_data(num_edges=30000, seed=2)
+    states = []
+    for hinted in (True, False):
+        if not hinted:
+            monkeypatch.setattr(ops, "set_amax_hint", lambda t, buf: None)
+        ops._AMAX_HINTS.clear()
+        torch.manual_seed(7)
+        args = _args(batch_size=1024, output_dir=str(tmp_path), device="cuda", no_hip_graph=not hip_graph)
+        trainer = T.Trainer(T.create_model(tr["num_nodes"], 3, args), tr, va, full, dev, args)
+        loss, _ = trainer.train_epoch(max_steps=7)
+        enc = trainer.model.encoder
+        table = enc.node_embeddings.weight
+        if hinted:
+            from primekg_rgcn_linkprediction_amd.conv import _encoder_hints
+            assert _encoder_hints(table, enc.conv1, enc.conv2) is not None, "the optimizer's maxima did not reach the encoder"
+            assert torch.equal(ops.amax_value(ops.amax_hint(table)), table.detach().abs().max())
+            graph = ops.bucket(trainer.train_edge_index, trainer.train_edge_type, tr["num_nodes"], 3)
+            if not hip_graph:       # (a captured step runs its passes through the wrappers: nothing is recorded then)
+                hinted_passes = [v for k, v in graph.__dict__.get("_regions", {}).items()
+                                 if k[0] in ("encoder2.forward", "encoder2.layer1") and k[1][-2] is True]
+                assert hinted_passes and all(isinstance(v, ops._Plan) for v in hinted_passes), \
+                    ("the hinted pass is not issued natively", hinted_passes)
+        states.append(({k: v.clone() for k, v in trainer.model.state_dict().items()}, loss))
+        if hinted:
+            with torch.no_grad():
+                table.mul_(1.0)                                   # any write through torch: the hint is gone
+            assert ops.amax_hint(table) is None
+    assert states[0][1] == states[1][1]
+    for k, v in states[0][0].items():
+        assert torch.equal(v, states[1][0][k]), k
+
+
+@pytest.mark.gpu
 def test_short_run_learns_and_checkpoints(tmp_path):
     dev = need_gpu()
     torch.manual_seed(1)

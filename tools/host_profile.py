@@ -69,10 +69,12 @@ issue, total = per_step(big.explicit, 200)
 print(f"explicit step (rgcn_encoder2_step: both passes, no autograd engine): C2 {issue * 1e6:.0f} us per step issued, {total * 1e6:.0f} us with the final sync")
 issue, total = per_step(small.explicit, 2000)
 print(f"explicit step (rgcn_encoder2_step: both passes, no autograd engine): 1k-node graph (host-bound) {total * 1e6:.0f} us per step")
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(2000):
-    small()
-pr.disable()
-torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 25)
+for name, fn in (("autograd step", small), ("explicit step", small.explicit)):
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(2000):
+        fn()
+    pr.disable()
+    torch.cuda.synchronize()
+    print(f"---- cProfile of 2000 x {name} on the 1k-node graph")
+    pstats.Stats(pr).sort_stats("tottime").print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 25)

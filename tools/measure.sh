@@ -4,7 +4,7 @@
 # (separate runs, --kernel-trace only beside --pmc), the N > 1 legs rehearsed with two gloo ranks on the one GPU.
 # usage: bash tools/measure.sh <tag> [1|2]     -> gpurun_out/<tag>_*   (part 1: bench lines + kernel stats; part 2: PMC
 #        passes, gloo rehearsals, host profile, stamps - each part fits one gpurun call of <= 20 minutes)
-tag=${1:-r03}
+tag=${1:-r04}
 part=${2:-1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out
