@@ -236,7 +236,8 @@ class Run:
             how = ("halo all-to-all-v of the rows a rank's edges read, interior rows computed while it is in flight"
                    if summ["scheme"] == "pull" else
                    "partial sums of the boundary rows from the source owner: reduce-scatter forward, halo all-to-all-v backward")
-            self.parallelism = (f"node-partitioned x{world} (degree-balanced deal), scheme '{summ['scheme']}': {how}, per "
+            deal = {"clustered": "locality-aware clustered assignment", "deal": "degree-balanced deal"}.get(summ.get("partition"), "given assignment")
+            self.parallelism = (f"node-partitioned x{world} ({deal}), scheme '{summ['scheme']}': {how}, per "
                                 f"layer and direction, over {exchange}")
 
     def describe(self, headline):

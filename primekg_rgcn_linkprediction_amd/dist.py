@@ -304,9 +304,9 @@ class NodePartition:
             # random graph (C4: every node ~80 neighbours on all ranks) has no interior rows under any assignment
             light = float((deg <= 8).float().mean()) if num_nodes else 0.0
             method = "clustered" if (world > 1 and num_nodes <= cls.CLUSTER_MAX_NODES and light >= 0.15) else "deal"
-        if method == "clustered":
-            return cls.clustered(edge_index, num_nodes, world)
-        return cls(edge_index, num_nodes, world)
+        part = cls.clustered(edge_index, num_nodes, world) if method == "clustered" else cls(edge_index, num_nodes, world)
+        part.method = method
+        return part
 
     def _finish(self, rank_of: Tensor, slot_of: Tensor, interior: Tensor) -> None:
         self.rank_of, self.slot_of, self.interior = rank_of, slot_of, interior
@@ -843,7 +843,8 @@ class PartitionedEncoder:
     def exchange_summary(self) -> dict:
         """rows this rank receives per exchange, as a fraction of the rows it does not own"""
         s = self.shard
-        return {"scheme": self.scheme, "rows_own": s.num_own, "rows_remote": self.part.num_nodes - s.num_own,
+        return {"scheme": self.scheme, "partition": getattr(self.part, "method", "given"), "rows_own": s.num_own,
+                "rows_remote": self.part.num_nodes - s.num_own,
                 "rows_interior": s.num_interior, "interior_boundary_split": s.split,
                 "push_rows_exchanged": (s.push_rows["total"] if s.push_rows else None),
                 "halo_rows_forward": s.halo_in.num_halo if s.halo_in else None,
