@@ -89,8 +89,7 @@ inline unsigned grid_for(int64_t n) { return (unsigned)std::max<int64_t>(1, ceil
 // of <= RGCN_CHUNK_UP (a workgroup per run) until one row is left.  Order inside level 0: packs first
 // (by descending edge count), then the single items by descending length, so the lane groups of a
 // wavefront finish together and long items start first; packs occupy RGCN_PACK-aligned slots.
-int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, int64_t R, rgcn_csr* csr,
-               const std::vector<int32_t>* first_col = nullptr, int block_shift = 31) {
+int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, int64_t R, rgcn_csr* csr) {
   struct Pending { int32_t seg, begin, end; };
   struct Pack { int32_t begin, end, dst, final_row; };
   std::vector<std::vector<rgcn_item>> levels;
@@ -119,21 +118,12 @@ int build_plan(const std::vector<int32_t>& rowptr, int64_t NR, int64_t R, rgcn_c
   }
   std::stable_sort(packs.begin(), packs.end(),
                    [](const Pack& a, const Pack& b) { return (a.end - a.begin) > (b.end - b.begin); });
-  {  // singles by descending length, stable: lengths are 0..RGCN_CHUNK, so a counting sort does it.
-     // EXPERIMENT (round 4, first_col != NULL): by the block of the gathered table their FIRST source row lies in (2^block_shift
-     // rows per block), then by length - typed relations read one node type's rows per (destination type, relation), so
-     // the gather then works through one source block at a time
-    const int nblk = first_col ? 64 : 1;
-    auto blk = [&](const rgcn_item& it) {
-      if (!first_col || it.end <= it.begin) return 0;
-      return std::min(nblk - 1, (int)((*first_col)[(size_t)it.begin] >> block_shift));
-    };
-    std::vector<int64_t> start((size_t)nblk * (RGCN_CHUNK + 1) + 1, 0);
-    auto key = [&](const rgcn_item& it) { return (size_t)blk(it) * (RGCN_CHUNK + 1) + (RGCN_CHUNK - (it.end - it.begin)); };
-    for (const rgcn_item& it : singles) ++start[key(it) + 1];
-    for (size_t l = 0; l + 1 < start.size(); ++l) start[l + 1] += start[l];
+  {  // singles by descending length, stable: lengths are 0..RGCN_CHUNK, so a counting sort does it
+    std::vector<int64_t> start(RGCN_CHUNK + 2, 0);
+    for (const rgcn_item& it : singles) ++start[RGCN_CHUNK - (it.end - it.begin) + 1];
+    for (int l = 0; l <= RGCN_CHUNK; ++l) start[l + 1] += start[l];
     std::vector<rgcn_item> sorted(singles.size());
-    for (const rgcn_item& it : singles) sorted[(size_t)start[key(it)]++] = it;
+    for (const rgcn_item& it : singles) sorted[(size_t)start[RGCN_CHUNK - (it.end - it.begin)]++] = it;
     singles.swap(sorted);
   }
   levels.emplace_back();
@@ -317,17 +307,7 @@ int plan_structure(rgcn_csr* c, int64_t R, hipStream_t stream) {
     RGCN_HIP_TRY(hipMalloc((void**)&c->tile_mask, mask.size() * sizeof(uint32_t)));
     RGCN_HIP_TRY(hipMemcpy(c->tile_mask, mask.data(), mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
-  {
-    std::vector<int32_t> cols;
-    const char* e = getenv("RGCN_ITEMS_BY_BLOCK");                 // EXPERIMENT: log2 of the rows per source block (e.g. 12)
-    const int64_t E = NR > 0 ? rp[(size_t)NR] : 0;
-    if (e && E > 0 && E < (1 << 27)) {
-      cols.resize((size_t)E);
-      RGCN_HIP_TRY(hipMemcpyAsync(cols.data(), c->col, E * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-      RGCN_HIP_TRY(hipStreamSynchronize(stream));
-    }
-    TRY_PLAN(build_plan(rp, NR, R, c, cols.empty() ? nullptr : &cols, e ? atoi(e) : 31));
-  }
+  TRY_PLAN(build_plan(rp, NR, R, c));
   c->weight_bound = 1.f;
   if (c->weighted && NR > 0 && rp[(size_t)NR] > 0) {      // one-time, on the host: max over segments of sum |w|
     std::vector<float> w((size_t)rp[(size_t)NR]);
