@@ -326,6 +326,25 @@ int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const floa
  * layers (src/models/rgcn.py:125) here: the dropped activations relu_mask = relu(z) * m / (1 - p) are positive
  * exactly where a unit is active AND kept, so mask and factor together are autograd of dropout(relu(z)) - without
  * rescaling (and re-splitting) the layer's weights every step. */
+/* conv2's input gradient with conv1's transform-first product CHAINED behind it inside the workgroup (round 4; the backward of
+ * conv1 -> ReLU -> conv2, /root/reference/src/models/rgcn.py:123-128): grad_x = gz = ([gagg | g] * [W_r^T ; root^T]) . relu_mask,
+ * exactly as rgcn_transform_bwd_input_split (the same bits, grad_x_amax published alike), and t_out[N, (R1 + has_root1) * d_in1] =
+ * gz * [W1_r^T | root1^T] from conv1's split weights `packed1` (its natural-order image) - what rgcn_transform_first_split(gz, ...)
+ * would compute in a launch of its own, a launch that is almost all latency at K = d_in (four k-tiles).  The workgroup owns whole
+ * rows of gz (d_in == 128, one column block), keeps its 64 x 128 tile as fp16 hi / lo fragments under the TILE's maximum (a
+ * power-of-two scale per row tile factors out of every row's sum; where no lo part is subnormal the bits equal the per-tensor
+ * scale's) and walks the column blocks of t_out with a four-slot LDS-DMA ring of conv1's weights.  _supported: d_in == 128.
+ * Measured (MI355X, C2): 47.6-49.5 us for the two launches, 43.2 us chained. */
+int rgcn_transform_bwd_input_chain_supported(int64_t num_relations, int64_t d_in, int64_t d_out, int64_t num_relations1,
+                                             int64_t d_in1);
+int rgcn_transform_bwd_input_chain_split(const float* gagg, const float* g, const float* weight, const float* root,
+                                         const void* packed, const float* relu_mask, const uint32_t* tile_mask,
+                                         int64_t num_nodes, int64_t num_relations, int64_t d_in, int64_t d_out,
+                                         const float* gagg_amax, float gagg_amax_mul, const float* g_amax, float* grad_x,
+                                         float* grad_x_amax, void* workspace, size_t workspace_bytes, void* stream,
+                                         const rgcn_graph* hub_graph, int hub_transposed, float* hub_partial,
+                                         float out_scale, const void* packed1, int has_root1, int64_t num_relations1,
+                                         int64_t d_in1, float* t_out);
 /* Transform-first half of the input gradient (layers with d_out >= 2 d_in): T[N, (R + 1) * d_in] =
  * g * [W_0^T | ... | W_{R-1}^T | root^T] from the split weights' natural-order image (no concatenation, no second
  * split); grad_x is then rgcn_aggregate over the merged transposed structure of T viewed [N * (R + 1), d_in].
@@ -543,7 +562,7 @@ enum {
   RGCN_FN_ABSMAX = 0, RGCN_FN_ABSMAX_MULTI, RGCN_FN_ABSMAX_PACK, RGCN_FN_WEIGHTS_SPLIT_PACK_MULTI, RGCN_FN_AGGREGATE,
   RGCN_FN_AGGREGATE_AND_REDUCE, RGCN_FN_AGGREGATE_AMAX, RGCN_FN_AGGREGATE_DEFERRED, RGCN_FN_TRANSFORM_FWD_SPLIT,
   RGCN_FN_TRANSFORM_BWD_INPUT_SPLIT, RGCN_FN_TRANSFORM_FIRST_SPLIT, RGCN_FN_TRANSFORM_BWD_PARAMS_SPLIT_BEGIN,
-  RGCN_FN_SLAB_REDUCE, RGCN_FN_LAYER_FWD_FUSED, RGCN_FN_LAYER_BWD_INPUT_FUSED, RGCN_FN_COUNT
+  RGCN_FN_SLAB_REDUCE, RGCN_FN_LAYER_FWD_FUSED, RGCN_FN_LAYER_BWD_INPUT_FUSED, RGCN_FN_TRANSFORM_BWD_INPUT_CHAIN_SPLIT, RGCN_FN_COUNT
 };
 typedef struct rgcn_seq_arg {
   int32_t kind;  /* RGCN_SEQ_* */

@@ -49,7 +49,8 @@ SEQ_IMM, SEQ_FLOAT, SEQ_BASE, SEQ_JOB, SEQ_STREAM, SEQ_ARRAY = range(6)
 SEQ_FUNCTIONS = ("rgcn_absmax", "rgcn_absmax_multi", "rgcn_absmax_pack", "rgcn_weights_split_pack_multi", "rgcn_aggregate",
                  "rgcn_aggregate_and_reduce", "rgcn_aggregate_amax", "rgcn_aggregate_deferred", "rgcn_transform_fwd_split",
                  "rgcn_transform_bwd_input_split", "rgcn_transform_first_split", "rgcn_transform_bwd_params_split_begin",
-                 "rgcn_slab_reduce", "rgcn_layer_fwd_fused", "rgcn_layer_bwd_input_fused")
+                 "rgcn_slab_reduce", "rgcn_layer_fwd_fused", "rgcn_layer_bwd_input_fused",
+                 "rgcn_transform_bwd_input_chain_split")
 # their HOST array parameters: position -> (entries are device pointers?, position of the parameter holding the count)
 SEQ_HOST_ARRAYS = {
     "rgcn_absmax_multi": {1: (True, 0), 2: (False, 0), 3: (True, 0)},
@@ -103,6 +104,10 @@ PROTOTYPES = {
                                          _P, _P, _P, c_size_t, _P, c_void_p, c_int, _P]),
     "rgcn_transform_bwd_input_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, c_int,
                                                _P, _P, _P, c_size_t, _P, c_void_p, c_int, _P, c_float]),
+    "rgcn_transform_bwd_input_chain_supported": (c_int, [_I64, _I64, _I64, _I64, _I64]),
+    "rgcn_transform_bwd_input_chain_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, c_float, _P, _P,
+                                                     _P, _P, c_size_t, _P, c_void_p, c_int, _P, c_float, _P, c_int, _I64,
+                                                     _I64, _P]),
     "rgcn_aggregate_deferrable": (c_int, [c_void_p, c_int, _I64]),
     "rgcn_aggregate_deferred": (c_int, [c_void_p, c_int, _P, _I64, _P, _P, c_size_t, POINTER(SlabJob), _P]),
     "rgcn_transform_first_split": (c_int, [_P, _P, c_int, _I64, _I64, _I64, _I64, _P, c_int, _P, _P, c_size_t, _P]),

@@ -110,10 +110,17 @@ def _fused_backward(graph, g, r, d_in, d_out, g_amax, packed, precision) -> bool
             and ops.GEMM_PRECISION == "split" and ops.fused_bwd_supported(r, d_in, d_out))
 
 
+def _transform_first_applies(graph: "ops.BucketedGraph", weight: Tensor, root: Optional[Tensor], packed, precision) -> bool:
+    """does `_input_grad` take the transform-first order from the step's split weights for this layer?"""
+    r, d_in, d_out = weight.shape
+    from_packed = packed is not None and ops.GEMM_PRECISION == "split" and precision is None and d_out % 32 == 0
+    return bool(from_packed and d_out >= _TRANSFORM_FIRST_RATIO * d_in and root is not None and not graph.bipartite)
+
+
 def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Optional[Tensor],
                 tail: Optional["ops.PendingParamGrads"] = None, g_amax: Optional[Tensor] = None,
                 scales: Optional[_Scales] = None, packed: Optional["ops.SplitWeights"] = None,
-                precision: Optional[str] = None) -> Tensor:
+                precision: Optional[str] = None, t_first: Optional[Tensor] = None) -> Tensor:
     """``d loss / d x`` of one layer from ``g = d loss / d out``.
 
     Default: gather first (``gagg = transposed aggregate of g``, then one GEMM with
@@ -144,7 +151,9 @@ def _input_grad(graph: "ops.BucketedGraph", g: Tensor, weight: Tensor, root: Opt
         return ops.transform_bwd_input(gagg, g, weight, root, graph=graph, amax=(g_amax, g_amax),
                                        amax_mul=graph.weight_bound(True), packed=packed,
                                        precision=precision, hubs=hubs)                    # autograd of A6 wrt x
-    if from_packed:
+    if t_first is not None:
+        t = t_first                              # (already formed behind conv2's input gradient: ops.transform_bwd_input_chain)
+    elif from_packed:
         t = ops.transform_first(g.contiguous(), packed, g_amax)                   # from the step's split weights: no cat, no second split
     else:
         ops.guard_torch_op("weight concatenation of the transform-first input gradient")
@@ -173,6 +182,7 @@ def _defer_hubs(half: bool, packed, amax, k: int, n_out: int) -> bool:
 
 
 _DEFER_HUBS = True
+_CHAIN = True          # conv1's transform-first product chained behind conv2's input-gradient GEMM (ops.transform_bwd_input_chain)
 
 
 def _train_fused(graph, n, r, d_in, d_out, half) -> bool:
@@ -316,6 +326,7 @@ def _enc2_backward(x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax, pk1bu
     """the whole backward of conv1 -> ReLU -> [dropout p] -> conv2 -> (gx | None, gw1, groot1, gb1, gw2, groot2, gb2)"""
     r = graph.num_relations
     has_root1, has_b1, has_root2, has_b2 = flags
+    t_first = None
     pk1, pk2 = _packs([pk1buf, pk2buf], [(w1, root1), (w2, root2)])
     scales = _Scales(g)
     g_amax, gz_amax = scales.first, scales.slot()
@@ -334,14 +345,22 @@ def _enc2_backward(x, agg1, h, agg2, w1, root1, w2, root2, x_amax, h_amax, pk1bu
             gagg2, hubs2 = ops.aggregate_deferred(graph, g, transposed=True, tail=red2)
         else:
             gagg2, hubs2 = ops.aggregate(graph, g, transposed=True, tail=red2), None
-        gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph, amax=(g_amax, g_amax),
-                                     amax_mul=wb, amax_out=gz_amax, packed=pk2, precision=prec, hubs=hubs2,
-                                     out_scale=scale)   # d loss / d (pre-ReLU of conv1)
+        # conv1's input gradient is transform-first (T = gz [W1_r^T | root1^T], then one gather): T is formed by the SAME
+        # launch that forms gz, from the workgroup's own tile of it (round 4: one launch less, no re-read of gz)
+        if (_CHAIN and need_x and prec is None and pk1 is not None and pk2 is not None and g_amax is not None
+                and _transform_first_applies(graph, w1, root1, pk1, prec) and ops.chain_supported(w2, w1)):
+            gz, t_first = ops.transform_bwd_input_chain(gagg2, g, w2, root2, h, pk2, pk1, graph=graph, amax=(g_amax, g_amax),
+                                                        amax_mul=wb, amax_out=gz_amax, hubs=hubs2, out_scale=scale)
+        else:
+            gz = ops.transform_bwd_input(gagg2, g, w2, root2, relu_mask=h, graph=graph, amax=(g_amax, g_amax),
+                                         amax_mul=wb, amax_out=gz_amax, packed=pk2, precision=prec, hubs=hubs2,
+                                         out_scale=scale)   # d loss / d (pre-ReLU of conv1)
     red1 = ops.transform_bwd_params(agg1, x, gz, r, want_root=has_root1, want_bias=has_b1, graph=graph,
                                     defer=True, amax=(x_amax, x_amax, gz_amax), precision=prec)
     gx = None
     if need_x:
-        gx = _input_grad(graph, gz, w1, root1, tail=red1, g_amax=gz_amax, scales=scales, packed=pk1, precision=prec)
+        gx = _input_grad(graph, gz, w1, root1, tail=red1, g_amax=gz_amax, scales=scales, packed=pk1, precision=prec,
+                         t_first=t_first)
     red2.finish()
     red1.finish()
     (gw2, groot2, gb2), (gw1, groot1, gb1) = red2.grads, red1.grads
@@ -355,7 +374,7 @@ _R_BACKWARD = ops.Region("encoder2.backward", _enc2_backward)
 
 
 def _policy_key():
-    return (_TRAIN_FUSED, _DEFER_HUBS, _TRANSFORM_FIRST_RATIO, _EVAL_INLINE_LIMIT, _TRAIN_FUSED_MIN_BYTES)
+    return (_TRAIN_FUSED, _DEFER_HUBS, _TRANSFORM_FIRST_RATIO, _EVAL_INLINE_LIMIT, _TRAIN_FUSED_MIN_BYTES, _CHAIN)
 
 
 class _Encoder2Function(torch.autograd.Function):

@@ -130,6 +130,11 @@ int rgcn_sequence_run(const rgcn_seq_call* calls, int num_calls, const rgcn_seq_
         rc = rgcn_layer_bwd_input_fused((const int32_t*)P(0), (const int32_t*)P(1), CF(2), (const uint32_t*)P(3), I(4), I(5),
                                         CF(6), CF(7), P(8), (int)I(9), CF(10), I(11), I(12), CF(13), F(14), MF(15), MF(16),
                                         P(17), F(18)); break;
+      case RGCN_FN_TRANSFORM_BWD_INPUT_CHAIN_SPLIT: NEED(28);
+        rc = rgcn_transform_bwd_input_chain_split(CF(0), CF(1), CF(2), CF(3), P(4), CF(5), (const uint32_t*)P(6), I(7), I(8),
+                                                  I(9), I(10), CF(11), F(12), CF(13), MF(14), MF(15), P(16), (size_t)I(17),
+                                                  P(18), G(19), (int)I(20), MF(21), F(22), P(23), (int)I(24), I(25), I(26),
+                                                  MF(27)); break;
       default: return RGCN_ERR_UNSUPPORTED;
     }
 #undef P

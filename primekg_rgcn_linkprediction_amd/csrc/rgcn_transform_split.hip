@@ -152,7 +152,22 @@ struct hub_fin {
   int d, tiles;
 };
 
-template <int WM, int WN, int TN, int EPI, bool LO>
+// CHAIN (round 4): a SECOND product behind the first one, inside the workgroup - T[M, N2] = C * B2, B2 given split like B
+// ([N2][N] k-contiguous, its own inverse scale) - for the backward of conv1 -> ReLU -> conv2: C = gz = d loss / d (pre-ReLU of
+// conv1) is the input-gradient of conv2 AND the only operand of conv1's transform-first product T = gz * [W1_r^T | root1^T]
+// (K = 128: four k-tiles a workgroup, a launch that was almost all latency).  The workgroup owns whole rows of C (N == BN), so
+// it keeps its 64 x 128 tile, splits it under the TILE's own maximum (a power-of-two scale per row tile is as exact as one
+// per tensor - it factors out of every row's sum) into an fp16 hi / lo image in LDS and runs the N2 / 128 column blocks of
+// the second product from there: no second launch, no re-read of gz, no cold first touch.
+struct nt_chain {
+  const __half* Ch;            // B2 hi [N2][N]
+  const __half* Cl;            // B2 lo
+  const float* c_inv_scale;
+  float* T;                    // [M, N2]
+  int N2;
+};
+
+template <int WM, int WN, int TN, int EPI, bool LO, bool CHAIN = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __restrict__ A1, int K1,
                                                             const float* __restrict__ A2, int K2,
                                                             const __half* __restrict__ Bh,
@@ -163,7 +178,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
                                                             const float* __restrict__ mask, float* __restrict__ C,
                                                             int M, int N, const uint32_t* __restrict__ tile_mask,
                                                             int kseg, unsigned* __restrict__ amax_out,
-                                                            const hub_fin fin, float out_scale) {
+                                                            const hub_fin fin, float out_scale, const nt_chain chain) {
+  static_assert(!CHAIN || (WM == 2 && WN == 2 && TN == 2 && LO), "the chained product is built for the 64 x 128 tile");
   constexpr int WAVES = WM * WN;                 // WM wave rows (32 output rows each) x WN wave columns (32 TN columns each)
   constexpr int BM = 32 * WM, BN = 32 * TN * WN, NBUF = WM == 2 ? 3 : 4, D = NBUF - 1;   // D k-tiles in flight
   constexpr int PARTS = LO ? 2 : 1;              // B images staged: hi (and lo)
@@ -394,7 +410,172 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
   // rides in this epilogue): ONE rounding of acc * (ia * out_scale), ib exact
   const float ia = pow2f(K2 > 0 ? -ea2 : -ea1) * out_scale, ib = b_inv_scale[0];
   float cmax = 0.f;
-  if (m0 + BM <= M && n0 + BN <= N) {
+  if constexpr (CHAIN) {
+    // ---- first product's epilogue (as the interior tile below, rows past M guarded), values kept in LDS ----
+    constexpr int W = 64, RPR = 4, NV = 8;
+    constexpr unsigned IMG = 40 * 1024, IMG_LO = IMG + 16 * 1024;      // [0, 32 KB): transpose area / B2 ring; image behind it
+    static_assert(IMG_LO + 16 * 1024 <= NBUF * BUF_BYTES, "LDS budget of the chained product");
+    __builtin_amdgcn_s_barrier();
+    float* tr = reinterpret_cast<float*>(lds) + wave * (32 * W);
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tr[((r & 3) + 8 * (r >> 2) + 4 * lh) * W + b * 32 + li] = acc[b][r];
+    const int trow = lane >> 4, tc4 = (lane & 15) * 4;
+    const int nq = wn * W + tc4;                                      // n0 == 0: the workgroup owns whole rows
+    float4 mk4[NV];
+    if (EPI == EPI_MASK) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) {
+        const int m = m0 + wm * 32 + q * RPR + trow;
+        mk4[q] = m < M ? *reinterpret_cast<const float4*>(mask + (size_t)m * N + nq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int m = m0 + wm * 32 + q * RPR + trow;
+      const float4 a = *reinterpret_cast<const float4*>(tr + (q * RPR + trow) * W + tc4);
+      float4 v;
+      v.x = a.x * ia * ib; v.y = a.y * ia * ib; v.z = a.z * ia * ib; v.w = a.w * ia * ib;
+      if (EPI == EPI_MASK) {
+        v.x = mk4[q].x > 0.f ? v.x : 0.f; v.y = mk4[q].y > 0.f ? v.y : 0.f;
+        v.z = mk4[q].z > 0.f ? v.z : 0.f; v.w = mk4[q].w > 0.f ? v.w : 0.f;
+      }
+      if (m < M) *reinterpret_cast<float4*>(C + (size_t)m * N + nq) = v;
+      else v = make_float4(0.f, 0.f, 0.f, 0.f);
+      cmax = fmaxf(cmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      *reinterpret_cast<float4*>(tr + (q * RPR + trow) * W + tc4) = v;   // (the same lane reads it back below)
+    }
+    // ---- the tile's own maximum -> its power-of-two scale; the tile as fp16 hi / lo image [64][128], 256-byte rows,
+    //      16-byte chunk c of row r at chunk slot c ^ (r & 15): the fragment reads below are conflict free ----
+    float* wmax = reinterpret_cast<float*>(lds + 32 * 1024);
+    {
+      const unsigned mw = __ockl_wfred_max_u32(__float_as_uint(cmax));
+      if (lane == 0) wmax[wave] = __uint_as_float(mw);
+    }
+    __syncthreads();
+    const float tile_max = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const int e2 = scale_exponent(tile_max);
+    const float s2 = pow2f(e2);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int rl = wm * 32 + q * RPR + trow, col = wn * W + tc4;
+      const float4 v = *reinterpret_cast<const float4*>(tr + (q * RPR + trow) * W + tc4);
+      const float u[4] = {v.x * s2, v.y * s2, v.z * s2, v.w * s2};
+      half4v h, l;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const _Float16 hh = (_Float16)u[c];
+        h[c] = hh;
+        l[c] = (_Float16)(u[c] - (float)hh);
+      }
+      const unsigned at = (unsigned)(rl * 256 + ((((col >> 3) ^ (rl & 15)) << 4) | ((col & 4) << 1)));
+      *reinterpret_cast<float2v*>(lds + IMG + at) = __builtin_bit_cast(float2v, h);
+      *reinterpret_cast<float2v*>(lds + IMG_LO + at) = __builtin_bit_cast(float2v, l);
+    }
+    __syncthreads();                               // image complete
+    // ---- second product: T[rows, N2] = image * B2.  The wave's A operand - its 32 rows of the image, all of K = 128 - goes
+    //      into registers once (16 fragments), after which the WHOLE ring is free for B2: four slots of one k-tile each
+    //      (hi + lo, 16 KB), three tiles in flight, one barrier per tile, the column blocks walked back to back and their
+    //      accumulators stored straight from the MFMA layout (no LDS turn: the ring never drains between blocks) ----
+    const __half* __restrict__ Ch = chain.Ch;
+    const __half* __restrict__ Cl = chain.Cl;
+    const int N2 = chain.N2, KC = N;              // the second product's K is the first one's N (= 128)
+    constexpr int SLOT2 = 2 * B_BYTES, NS2 = 4, D2 = NS2 - 1, P2 = 2 * B_PW, KT2 = 4;   // 4 k-tiles per column block (KC == 128)
+    static_assert(NS2 * SLOT2 <= NBUF * BUF_BYTES, "B2 ring");
+    f32x4 fah[8], fal[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const unsigned aa = (unsigned)(arow * 256 + (((2 * ks + lh) ^ (arow & 15)) << 4));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fah[ks]) : "v"(aa), "n"(IMG));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fal[ks]) : "v"(aa), "n"(IMG_LO));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fah[0]), "+v"(fah[1]), "+v"(fah[2]), "+v"(fah[3]), "+v"(fah[4]), "+v"(fah[5]), "+v"(fah[6]), "+v"(fah[7]),
+                   "+v"(fal[0]), "+v"(fal[1]), "+v"(fal[2]), "+v"(fal[3]), "+v"(fal[4]), "+v"(fal[5]), "+v"(fal[6]), "+v"(fal[7]));
+    __builtin_amdgcn_s_barrier();                  // every wave has its fragments: the image's LDS belongs to the ring now
+    const int col_blocks = (N2 + BN - 1) / BN, rounds = col_blocks * KT2;
+    auto stage2 = [&](int r) {                     // round r = (column block r / 4, k-tile r % 4) -> slot r % 4
+      const int cb = r / KT2, kt = (r % KT2) * BK;
+      char* dst = lds + (r % NS2) * SLOT2;
+#pragma unroll
+      for (int j = 0; j < B_PW; ++j) {
+        const int row = (wave * B_PW + j) * 16 + (lane >> 2);
+        const int n = min(cb * BN + row, N2 - 1);
+        const int chunk = (lane & 3) ^ ((row >> 1) & 3);
+        const size_t off = (size_t)n * KC + kt + chunk * 8;
+        glds16(Ch + off, dst + (wave * B_PW + j) * 16 * BK * 2);
+        glds16(Cl + off, dst + B_BYTES + (wave * B_PW + j) * 16 * BK * 2);
+      }
+    };
+    unsigned b2_addr[TN][2];                       // B2 fragments of the two 16-k steps of a tile (inside a slot)
+#pragma unroll
+    for (int s2i = 0; s2i < 2; ++s2i)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int brow = (wn * TN + b) * 32 + li;
+        b2_addr[b][s2i] = (unsigned)(brow * BK * 2 + (((2 * s2i + lh) ^ ((brow >> 1) & 3)) << 4));
+      }
+    const float i2 = pow2f(-e2), ic = chain.c_inv_scale[0];
+#pragma unroll
+    for (int r = 0; r < D2; ++r)
+      if (r < rounds) stage2(r);
+    floatx16 acc2[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc2[b][q] = 0.f;
+    for (int cb2 = 0; cb2 < col_blocks; ++cb2)
+#pragma unroll
+    for (int kq = 0; kq < KT2; ++kq) {             // (k-tile of the column block: a compile-time index into the A fragments)
+      const int r = cb2 * KT2 + kq;
+      // tile r has landed for this wave (all but the tiles staged behind it), then for every wave; the barrier also says
+      // everybody is done with slot (r - 1) % 4, which the stage below refills
+      if (r + 2 < rounds) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P2) : "memory");
+      else if (r + 1 < rounds) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const unsigned slot = (unsigned)((r % NS2) * SLOT2);
+      f32x4 fbh[2][TN], fbl[2][TN];
+#pragma unroll
+      for (int s2i = 0; s2i < 2; ++s2i)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          asm volatile("ds_read_b128 %0, %1" : "=v"(fbh[s2i][b]) : "v"(b2_addr[b][s2i] + slot));
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fbl[s2i][b]) : "v"(b2_addr[b][s2i] + slot), "n"(B_BYTES));
+        }
+      if (r + D2 < rounds) stage2(r + D2);
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fbh[0][0]), "+v"(fbl[0][0]), "+v"(fbh[0][1]), "+v"(fbl[0][1]), "+v"(fbh[1][0]), "+v"(fbl[1][0]),
+                     "+v"(fbh[1][1]), "+v"(fbl[1][1]));
+#pragma unroll
+      for (int s2i = 0; s2i < 2; ++s2i) {
+        const half8 ah = __builtin_bit_cast(half8, fah[2 * kq + s2i]), al = __builtin_bit_cast(half8, fal[2 * kq + s2i]);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, __builtin_bit_cast(half8, fbh[s2i][b]), acc2[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, fbl[s2i][b]), acc2[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc2[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(half8, fbh[s2i][b]), acc2[b], 0, 0, 0);
+      }
+      if (kq == KT2 - 1) {                         // the column block is complete: out, straight from the MFMA layout
+        const int cb = cb2;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int n = cb * BN + (wn * TN + b) * 32 + li;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int m = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+            if (m < M && n < N2) chain.T[(size_t)m * N2 + n] = acc2[b][q] * i2 * ic;
+            acc2[b][q] = 0.f;
+          }
+        }
+      }
+    }
+  } else if (m0 + BM <= M && n0 + BN <= N) {
     // Interior tile.  An MFMA accumulator holds 4 consecutive ROWS of one column per lane: stored as it stands that
     // is 16 TN one-dword stores per lane (and as many mask loads), and a store tail is bound by the number of store
     // INSTRUCTIONS, not by bytes (MI355X guide, T21).  So the wave turns its 32 x (32 TN) block through LDS - the ring
@@ -833,7 +1014,11 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
                     const float* b_inv, const float* bias, const float* mask, int epi, float* C, int M, int N,
                     const uint32_t* tile_mask, int kseg, const float* a1_amax, float a1_mul, const float* a2_amax,
                     float* c_amax, float* scan_slots, bool half, hipStream_t stream, const hub_fin* hubs = nullptr,
-                    float out_scale = 1.f) {
+                    float out_scale = 1.f, const nt_chain* chained = nullptr) {
+  const nt_chain chain = chained ? *chained : nt_chain{};
+  if (chained && (half || N != 128 || bias || epi == EPI_RELU || !chain.Ch || !chain.Cl || !chain.c_inv_scale || !chain.T ||
+                  chain.N2 <= 0 || (chain.N2 & 3)))
+    return RGCN_ERR_UNSUPPORTED;
   const hub_fin fin = hubs ? *hubs : hub_fin{};
   if (fin.ptr && fin.d != 64 && fin.d != 128 && fin.d != 256) return RGCN_ERR_UNSUPPORTED;
   if (fin.ptr && (!a1_amax || fin.d != kseg)) return RGCN_ERR_ARG;   // an unfinished A1 cannot be scanned for its maximum
@@ -853,9 +1038,21 @@ int launch_nt_split(const float* A1, int K1, const float* A2, int K2, const __ha
   if (!r1.slots) { r1 = r2; r2 = amax_ref{nullptr, 0}; a1_mul = 1.f; }   // the kernels read r1 unconditionally
   if (kseg <= 0 || kseg % BK != 0) tile_mask = nullptr;
   unsigned* amax_out = reinterpret_cast<unsigned*>(c_amax);
+  if (chained) {                                 // the second product rides behind the first one (64 x 128 tiles, whole rows)
+    dim3 grid((unsigned)ceil_div64(M, 64), 1);
+    if (epi == EPI_MASK)
+      k_gemm_nt_split<2, 2, 2, EPI_MASK, true, true><<<grid, 256, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, C,
+                                                                             M, N, tile_mask, kseg, amax_out, fin, out_scale, chain);
+    else
+      k_gemm_nt_split<2, 2, 2, EPI_NONE, true, true><<<grid, 256, 0, stream>>>(A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, C,
+                                                                             M, N, tile_mask, kseg, amax_out, fin, out_scale, chain);
+    RGCN_HIP_TRY(hipGetLastError());
+    return RGCN_OK;
+  }
 #define RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, LO_)                                                                     \
   k_gemm_nt_split<WM_, WN_, TN_, EPI_, LO_><<<grid, 64 * WM_ * WN_, 0, stream>>>(                                     \
-      A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, C, M, N, tile_mask, kseg, amax_out, fin, out_scale)
+      A1, K1, A2, K2, Bh, Bl, b_inv, r1, a1_mul, r2, bias, mask, C, M, N, tile_mask, kseg, amax_out, fin, out_scale,  \
+      nt_chain{})
 #define RGCN_NT_SPLIT_W(WM_, WN_, TN_, EPI_)             \
   do {                                                   \
     if (half) RGCN_NT_LAUNCH(WM_, WN_, TN_, EPI_, false); \
@@ -1103,6 +1300,40 @@ int rgcn_transform_bwd_input_split(const float* gagg, const float* g, const floa
   return launch_nt_split(gagg, K1, g, K2, v.Bh_b, v.Bl_b, v.inv_scale, nullptr, relu_mask,
                          relu_mask ? EPI_MASK : EPI_NONE, grad_x, (int)N, (int)d_in, tile_mask, (int)d_out, gagg_amax,
                          gagg_amax_mul, g_amax, grad_x_amax, scan, half != 0, stream, hrc ? &fin : nullptr, out_scale);
+}
+
+int rgcn_transform_bwd_input_chain_supported(int64_t R, int64_t d_in, int64_t d_out, int64_t R1, int64_t d_in1) {
+  // conv2: [gagg | g] (K = (R + 1) d_out) -> gz [N, d_in]; conv1 (d_out1 = d_in): T [N, (R1 + 1) d_in1]
+  if (R <= 0 || R1 <= 0 || d_in != 128 || d_out <= 0 || (d_out % BK) || d_in1 <= 0 || (d_in1 & 3)) return 0;
+  return 1;
+}
+
+int rgcn_transform_bwd_input_chain_split(const float* gagg, const float* g, const float* weight, const float* root,
+                                         const void* packed, const float* relu_mask, const uint32_t* tile_mask, int64_t N,
+                                         int64_t R, int64_t d_in, int64_t d_out, const float* gagg_amax,
+                                         float gagg_amax_mul, const float* g_amax, float* grad_x, float* grad_x_amax,
+                                         void* workspace, size_t workspace_bytes, void* stream_,
+                                         const rgcn_graph* hub_graph, int hub_transposed, float* hub_partial,
+                                         float out_scale, const void* packed1, int has_root1, int64_t R1, int64_t d_in1,
+                                         float* t_out) {
+  if (bad_dims(N, R, d_in, d_out) || !grad_x || !t_out || !packed || !packed1 || !(out_scale > 0.f)) return RGCN_ERR_ARG;
+  if (!rgcn_transform_bwd_input_chain_supported(R, d_in, d_out, R1, d_in1)) return RGCN_ERR_UNSUPPORTED;
+  if (N == 0) return RGCN_OK;
+  if (!gagg || !g || !weight || !gagg_amax || !g_amax) return RGCN_ERR_ARG;
+  if (N > INT32_MAX / 2 || (R + 1) * d_out > (1 << 24) || (R1 + 1) * d_in1 > (1 << 24)) return RGCN_ERR_UNSUPPORTED;
+  if (!workspace || workspace_bytes < nt_workspace_bytes(R, d_in, d_out)) return RGCN_ERR_WORKSPACE;
+  hipStream_t stream = (hipStream_t)stream_;
+  const PackedWeights v = packed_view(const_cast<void*>(packed), R, d_in, d_out);
+  const PackedWeights v1 = packed_view(const_cast<void*>(packed1), R1, d_in1, d_in);     // conv1: d_out1 = d_in of conv2
+  float* scan = (float*)((char*)workspace + packed_bytes(R, d_in, d_out));
+  const int K1 = (int)(R * d_out), K2 = root ? (int)d_out : 0;
+  hub_fin fin;
+  const int hrc = make_hub_fin(hub_graph, hub_transposed, hub_partial, N, R, d_out, &fin);
+  if (hrc < 0) return hrc;
+  nt_chain chain{v1.Bh_n, v1.Bl_n, v1.inv_scale, t_out, (int)((R1 + (has_root1 ? 1 : 0)) * d_in1)};
+  return launch_nt_split(gagg, K1, g, K2, v.Bh_b, v.Bl_b, v.inv_scale, nullptr, relu_mask, relu_mask ? EPI_MASK : EPI_NONE,
+                         grad_x, (int)N, (int)d_in, tile_mask, (int)d_out, gagg_amax, gagg_amax_mul, g_amax, grad_x_amax, scan,
+                         false, stream, hrc ? &fin : nullptr, out_scale, &chain);
 }
 
 int rgcn_transform_first_split(const float* g, const void* packed, int has_root, int64_t N, int64_t R, int64_t d_in,

@@ -1223,6 +1223,60 @@ def transform_bwd_input(gagg, g, weight, root=None, relu_mask=None,
     return gx
 
 
+def chain_supported(weight: torch.Tensor, weight1: torch.Tensor) -> bool:
+    """can conv2's input gradient (``weight`` [R, d_in, d_out]) carry conv1's transform-first product (``weight1``
+    [R1, d_in1, d_in]) behind it in one launch (``transform_bwd_input_chain``)?  split precision, d_in == 128"""
+    r, d_in, d_out = weight.shape
+    r1, d_in1, d_out1 = weight1.shape
+    return bool(GEMM_PRECISION == "split" and d_out1 == d_in and GEMM_EVENTS is None and
+                _query("rgcn_transform_bwd_input_chain_supported", r, d_in, d_out, r1, d_in1))
+
+
+def transform_bwd_input_chain(gagg, g, weight, root, relu_mask, packed: SplitWeights, packed1: SplitWeights,
+                              graph: Optional[BucketedGraph] = None, amax=None, amax_out: Optional[torch.Tensor] = None,
+                              amax_mul: float = 1.0, hubs: Optional[DeferredHubs] = None, out_scale: float = 1.0):
+    """``(gz, T)``: ``gz = transform_bwd_input(gagg, g, weight, root, relu_mask, ...)`` - the same bits - and
+    ``T = transform_first(gz, packed1)``, conv1's transform-first product (``[N, (R1 + 1) * d_in1]``), computed by the
+    SAME launch: every workgroup keeps its 64-row tile of ``gz`` as fp16 hi / lo fragments and multiplies it by conv1's
+    weights right away (``rgcn_transform_bwd_input_chain_split``; 47.6-49.5 -> 43.2 us at C2)."""
+    _need_gpu("g", g, torch.float32)
+    _need_gpu("gagg", gagg, torch.float32)
+    _need_gpu("weight", weight, torch.float32)
+    r, d_in, d_out = weight.shape
+    r1, d_in1, _ = packed1.shape
+    n = g.size(0)
+    if tuple(g.shape) != (n, d_out) or tuple(gagg.shape) != (n, r * d_out):
+        raise ValueError("g must be [N, d_out] and gagg [N, R*d_out]")
+    if root is not None:
+        _need_gpu("root", root, torch.float32)
+    if relu_mask is not None:
+        _need_gpu("relu_mask", relu_mask, torch.float32)
+        if tuple(relu_mask.shape) != (n, d_in):
+            raise ValueError(f"relu_mask must be [{n}, {d_in}]")
+    if not packed.matches(weight, root) or packed1.shape[2] != d_in:
+        raise ValueError("packed / packed1 do not belong to these layers")
+    a1, a2 = amax if amax is not None else (None, None)
+    _check_amax("gagg_amax", a1, g.device)
+    _check_amax("g_amax", a2, g.device)
+    _check_amax("amax_out", amax_out, g.device)
+    if a1 is None or a2 is None:
+        raise ValueError("the chained transform needs the operand maxima (amax=)")
+    lib = _L()
+    cols = (r1 + (1 if packed1.has_root else 0)) * d_in1
+    with _on(g.device):
+        gz = _empty(n, d_in, dtype=torch.float32, device=g.device)
+        t = _empty(n, cols, dtype=torch.float32, device=g.device)
+        nbytes = _query("rgcn_transform_split_workspace_bytes", r, d_in, d_out)
+        ws = _workspace(nbytes, g.device)
+        rc = lib.rgcn_transform_bwd_input_chain_split(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root), _ptr(packed.buf),
+                                                      _ptr(relu_mask), _mask_for(graph, True, n, r), n, r, d_in, d_out,
+                                                      _ptr(a1), float(amax_mul), _ptr(a2), _ptr(gz), _ptr(amax_out), _ptr(ws),
+                                                      nbytes, _stream(), *_hub_args(hubs, n, r), float(out_scale),
+                                                      _ptr(packed1.buf), int(packed1.has_root), r1, d_in1, _ptr(t))
+    _lib.check(rc, "rgcn_transform_bwd_input_chain_split")
+    return gz, t
+
+
 def transform_first(g: torch.Tensor, packed: SplitWeights, amax: Optional[torch.Tensor] = None,
                     precision: Optional[str] = None) -> torch.Tensor:
     """``T = g @ [W_0^T | ... | W_{R-1}^T | root^T]`` -> ``[N, (R + 1) * d_in]`` (``R * d_in`` without a root) from
@@ -1658,7 +1712,7 @@ _SEQ_STREAM_POS = {"rgcn_absmax": 5, "rgcn_absmax_multi": 6, "rgcn_absmax_pack":
                    "rgcn_aggregate": 7, "rgcn_aggregate_and_reduce": 8, "rgcn_aggregate_amax": 9, "rgcn_aggregate_deferred": 8,
                    "rgcn_transform_fwd_split": 20, "rgcn_transform_bwd_input_split": 19, "rgcn_transform_first_split": 12,
                    "rgcn_transform_bwd_params_split_begin": 18, "rgcn_slab_reduce": 1, "rgcn_layer_fwd_fused": 17,
-                   "rgcn_layer_bwd_input_fused": 17}
+                   "rgcn_layer_bwd_input_fused": 17, "rgcn_transform_bwd_input_chain_split": 18}
 _SEQ_PURE = ("rgcn_graph_tile_mask", "rgcn_graph_num_levels", "rgcn_graph_weight_bound", "rgcn_aggregate_deferrable",
              "rgcn_graph_num_edges", "rgcn_graph_num_nodes", "rgcn_graph_num_relations", "rgcn_abi_version", "rgcn_strerror")
 REGIONS = True      # False: always through the wrappers (tests, tools/host_profile.py)

@@ -1858,6 +1858,45 @@ def test_native_step_replays_the_recorded_pass_bit_for_bit(p, frozen_input, monk
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,d_in1,d_out2,mask,root1,scale", [(30926, 64, 128, True, True, 1.0), (1000, 64, 128, True, True, 2.0),
+                                                            (777, 32, 64, False, True, 1.0), (130, 64, 256, True, False, 1.0),
+                                                            (63, 128, 128, True, True, 1.0)])
+def test_chained_transform_first_equals_the_two_launches(n, d_in1, d_out2, mask, root1, scale):
+    """``ops.transform_bwd_input_chain``: conv2's input gradient with conv1's transform-first product formed behind it by
+    the same workgroup.  ``gz`` is the bits of ``transform_bwd_input``; ``T`` equals ``transform_first(gz)`` to rounding
+    - the chained product splits its tile of gz under the TILE's maximum, the stand-alone one under the tensor's, which
+    changes a bit only where a lo part is subnormal under the one scale and not the other - and is itself within 2e-6 of
+    float64; ragged last row tile, no mask, no root, the dropout factor, the published maximum of gz."""
+    dev = need_gpu()
+    r, hidden = 3, 128
+    gen = torch.Generator().manual_seed(n)
+    w2, root2 = torch.randn(r, hidden, d_out2, generator=gen).to(dev) * 0.1, torch.randn(hidden, d_out2, generator=gen).to(dev) * 0.1
+    w1 = torch.randn(r, d_in1, hidden, generator=gen).to(dev) * 0.1
+    r1 = torch.randn(d_in1, hidden, generator=gen).to(dev) * 0.1 if root1 else None
+    g = torch.randn(n, d_out2, generator=gen).to(dev) * 0.01
+    gagg = torch.randn(n, r * d_out2, generator=gen).to(dev) * 0.01
+    gagg[::7] *= 1e-4                                                          # a spread of magnitudes across row tiles
+    h = torch.randn(n, hidden, generator=gen).to(dev) if mask else None
+    g_amax = ops.absmax(g)
+    pk2, pk1 = ops.split_weights_many([(w2, root2), (w1, r1)])
+    assert ops.chain_supported(w2, w1)
+    za, zb = ops.amax_buffer(dev, 2)
+    want_gz = ops.transform_bwd_input(gagg, g, w2, root2, relu_mask=h, amax=(g_amax, g_amax), amax_mul=1.5, amax_out=za,
+                                      packed=pk2, out_scale=scale)
+    want_t = ops.transform_first(want_gz, pk1, za)
+    gz, t = ops.transform_bwd_input_chain(gagg, g, w2, root2, h, pk2, pk1, amax=(g_amax, g_amax), amax_mul=1.5, amax_out=zb,
+                                          out_scale=scale)
+    assert torch.equal(gz, want_gz)
+    assert torch.equal(ops.amax_value(zb), ops.amax_value(za)) and torch.equal(ops.amax_value(zb), gz.abs().max())
+    assert t.shape == want_t.shape == (n, (r + int(root1)) * d_in1)
+    tmax = float(want_t.abs().max())
+    assert float((t - want_t).abs().max()) <= 1e-6 * tmax
+    wcat = torch.cat([w1.reshape(r * d_in1, hidden)] + ([r1] if root1 else [])).double()
+    t64 = gz.double() @ wcat.t()
+    assert float((t.double() - t64).abs().max()) <= 2e-6 * float(t64.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("num_bases", [None, 4])
 def test_explicit_encoder_step_equals_the_autograd_step_bit_for_bit(num_bases):
     """``rgcn_encoder2_step``: forward + backward for a given cotangent without the autograd engine (the two recorded
