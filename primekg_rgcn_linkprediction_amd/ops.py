@@ -1228,7 +1228,7 @@ def chain_supported(weight: torch.Tensor, weight1: torch.Tensor) -> bool:
     [R1, d_in1, d_in]) behind it in one launch (``transform_bwd_input_chain``)?  split precision, d_in == 128"""
     r, d_in, d_out = weight.shape
     r1, d_in1, d_out1 = weight1.shape
-    return bool(GEMM_PRECISION == "split" and d_out1 == d_in and GEMM_EVENTS is None and
+    return bool(GEMM_PRECISION == "split" and d_out1 == d_in and
                 _query("rgcn_transform_bwd_input_chain_supported", r, d_in, d_out, r1, d_in1))
 
 
@@ -1268,11 +1268,13 @@ def transform_bwd_input_chain(gagg, g, weight, root, relu_mask, packed: SplitWei
         t = _empty(n, cols, dtype=torch.float32, device=g.device)
         nbytes = _query("rgcn_transform_split_workspace_bytes", r, d_in, d_out)
         ws = _workspace(nbytes, g.device)
-        rc = lib.rgcn_transform_bwd_input_chain_split(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root), _ptr(packed.buf),
-                                                      _ptr(relu_mask), _mask_for(graph, True, n, r), n, r, d_in, d_out,
-                                                      _ptr(a1), float(amax_mul), _ptr(a2), _ptr(gz), _ptr(amax_out), _ptr(ws),
-                                                      nbytes, _stream(), *_hub_args(hubs, n, r), float(out_scale),
-                                                      _ptr(packed1.buf), int(packed1.has_root), r1, d_in1, _ptr(t))
+        # (bench.py's bracket: K + cols reduction columns against d_in outputs = the flops and operand bytes of both products)
+        with _GemmBracket("bwd_input_chain", n, (r + (root is not None)) * d_out + cols, d_in, "split"):
+            rc = lib.rgcn_transform_bwd_input_chain_split(_ptr(gagg), _ptr(g), _ptr(weight), _ptr(root), _ptr(packed.buf),
+                                                          _ptr(relu_mask), _mask_for(graph, True, n, r), n, r, d_in, d_out,
+                                                          _ptr(a1), float(amax_mul), _ptr(a2), _ptr(gz), _ptr(amax_out), _ptr(ws),
+                                                          nbytes, _stream(), *_hub_args(hubs, n, r), float(out_scale),
+                                                          _ptr(packed1.buf), int(packed1.has_root), r1, d_in1, _ptr(t))
     _lib.check(rc, "rgcn_transform_bwd_input_chain_split")
     return gz, t
 
