@@ -104,6 +104,36 @@ struct amax_ref {
 __device__ inline float amax_of(const amax_ref& r, int lane) {
   return r.count == 0 ? rgcn_amax_value(r.slots, lane) : rgcn_partials_max(r.slots, r.count, lane);
 }
+// The same value in two halves, for a kernel that counts vmcnt itself: `amax_request` issues a lane's four loads
+// (either layout, no branch) as instructions the compiler does not track - a wait of its own could only be vmcnt(0):
+// it does not count LDS-DMAs issued behind a load as "younger, in order" - and the caller covers them with ONE counted
+// s_waitcnt that names every v[] as an operand (RGCN_AMAX_WAIT) before `amax_reduce` touches them.
+// tools/check_waitcnt.py verifies in the disassembly that nothing reads such a register before that wait.
+struct amax_loads {
+  float v[4];
+};
+__device__ inline amax_loads amax_request(const amax_ref& r, int lane) {
+  amax_loads q;
+  const int stride = r.count == 0 ? RGCN_AMAX_HEAD_STRIDE : 1, last = r.count == 0 ? RGCN_AMAX_HEADS - 1 : r.count - 1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float* p = r.slots + min(lane + 64 * j, last) * stride;                       // (a repeated element: same maximum)
+    asm volatile("global_load_dword %0, %1, off" : "=v"(q.v[j]) : "v"(p) : "memory");
+  }
+  return q;
+}
+#define RGCN_AMAX_WAIT(a, b, c, younger)                                                                             \
+  asm volatile("s_waitcnt vmcnt(%12)"                                                                                 \
+               : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]),     \
+                 "+v"(b.v[3]), "+v"(c.v[0]), "+v"(c.v[1]), "+v"(c.v[2]), "+v"(c.v[3])                                  \
+               : "n"(younger)                                                                                         \
+               : "memory")
+__device__ inline float amax_reduce(const amax_loads& q) {
+  float m = fmaxf(fmaxf(q.v[0], q.v[1]), fmaxf(q.v[2], q.v[3]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return m;
+}
 
 // ---------------------------------------------------------------------------------------
 // The weights of one layer, split ONCE per step for both transforms that multiply by them:
@@ -731,6 +761,13 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const float* __re
   const bool bias_block = (bias_part != nullptr) && (kc_tile == (K2 > 0 ? kc_tiles - 1 : 0));
   const bool do_bias = bias_block && (tid < 128);
   RGCN_STAMP(0);
+  // The operand maxima are requested FIRST, ahead of the DMAs: loads return in order, so "all but the 3 P youngest"
+  // says they have arrived and the conversion of tile 0 starts when tile 0 has landed.  (Requested behind the DMAs,
+  // as until round 4, the wait before their use was vmcnt(0): all three staged tiles.)  For the count to be a constant
+  // the prologue always issues three tiles' DMAs - for tiles past the split's end they re-read clamped rows into ring
+  // slots nobody converts.
+  amax_loads q1 = amax_request(amax1, lane), q2 = amax_request(amax2.slots ? amax2 : amax1, lane),
+             qg = amax_request(gmax, lane);
   unsigned rel_bits = 0u;                                        // m-tiles without any of this kc tile's relations: skipped
   if (tile_mask != nullptr && !bias_block && kc0 + TKC <= K1)
     for (int c = kc0; c < kc0 + TKC; c += kseg) rel_bits |= 1u << (c / kseg);
@@ -754,7 +791,7 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const float* __re
   const bool a_first = acol < K1;
   const float* a_src = a_first ? A1 + acol : A2 + (acol - K1);
   const int lda = a_first ? K1 : K2;
-  const bool g_ok = n0 + d_col < N;
+  const int gcol = min(n0 + d_col, N - 4);                       // as for A: every lane issues every DMA (the counted waits rely on it)
   auto stage = [&](int mt, int slot) {
     char* sA = lds + slot * SLOT_BYTES;
     char* sG = sA + A_FLOATS * 4;
@@ -768,23 +805,28 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const float* __re
     for (int j = 0; j < G_PW; ++j) {
       const int r0 = (wave * G_PW + j) * 2;
       const int m = min(mt + r0 + d_row, M - 1);
-      if (g_ok) glds16(G + (size_t)m * N + n0 + d_col, sG + r0 * 128 * 4);
+      glds16(G + (size_t)m * N + gcol, sG + r0 * 128 * 4);
     }
   };
 
   // tiles T0, T1, T2 in the ring; `cur` is multiplied, `nxt` converted, `aft` in flight
-  int cur = next_mt(mbeg - 32), nxt = cur < mend ? next_mt(cur) : mend, aft = nxt < mend ? next_mt(nxt) : mend;
-  if (cur < mend) stage(cur, 0);
-  if (nxt < mend) stage(nxt, 1);
-  if (aft < mend) stage(aft, 2);
+  // (each tile's DMAs leave as soon as the tile is known: looking a tile up can be a dependent read of the occupancy
+  // words, and three of those ahead of the first DMA were a microsecond of the prologue)
+  int cur = next_mt(mbeg - 32);
+  stage(cur, 0);
+  int nxt = cur < mend ? next_mt(cur) : mend;
+  stage(nxt, 1);
+  int aft = nxt < mend ? next_mt(nxt) : mend;
+  stage(aft, 2);
 
-  // operand scales (behind the first DMA issue).  Conversion: waves 0-3 convert A - thread (column pair cp, row
-  // group mg) - waves 4-7 convert G; a column pair lies in one A operand (K1 even).
+  // operand scales.  Conversion: waves 0-3 convert A - thread (column pair cp, row group mg) - waves 4-7 convert G;
+  // a column pair lies in one A operand (K1 even).
   const bool conv_a = wave < 4;
   const int cp = tid & 63, mg = (tid >> 6) & 3;
-  const float amax_a1 = amax_of(amax1, lane) * a1_mul;
-  const float amax_a2 = amax2.slots ? amax_of(amax2, lane) : amax_a1;
-  const int ea1 = scale_exponent(amax_a1), ea2 = scale_exponent(amax_a2), eg = scale_exponent(amax_of(gmax, lane));
+  RGCN_AMAX_WAIT(q1, q2, qg, 3 * P);             // the twelve loads are older than the 3 P DMAs staged above
+  const float amax_a1 = amax_reduce(q1) * a1_mul;
+  const float amax_a2 = amax2.slots ? amax_reduce(q2) : amax_a1;
+  const int ea1 = scale_exponent(amax_a1), ea2 = scale_exponent(amax_a2), eg = scale_exponent(amax_reduce(qg));
   const bool cfirst = kc0 + 2 * cp < K1 || !amax2.slots;         // the converting thread's columns
   const float sconv = conv_a ? pow2f(cfirst ? ea1 : ea2) : pow2f(eg);
   const bool w_first = kc0 + wk * 32 < K1 || !amax2.slots;       // the multiplying wave's 32 kc columns (epilogue scale)
@@ -843,9 +885,7 @@ __global__ __launch_bounds__(2 * kThreads) void k_gemm_tn_coop(const float* __re
 
   int t = 0;
   if (cur < mend) {                              // tile 0: landed for this wave, then for all; converted into planes 0
-    if (aft < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");
-    else if (nxt < mend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");     // (three tiles are always staged)
     __builtin_amdgcn_s_barrier();
     convert(cur, 0, 0);
   }

@@ -816,6 +816,10 @@ def _encoder_vs_oracle(dev, ei, et, n, r, dims, num_bases=None, seed=0, fwd_atol
     # oracle #3: float64, explicit backward, the device's ReLU decisions
     p64 = [{k: v.detach() for k, v in rp.items()} for rp in ref_p]
     f64 = O.encoder_explicit_f64(emb, p64[0], p64[1], ei, et, cot, relu_mask=mask)
+    # the fp32 loop path adds a segment's messages one after the other: on segments of thousands of edges ITS distance
+    # from float64 exceeds the gate (fuzz case 777/109: two nodes, 5,700-edge segments, 3.0e-5), so unless a config
+    # pins the number (C2/C3: 1e-5) the gate against it is the float64 gate plus that measured distance
+    gate32 = oracle32_atol or fwd_atol + float((out_ref.detach().double() - f64["out"]).abs().max())
     outs = []
     errs = {}
     # three routes to the same numbers: separate layers + torch relu, relu fused into conv1's
@@ -837,7 +841,7 @@ def _encoder_vs_oracle(dev, ei, et, n, r, dims, num_bases=None, seed=0, fwd_atol
             for k, v in c.named_parameters():
                 assert_grad(v.grad, f64["grads"][f"{name}.{k}"])
                 assert_grad(v.grad, rp[k].grad)
-        assert_fwd(out, out_ref.detach(), oracle32_atol or fwd_atol)
+        assert_fwd(out, out_ref.detach(), gate32)
         assert_grad(e_gpu.grad, e_ref.grad)
         if route == "encoder2":
             errs = {"fwd_max_abs_vs_f64": (out.double().cpu() - f64["out"]).abs().max(),
@@ -855,6 +859,20 @@ def _encoder_vs_oracle(dev, ei, et, n, r, dims, num_bases=None, seed=0, fwd_atol
     if tag:
         _record(tag, **errs)
     return errs
+
+
+def test_two_nodes_with_segments_of_thousands_of_edges_stay_at_the_float64_gate():
+    """Fuzz case 777/109 (tools/fuzz_encoder.py): 2 nodes, 17,001 edges, 3 relations of which one is empty - every
+    segment is a hub of 2,800 ... 5,700 edges.  The device sums them as a tree and stays inside 1e-5 of float64; the fp32
+    loop restatement, which adds edge by edge, is 3e-5 away from float64 itself (measured in the helper), so the gate
+    against it widens by that distance and the float64 gate is the one that binds."""
+    dev = need_gpu()
+    g = torch.Generator().manual_seed(109)
+    ei = torch.randint(0, 2, (2, 17001), generator=g)
+    et = torch.randint(0, 2, (17001,), generator=g)                      # relation 2 has no edges
+    errs = _encoder_vs_oracle(dev, ei, et, 2, 3, (32, 32, 32), seed=109)
+    assert errs["fwd_max_abs_vs_f64"] < 1e-5
+    assert errs["oracle32_fwd_max_abs_vs_f64"] > errs["fwd_max_abs_vs_f64"]
 
 
 def test_config_c1_two_layers_vs_oracle():

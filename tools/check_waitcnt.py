@@ -31,6 +31,7 @@ _INST = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
 _TARGET = re.compile(r"<(.+)\+0x([0-9a-f]+)>\s*$")
 _REG = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
 _LGKM = re.compile(r"lgkmcnt\((\d+)\)")
+_VM = re.compile(r"vmcnt\((\d+)\)")
 
 
 class Inst:
@@ -90,6 +91,17 @@ def _is_smem(op: str) -> bool:
                           "s_atomic", "s_buffer_atomic", "s_dcache", "s_sendmsg"))
 
 
+def _is_vmem(op: str) -> bool:
+    return op.startswith(("global_", "buffer_", "flat_", "scratch_", "tbuffer_"))
+
+
+def _vmem_dest(op: str, args: str) -> FrozenSet[str]:
+    """vector registers a vector-memory operation writes when its data returns (LDS-DMA loads write none)"""
+    if "load" not in op or "_lds_" in op:
+        return frozenset()
+    return _regs(args.split(",")[0])
+
+
 def _lds_dest(op: str, args: str) -> FrozenSet[str]:
     """vector registers an LDS operation writes when its data returns"""
     returning = op.startswith(("ds_read", "ds_bpermute", "ds_permute", "ds_swizzle", "ds_consume", "ds_append",
@@ -119,9 +131,22 @@ def _merge(a, b):
 
 
 def check_function(insts: List[Inst]) -> List[str]:
-    """-> one line per instruction that touches a register with an uncovered ds_read (empty: clean)"""
+    """-> one line per instruction that touches a register with an uncovered ds_read - or an uncovered vector-memory
+    load (``VM_CNT``: round 4's transform kernels request operand maxima with ``global_load_dword`` from inline asm
+    ahead of their LDS-DMAs and cover them with a counted ``s_waitcnt vmcnt(N)``) - (empty: clean)"""
+    return _check(insts, "lgkm") + _check(insts, "vm")
+
+
+def _check(insts: List[Inst], counter: str) -> List[str]:
+    """one counter's pass: "lgkm" (LDS reads; scalar memory makes the counter out of order) or "vm" (vector-memory
+    loads, in issue order with every other vector-memory operation, LDS-DMAs and stores included - the model the
+    compiler itself uses on gfx9)"""
     if not insts:
         return []
+    vm = counter == "vm"
+    wait_re = _VM if vm else _LGKM
+    is_op = _is_vmem if vm else _is_lds
+    dest_of = _vmem_dest if vm else _lds_dest
     index = {inst.addr: i for i, inst in enumerate(insts)}
     leaders = {0}
     for i, inst in enumerate(insts):
@@ -146,7 +171,7 @@ def check_function(insts: List[Inst]) -> List[str]:
             inst = insts[i]
             op = inst.op
             if op == "s_waitcnt":
-                m = _LGKM.search(inst.args)
+                m = wait_re.search(inst.args)
                 if m:
                     n = int(m.group(1))
                     if n == 0:
@@ -154,8 +179,8 @@ def check_function(insts: List[Inst]) -> List[str]:
                     elif not smem:
                         regs = {r: age for r, age in regs.items() if age < n}
                 continue
-            if _is_lds(op):
-                dest = _lds_dest(op, inst.args)
+            if is_op(op):
+                dest = dest_of(op, inst.args)
                 srcs = _regs(inst.args.split(",", 1)[1]) if (dest and "," in inst.args) else (_regs(inst.args) - dest)
                 hit = srcs & regs.keys()
                 if hit:
@@ -164,7 +189,7 @@ def check_function(insts: List[Inst]) -> List[str]:
                 for r in dest:                       # in-order returns: a queued register is simply delivered again
                     regs[r] = 0
                 continue
-            if _is_smem(op):
+            if _is_smem(op) and not vm:
                 smem = True
                 continue
             hit = _regs(inst.args) & regs.keys()
