@@ -128,6 +128,12 @@ __device__ inline amax_loads amax_request(const amax_ref& r, int lane) {
                  "+v"(b.v[3]), "+v"(c.v[0]), "+v"(c.v[1]), "+v"(c.v[2]), "+v"(c.v[3])                                  \
                : "n"(younger)                                                                                         \
                : "memory")
+#define RGCN_AMAX_WAIT2(a, b, younger)                                                                                \
+  asm volatile("s_waitcnt vmcnt(%8)"                                                                                  \
+               : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]),     \
+                 "+v"(b.v[3])                                                                                         \
+               : "n"(younger)                                                                                         \
+               : "memory")
 __device__ inline float amax_reduce(const amax_loads& q) {
   float m = fmaxf(fmaxf(q.v[0], q.v[1]), fmaxf(q.v[2], q.v[3]));
 #pragma unroll
@@ -230,8 +236,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
   // Every workgroup of the launch starts at once and its first loads meet a cold memory system (2 us and more): the
   // operand maxima, the relation mask of the row tile and the published maximum are all requested HERE, together,
   // so that the prologue pays that latency once - the first DMAs below need the mask, the split needs the maxima.
-  const float amax1_v = amax_of(amax1, lane) * a1_mul;
-  const float amax2_v = amax2.slots ? amax_of(amax2, lane) : 0.f;
+  // (round 4: the maxima as untracked loads without a branch - amax_request - so that they really are ONE round trip
+  // together with the mask words; written as amax_of() calls each was a branch with its own vmcnt(0) behind it)
+  amax_loads q1 = amax_request(amax1, lane), q2 = amax_request(amax2.slots ? amax2 : amax1, lane);
   const unsigned seen = rgcn_amax_peek(amax_out);
   unsigned rel_mask = 0xffffffffu;
   if (tile_mask) {
@@ -242,14 +249,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_nt_split(const float* __r
       if ((t32 + q) * 32 < M) rel_mask |= tile_mask[t32 + q];
     rel_mask = __builtin_amdgcn_readfirstlane(rel_mask);
   }
+  int fin_b = 0, fin_e = 0;                      // this row tile's range of deferred hub items (below): the same round trip
+  if (WAVES == 4 && fin.ptr) {
+    fin_b = fin.ptr[min(m0 >> 5, fin.tiles)];
+    fin_e = fin.ptr[min((m0 >> 5) + WM, fin.tiles)];
+  }
+  RGCN_AMAX_WAIT2(q1, q2, 0);
+  const float amax1_v = amax_reduce(q1) * a1_mul;
+  const float amax2_v = amax2.slots ? amax_reduce(q2) : 0.f;
 
   // Hub rows of this workgroup's row tiles whose partial rows the gather left unsummed: summed here, by the whole
   // workgroup, exactly as k_reduce_partials would (same function), written to A1 and only then read back by the
   // DMAs below.  Workgroups of other column blocks of the same rows write the same values.
   if (WAVES == 4 && fin.ptr) {                   // (rgcn_reduce_item is written for 256 threads)
-    const int t32 = m0 >> 5;
-    const int jb = __builtin_amdgcn_readfirstlane(fin.ptr[min(t32, fin.tiles)]);
-    const int je = __builtin_amdgcn_readfirstlane(fin.ptr[min(t32 + WM, fin.tiles)]);
+    const int jb = __builtin_amdgcn_readfirstlane(fin_b), je = __builtin_amdgcn_readfirstlane(fin_e);
     if (je > jb) {
       float4* red = reinterpret_cast<float4*>(lds);
       float* agg = const_cast<float*>(A1);
