@@ -329,6 +329,22 @@ def test_waitcnt_checker_catches_the_bug_class():
             "v_add_f32_e32 v9, v2, v2", "s_endpgm"]
     assert len(violations(smem)) == 1                                                         # out-of-order scalar return
     assert violations(smem[:3] + ["s_waitcnt lgkmcnt(0)"] + smem[4:]) == []
+    # vector-memory loads under a counted vmcnt (round 4: operand maxima requested ahead of the LDS-DMAs of a GEMM prologue):
+    # four DMAs behind two loads - vmcnt(4) covers both loads, a copy above the wait or a DMA skipped on one path does not
+    loads = ["global_load_dword v4, v[2:3], off", "global_load_dword v5, v[2:3], off offset:256"]
+    dmas = ["global_load_lds_dwordx4 v[8:9], off"] * 4
+    assert violations(loads + dmas + ["s_waitcnt vmcnt(4)", "v_max_f32_e32 v6, v4, v5", "s_endpgm"]) == []
+    copied = loads + dmas + ["v_mov_b32_e32 v20, v5", "s_waitcnt vmcnt(4)", "v_max_f32_e32 v6, v4, v20", "s_endpgm"]
+    assert len(violations(copied)) == 1 and "v5" in violations(copied)[0]
+    assert len(violations(loads + dmas + ["s_waitcnt vmcnt(5)", "v_max_f32_e32 v6, v4, v5", "s_endpgm"])) == 1   # v5 may be in flight
+    # one DMA sits behind a branch that can skip it: on that path only three are younger than the loads
+    skipped = listing(loads + dmas[:3]) \
+        + "\ts_cbranch_execz 1                                          // 000000001014: 00000000 <k+0x1c>\n" \
+        + "\tglobal_load_lds_dwordx4 v[8:9], off                        // 000000001018: 00000000\n" \
+        + "\ts_waitcnt vmcnt(4)                                         // 00000000101C: 00000000\n" \
+        + "\tv_max_f32_e32 v6, v4, v5                                   // 000000001020: 00000000\n" \
+        + "\ts_endpgm                                                   // 000000001024: 00000000\n"
+    assert len(W.check_function(W.parse_disassembly(skipped)["k"])) == 1
 
 
 def test_editing_any_header_rebuilds_the_objects_that_include_it(tmp_path):
