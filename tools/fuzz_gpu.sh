@@ -1,10 +1,19 @@
 #!/bin/bash
-# GPU box: the regression test for fuzz case 777/109, then the two fuzz scripts on fresh seeds (progress lines, no pipes)
-set -e
+# GPU box: the four fuzz scripts on fresh seeds against the library as built (progress lines, no pipes); summaries -> gpurun_out/<tag>_fuzz.txt
+tag=${1:-r04}
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py -x -q -k "two_nodes_with_segments or config_c1" > gpurun_out/r04z_regress.log 2>&1 || { cat gpurun_out/r04z_regress.log; exit 1; }
-echo "regression test ok"
-timeout -k 10 500 python tools/fuzz_encoder.py 150 777 > gpurun_out/r04z_fuzz_777.txt 2>&1 || true
-tail -n 3 gpurun_out/r04z_fuzz_777.txt
-timeout -k 10 400 python tools/fuzz_encoder.py 120 4242 > gpurun_out/r04z_fuzz_4242.txt 2>&1 || true
-tail -n 3 gpurun_out/r04z_fuzz_4242.txt
+out=gpurun_out/${tag}_fuzz.txt
+: > $out
+run() {  # name, seconds, command ...
+  local name=$1 limit=$2; shift 2
+  echo "$name"
+  timeout -k 10 $limit "$@" > gpurun_out/${tag}_fuzz_$name.log 2>&1
+  echo "== $name (rc $?): $*" >> $out
+  grep -E "^FAIL|cases in|worst|all " gpurun_out/${tag}_fuzz_$name.log >> $out || true
+}
+run encoder_a 500 python tools/fuzz_encoder.py 160 9001
+run encoder_b 500 python tools/fuzz_encoder.py 160 9002
+run dropout 300 python tools/fuzz_dropout.py 40 9003
+run head 300 python tools/fuzz_head.py 150 9004
+run dist 400 python tools/fuzz_dist.py 100 9005
+cat $out
