@@ -9,6 +9,9 @@
 #include "rgcn_split.h"
 
 constexpr int RGCN_PACK_JOBS = 4, RGCN_PREP_TENSORS = 8;
+#ifndef RGCN_STAMP
+#define RGCN_STAMP(i)                             // (tools/pack_probe.hip builds with the stamps of rgcn_transform_split.hip)
+#endif
 
 struct rgcn_pack_job {
   const float *W, *Rt;
@@ -62,6 +65,7 @@ __device__ inline void rgcn_pack_body(const rgcn_pack_job& J, float* red, int nb
   }
   const int eb = scale_exponent(m);
   const float sb = pow2f(eb);
+  RGCN_STAMP(1);                                  // the maximum is known
   if (bid == 0 && threadIdx.x == 0) J.scale_out[0] = pow2f(-eb);
   __half* __restrict__ Bh_f = J.Bh_f;
   __half* __restrict__ Bl_f = J.Bl_f;
@@ -110,6 +114,7 @@ __device__ inline void rgcn_pack_body(const rgcn_pack_job& J, float* red, int nb
       split(vfb, J.Fh_b, J.Fl_b, (size_t)e);
     }
   }
+  RGCN_STAMP(2);                                  // every store issued
 }
 
 struct rgcn_absmax_multi_job {

@@ -32,7 +32,6 @@
 #include "rgcn_slab_reduce.h"
 #include "rgcn_hub_finish.h"
 #include "rgcn_split.h"
-#include "rgcn_prep.h"
 
 // tools/gemm_stamps.hip includes this file with RGCN_STAMPS defined: thread 0 of every workgroup then leaves the 100 MHz
 // wall clock at four points of the kernel (entry, main loop reached, main loop left, end) - where a launch's time goes.
@@ -45,6 +44,9 @@ __device__ unsigned long long g_rgcn_stamps[8192 * 4];
 #else
 #define RGCN_STAMP(i)
 #endif
+
+#include "rgcn_prep.h"
+
 
 namespace {
 
@@ -710,8 +712,14 @@ __global__ __launch_bounds__(kPackThreads) void k_absmax_pack(const absmax_multi
   __shared__ float red[kPackThreads / 64];
   // a flat grid: pack_blocks workgroups per layer first (their chain is the longer one), then the scan's
   const int b = (int)blockIdx.x, npack = pack_blocks * layers;
+  RGCN_STAMP(0);
   if (b < npack) pack_body(JJ.j[b / pack_blocks], red, pack_blocks, b % pack_blocks);
   else absmax_body<kPackThreads>(J, zero, zero_count, red, b - npack, RGCN_AMAX_HEADS);
+#ifdef RGCN_STAMPS
+  if (b >= npack) { RGCN_STAMP(1); RGCN_STAMP(2); }     // (a scanning workgroup: entry and end only)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RGCN_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -4,7 +4,12 @@ fourth step on, both forward halves and the backward issued natively - against t
 ``conv2(F.dropout(relu(conv1(x)), p))`` under the same seed: the forward bit for bit, every gradient to 2e-6.  Random
 graphs, widths, p in {0.1, 0.5, 0.8}, six steps each with fresh inputs.
 
-    python tools/fuzz_dropout.py [cases] [seed]
+    python tools/fuzz_dropout.py [cases] [seed] [only_case]
+
+The two routes take conv2's input scale from different places: the three ops scan the dropped activations for their exact
+maximum, the fused node takes the BOUND ``max |h| / (1 - p)`` from conv1's epilogue (no scan).  Both are powers of two from the
+value's exponent, so the bits agree unless every activation of the top binade was dropped - then the scales differ by a power
+of two and the outputs agree to rounding instead (reported as "scale" cases, gate 2e-6 of the largest output; seed 9003 case 11).
 """
 import os
 import sys
@@ -18,13 +23,19 @@ from primekg_rgcn_linkprediction_amd import RGCNConv, rgcn_encoder2  # noqa: E40
 dev = torch.device("cuda:0")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 gen = torch.Generator().manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 2468)
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
+
+
+def binade(v: float) -> int:
+    import math
+    return math.frexp(v)[1] if v > 0 else 0
 
 
 def rnd(lo, hi):
     return int(torch.randint(lo, hi + 1, (1,), generator=gen))
 
 
-t0, worst = time.time(), 0.0
+t0, worst, scale_cases = time.time(), 0.0, 0
 for case in range(cases):
     n = [rnd(2, 70), rnd(120, 300), rnd(1000, 20000)][rnd(0, 2)]
     r = [1, 3, 5, 16][rnd(0, 3)]
@@ -36,6 +47,12 @@ for case in range(cases):
         ei[1, torch.rand(e, generator=gen) < 0.3] = rnd(0, n - 1)        # a hub
     et = torch.randint(0, r, (e,), generator=gen)
     label = f"case {case}: n={n} e={e} r={r} dims={dims} p={p}"
+    if only is not None and case != only:                      # keep the generator in step, skip the work
+        for step in range(6):
+            torch.randn(n, dims[0], generator=gen)
+            torch.randn(n, dims[2], generator=gen)
+        continue
+    case_worst = 0.0
     try:
         torch.manual_seed(case)
         convs = [RGCNConv(dims[0], dims[1], r).to(dev), RGCNConv(dims[1], dims[2], r).to(dev)]
@@ -53,13 +70,25 @@ for case in range(cases):
             h = torch.relu(convs[0](x, eid, etd))
             want = convs[1](torch.nn.functional.dropout(h, p, True), eid, etd)
             g_want = torch.autograd.grad(want, [x] + params, cot)
-            assert torch.equal(got, want), f"forward bits at step {step}"
+            if not torch.equal(got, want):
+                # the one legitimate way for the bits to differ: the scales of conv2's input (see the header)
+                torch.manual_seed(100 * case + step)
+                hd = torch.nn.functional.dropout(torch.relu(convs[0](x, eid, etd)).detach(), p, True)
+                exact, bound = float(hd.abs().max()), float(h.detach().abs().max()) * (1.0 / (1.0 - p))
+                ferr = float((got - want).detach().abs().max()) / max(1.0, float(want.detach().abs().max()))
+                assert binade(exact) != binade(bound), (f"forward bits at step {step} although both routes scale conv2's input "
+                                                         f"alike (max {exact:.6g}, bound {bound:.6g}); distance {ferr:.2e}")
+                assert ferr <= 2e-6, f"forward {ferr:.2e} at step {step} (scales differ: max {exact:.6g}, bound {bound:.6g})"
+                scale_cases += 1
+                print(f"     {label} step {step}: max |dropped h| = {exact:.6g} against the bound {bound:.6g}: another binade, "
+                      f"outputs {ferr:.2e} apart", flush=True)
             for a, b in zip(g_got, g_want):
                 scale = float(b.abs().max())
                 err = float((a - b).abs().max()) / max(scale, 1e-30)
-                worst = max(worst, err)
+                worst, case_worst = max(worst, err), max(case_worst, err)
                 assert err <= 2e-6 or scale == 0.0, f"gradient {err:.2e} at step {step}"
-        print(f"ok   {label}", flush=True)
+        print(f"ok   {label}  (gradients within {case_worst:.1e})", flush=True)
     except Exception as exc:  # noqa: BLE001
         print(f"FAIL {label}: {type(exc).__name__}: {exc}", flush=True)
-print(f"{cases} cases in {time.time() - t0:.0f} s; worst gradient distance between the fused node and the three ops {worst:.2e}")
+print(f"{cases} cases in {time.time() - t0:.0f} s; worst gradient distance between the fused node and the three ops {worst:.2e}; "
+      f"{scale_cases} steps where the two routes scaled conv2's input by different powers of two (bits differ, values to rounding)")

@@ -1,9 +1,12 @@
 // Round 4 probe: where do the ~13 us of the first launch of a forward pass (k_absmax_pack: max |x| + both layers' split
 // weights) go?  Times the launch and its parts on C2's shapes, each as 20 back-to-back launches between events:
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/pack_probe.hip -o tools/pack_probe && tools/pack_probe
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DRGCN_STAMPS] tools/pack_probe.hip -o tools/pack_probe && tools/pack_probe
+// (with -DRGCN_STAMPS: also the in-kernel wall clock of the launch's phases, per workgroup)
 #include "../primekg_rgcn_linkprediction_amd/csrc/rgcn_transform_split.hip"
 
+#include <algorithm>
 #include <cstdio>
+#include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -61,5 +64,29 @@ int main() {
   timed([&] { rc = rgcn_absmax_multi(5, tens, nums, outs, zero, 1, stream); }, "rgcn_absmax_multi: x and the four weight tensors");
   timed([&] { rc = rgcn_weights_split_pack_multi(2, ws, rs, Rs, di, dout, wa, ra, pk, pb, zero, 1, stream); }, "rgcn_weights_split_pack_multi with given maxima (no scan: the optimizer-hinted first launch)");
   timed([&] { rc = rgcn_weights_split_pack_multi(2, ws, rs, Rs, di, dout, nullptr, nullptr, pk, pb, zero, 1, stream); }, "rgcn_weights_split_pack_multi scanning");
+#ifdef RGCN_STAMPS
+  // in-kernel wall clock (100 MHz) of one launch: entry, maximum known, stores issued, stores drained - per workgroup
+  rc = rgcn_absmax_pack(x, N * 64, ax, zero, 1, 2, ws, rs, Rs, di, dout, pk, pb, stream);
+  hipStreamSynchronize(stream);
+  std::vector<unsigned long long> st(8192 * 4);
+  hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_rgcn_stamps), st.size() * sizeof(unsigned long long));
+  const int npack = 128, total = 128 + RGCN_AMAX_HEADS;
+  unsigned long long t0 = ~0ull, t3 = 0;
+  for (int w = 0; w < total; ++w) { t0 = std::min(t0, st[w * 4]); t3 = std::max(t3, st[w * 4 + 3]); }
+  auto med = [&](int lo, int hi, auto f) {
+    std::vector<double> v;
+    for (int w = lo; w < hi; ++w) v.push_back(f(w) * 0.01);
+    std::sort(v.begin(), v.end());
+    printf(" min %5.2f median %5.2f max %5.2f us\n", v.front(), v[v.size() / 2], v.back());
+  };
+  printf("  one launch, first entry -> last exit %.2f us\n", (t3 - t0) * 0.01);
+  printf("  pack workgroups (128): entry after first entry  "); med(0, npack, [&](int w) { return (double)(st[w * 4] - t0); });
+  printf("                         entry -> maximum known   "); med(0, npack, [&](int w) { return (double)(st[w * 4 + 1] - st[w * 4]); });
+  printf("                         -> every store issued    "); med(0, npack, [&](int w) { return (double)(st[w * 4 + 2] - st[w * 4 + 1]); });
+  printf("                         -> stores drained        "); med(0, npack, [&](int w) { return (double)(st[w * 4 + 3] - st[w * 4 + 2]); });
+  printf("                         exit before last exit    "); med(0, npack, [&](int w) { return (double)(t3 - st[w * 4 + 3]); });
+  printf("  scan workgroups (256): entry after first entry  "); med(npack, total, [&](int w) { return (double)(st[w * 4] - t0); });
+  printf("                         lifetime                 "); med(npack, total, [&](int w) { return (double)(st[w * 4 + 3] - st[w * 4]); });
+#endif
   return 0;
 }
