@@ -550,6 +550,8 @@ def rgcn_conv(x: Tensor, edge_index: Tensor, edge_type: Tensor, weight: Tensor,
 def _encoder_hints(x: Tensor, conv1: "RGCNConv", conv2: "RGCNConv"):
     """the operand maxima the optimizer left (``ops.amax_hint``) for x, conv1.weight / root, conv2.weight / root - all
     of them or None (plain weights with a root, fp32 table, split precision)"""
+    if not ops._AMAX_HINTS:                       # nobody left a maximum (no native optimizer step): nothing to look up
+        return None
     if ops.GEMM_PRECISION != "split" or conv1.num_bases is not None or conv2.num_bases is not None:
         return None
     if conv1.root is None or conv2.root is None or conv1.gather_dtype not in (None, torch.float32):

@@ -1958,6 +1958,15 @@ class _Plan:
             else:
                 self._small_off.append(None)
         self._small = sum(o is not None for o in self._small_off) >= 2
+        self._small_f32 = all(dt == torch.float32 for o, (_, _, _, dt) in zip(self._small_off, self.external) if o is not None)
+
+        def dense_strides(shape):
+            st, acc = [], 1
+            for dim in reversed(shape):
+                st.append(acc)
+                acc *= dim
+            return tuple(reversed(st))
+        self._small_strides = [dense_strides(shape) for _, _, shape, _ in self.external]
         # what the recorded addresses stand for: a later call whose inputs differ in type, shape or place must not be
         # replayed (the wrappers would have refused it; the native list would read the wrong bytes)
         self.signature = rec.input_signature
@@ -1989,10 +1998,16 @@ class _Plan:
             if fill is None:
                 arena = torch.empty(self.arena_bytes, dtype=torch.uint8, device=self.device)
                 if self._small:                              # the small ones (parameter gradients) share ONE allocation
-                    slab = torch.empty(self._small_bytes, dtype=torch.uint8, device=self.device)
-                    ext = [slab[o: o + nb].view(dtype).view(shape) if o is not None else
-                           torch.empty(shape, dtype=dtype, device=self.device)
-                           for o, (_, nb, shape, dtype) in zip(self._small_off, self.external)]
+                    if self._small_f32:                      # all float32: one as_strided per output instead of slice + 2 views
+                        slab = torch.empty(self._small_bytes // 4, dtype=torch.float32, device=self.device)
+                        ext = [slab.as_strided(shape, st, o // 4) if o is not None else
+                               torch.empty(shape, dtype=dtype, device=self.device)
+                               for o, st, (_, nb, shape, dtype) in zip(self._small_off, self._small_strides, self.external)]
+                    else:
+                        slab = torch.empty(self._small_bytes, dtype=torch.uint8, device=self.device)
+                        ext = [slab[o: o + nb].view(dtype).view(shape) if o is not None else
+                               torch.empty(shape, dtype=dtype, device=self.device)
+                               for o, (_, nb, shape, dtype) in zip(self._small_off, self.external)]
                 else:
                     ext = [torch.empty(shape, dtype=dtype, device=self.device) for _, _, shape, dtype in self.external]
             else:

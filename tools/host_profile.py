@@ -69,6 +69,29 @@ issue, total = per_step(big.explicit, 200)
 print(f"explicit step (rgcn_encoder2_step: both passes, no autograd engine): C2 {issue * 1e6:.0f} us per step issued, {total * 1e6:.0f} us with the final sync")
 issue, total = per_step(small.explicit, 2000)
 print(f"explicit step (rgcn_encoder2_step: both passes, no autograd engine): 1k-node graph (host-bound) {total * 1e6:.0f} us per step")
+# Is the small graph's loop really bound by the host?  Its DEVICE time per step = the same step as a replayed HIP graph
+# (no host work between launches): twelve dependent launches have a floor of their own (each a launch boundary plus a
+# prologue's latencies), and where that floor is close to the eager figure, the eager figure is not host cost - the
+# "issued" time on C2 (the host running ahead of a busy GPU) is.
+def replayed(fn, reps=200):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(10):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps // 10):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (reps // 10 * 10)
+
+
+dev_small, dev_big = replayed(small.explicit), replayed(big.explicit)
+print(f"explicit step as a replayed HIP graph (device time alone): 1k-node graph {dev_small * 1e6:.0f} us per step, C2 {dev_big * 1e6:.0f} us")
 for name, fn in (("autograd step", small), ("explicit step", small.explicit)):
     pr = cProfile.Profile()
     pr.enable()
